@@ -1,0 +1,84 @@
+"""Residual-quantiser oracle (numpy).  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Restates rqvae/models/rqvae/quantizations.py of the reference:
+  compute_distances        :43-62   (||x||^2 + ||c||^2 - 2 x.c^T, fp32, expanded form)
+  find_nearest_embedding   :64-69   (argmin, first minimum on ties)
+  VQEmbedding.forward/embed:131-146 (gather; padding row K excluded from the search, :45)
+  RQBottleneck.quantize    :237-271 (depth loop on the residual, cumulative quants)
+  embed_code               :297-311 (cat over depth then .sum(-2))
+  embed_code_with_depth    :313-334 (no depth reduction)
+"""
+import numpy as np
+
+
+def compute_distances(x, codebook):
+    """quantizations.py:43-62.  x (..., D) fp32, codebook (K, D) fp32 (padding row
+    already dropped) -> (..., K) fp32.  Same expanded form and fp32 arithmetic as
+    torch.addmm(beta=1, alpha=-2); summation order inside the GEMM is BLAS-defined
+    on both sides, hence the 'unambiguous margin' notion in rq_quantize_margins."""
+    x = np.asarray(x, np.float32)
+    cb = np.asarray(codebook, np.float32)
+    flat = x.reshape(-1, x.shape[-1])
+    xn = (flat * flat).sum(1, keepdims=True, dtype=np.float32)
+    cn = (cb * cb).sum(1, dtype=np.float32)[None, :]
+    d = (xn + cn) + np.float32(-2.0) * (flat @ cb.T)
+    return d.reshape(*x.shape[:-1], cb.shape[0]).astype(np.float32)
+
+
+def rq_quantize(x, codebooks):
+    """quantizations.py:237-271.  x (B,h,w,D) fp32; codebooks = list (len depth) of
+    (K_i, D) fp32 arrays (same array repeated when shared_codebook).
+    Returns (quant_list: depth x (B,h,w,D) cumulative fp32, codes (B,h,w,depth) int64)."""
+    x = np.asarray(x, np.float32)
+    residual = x.copy()
+    agg = np.zeros_like(x)
+    quant_list, code_list = [], []
+    for cb in codebooks:
+        cb = np.asarray(cb, np.float32)
+        d = compute_distances(residual, cb)
+        code = d.argmin(-1)                      # first minimum, like torch.argmin
+        quant = cb[code]
+        residual = residual - quant              # residual_feature.sub_(quant)
+        agg = agg + quant                        # aggregated_quants.add_(quant)
+        quant_list.append(agg.copy())
+        code_list.append(code[..., None])
+    return quant_list, np.concatenate(code_list, -1).astype(np.int64)
+
+
+def rq_quantize_margins(x, codebooks):
+    """Exact (fp64, direct ||r-c||^2) top-2 gap per vector and depth, following the
+    oracle's own code path.  A vector/depth is 'unambiguous' when gap > tau
+    (tau = 1e-3 at D=256, N(0,1) data: SURVEY.md §8c); bit-exact code parity is
+    claimed on the prefix of depths up to the first ambiguous one."""
+    x64 = np.asarray(x, np.float64)
+    residual = x64.reshape(-1, x64.shape[-1]).copy()
+    gaps, codes = [], []
+    for cb in codebooks:
+        cb64 = np.asarray(cb, np.float64)
+        d = ((residual ** 2).sum(1)[:, None] + (cb64 ** 2).sum(1)[None, :]
+             - 2.0 * residual @ cb64.T)
+        part = np.partition(d, 1, axis=1)
+        gaps.append(part[:, 1] - part[:, 0])
+        code = d.argmin(1)
+        codes.append(code)
+        residual = residual - cb64[code]
+    shp = x64.shape[:-1]
+    return (np.stack(gaps, -1).reshape(*shp, -1),
+            np.stack(codes, -1).reshape(*shp, -1).astype(np.int64))
+
+
+def rq_embed_code(codes, codebooks):
+    """quantizations.py:297-311: sum_d codebook_d[code[..., d]] (cat then sum(-2), fp32,
+    summed in depth order)."""
+    codes = np.asarray(codes)
+    out = None
+    for i, cb in enumerate(codebooks):
+        e = np.asarray(cb, np.float32)[codes[..., i]]
+        out = e.copy() if out is None else out + e
+    return out
+
+
+def rq_embed_code_with_depth(codes, codebooks):
+    """quantizations.py:313-334: (..., depth, D), no reduction."""
+    codes = np.asarray(codes)
+    return np.stack([np.asarray(cb, np.float32)[codes[..., i]] for i, cb in enumerate(codebooks)], -2)

@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF on CPU.
+
+Run in the build container only (needs /root/reference; the GPU box never runs this):
+    python tests/golden/make_golden.py
+
+The reference (kakaobrain/rq-vae-transformer) is imported from /root/reference behind a
+stub for the one missing import (omegaconf, rqvae/models/rqtransformer/configs.py:18; the
+model classes never call it).  Weights come from oracle.weights.make_params (seeded, keyed by
+state_dict name) and are loaded with load_state_dict(strict=True), so the fixtures also pin the
+reference's key/shape tables.  Each fixture stores only seeds + reference outputs; inputs and
+weights are regenerated from the seeds by the tests.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+_m = types.ModuleType('omegaconf')
+_m.OmegaConf = type('OmegaConf', (), {})
+_m.MISSING = '???'
+_m.DictConfig = dict
+sys.modules['omegaconf'] = _m
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+from rqvae.models.rqvae import RQVAE  # noqa: E402  (reference)
+from rqvae.models.rqtransformer import RQTransformer  # noqa: E402  (reference)
+from rqvae.utils.utils import top_k_logits, top_p_probs  # noqa: E402  (reference)
+import torch.nn.functional as F  # noqa: E402
+
+import oracle  # noqa: E402
+from oracle import configs as C  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+class Cfg(dict):
+    """attribute-dict with .copy() -- all RQTransformer.__init__ needs (transformers.py:39-52)."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+    def copy(self):
+        return to_cfg(json.loads(json.dumps(self)))
+
+
+def to_cfg(d):
+    return Cfg({k: to_cfg(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def ref_rqvae(hps, dd, seed):
+    m = RQVAE(**hps, ddconfig=dd, checkpointing=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    mine = oracle.rqvae_param_shapes(hps, dd)
+    assert shapes == {k: tuple(v) for k, v in mine.items()}, 'rqvae key/shape table mismatch'
+    params = oracle.make_params(mine, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m, params
+
+
+def ref_rqt(cfg, seed):
+    m = RQTransformer(to_cfg(cfg)).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    mine = oracle.rqt_param_shapes(cfg)
+    assert shapes == {k: tuple(v) for k, v in mine.items()}, 'rqt key/shape table mismatch'
+    params = oracle.make_params(mine, seed)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return m, params
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f'  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+# ------------------------------------------------------------------ 1. residual quantiser
+def gen_rq():
+    from rqvae.models.rqvae.quantizations import RQBottleneck
+    for tag, K, Dm, N, seed in (('small', 500, 64, 192, 11), ('full', 16384, 256, 1024, 12)):
+        rng = np.random.default_rng(seed)
+        cb = rng.standard_normal((K, Dm), dtype=np.float32)
+        x = rng.standard_normal((N // 64, 8, 8, Dm), dtype=np.float32)
+        if tag == 'small':      # half the vectors near codewords (realistic margins)
+            x.reshape(-1, Dm)[::2] = cb[rng.integers(0, K, N // 2)] * 2.5 + 0.1 * x.reshape(-1, Dm)[::2]
+        rq = RQBottleneck([8, 8, Dm], [8, 8, 4], K, shared_codebook=True).eval()
+        w = np.concatenate([cb, np.zeros((1, Dm), np.float32)])
+        rq.codebooks[0].weight.data.copy_(torch.from_numpy(w))
+        quant_list, codes = rq.quantize(torch.from_numpy(x))
+        emb = rq.embed_code(codes)
+        embd, _ = rq.embed_code_with_depth(codes.reshape(N // 64, 64, 4))
+        assert torch.equal(emb, quant_list[-1])
+        gaps, codes64 = oracle.rq_quantize_margins(x, [cb] * 4)
+        oq, oc = oracle.rq_quantize(x, [cb] * 4)
+        print(f'  rq[{tag}] oracle==ref codes: {(oc == codes.numpy()).mean():.6f}, fp64==ref: '
+              f'{(codes64 == codes.numpy()).mean():.6f}, min gap {gaps.min():.2e}')
+        arrs = dict(seed=seed, K=K, D=Dm, N=N, codes=codes.numpy().astype(np.int32), gaps=gaps.astype(np.float32),
+                    quant_last_sum=quant_list[-1].numpy().astype(np.float64).sum(-1).astype(np.float32))
+        if tag == 'small':
+            arrs.update(x=x, codebook=cb, quant_list=np.stack([q.numpy() for q in quant_list]),
+                        embed_with_depth=embd.numpy())
+        save(f'rq_{tag}.npz', **arrs)
+
+
+# ------------------------------------------------------------------ 2. sampler filters
+def gen_sampler():
+    rng = np.random.default_rng(21)
+    V = 1024
+    logits = (3.0 * rng.standard_normal((8, V))).astype(np.float32)
+    logits[1, :] = np.round(logits[1, :])            # many exact ties (incl. at the k-th value)
+    logits[2, 5] = np.nan                            # NaN scrub path (utils.py:103-105)
+    logits[3, :] = 0.0                               # uniform row: every prob tied
+    logits[4, 7] = 40.0                              # one dominant token
+    cases = [(1.0, None, None), (1.0, V, 1.0), (1.0, 100, None), (0.8, 100, 0.95), (1.0, None, 0.5),
+             (1.3, 1, None), (1.0, 1024, 0.95), (0.5, 17, 0.3)]
+    out = {}
+    for i, (t, k, p) in enumerate(cases):
+        x = torch.from_numpy(logits).to(torch.float32) / t
+        if k is not None:
+            x = top_k_logits(x, k)
+        x[torch.isnan(x)] = -float('inf')
+        probs = F.softmax(x, dim=-1)
+        if p is not None:
+            probs = top_p_probs(probs, p)
+        out[f'probs_{i}'] = probs.numpy()
+        o = oracle.filtered_probs(logits, t, k, p)
+        tv = 0.5 * np.abs(o - probs.numpy()).sum(-1)
+        srt = np.abs(np.sort(o, -1) - np.sort(probs.numpy(), -1)).sum(-1)   # tie-order invariant
+        print(f'  sampler case {i} (T={t},k={k},p={p}): oracle TV to ref, tie-free rows {tv[[0, 2, 4, 5, 6, 7]].max():.2e}; '
+              f'sorted-multiset L1, all rows {srt.max():.2e}')
+    save('sampler.npz', logits=logits, cases=np.array([[t, -1 if k is None else k, -1 if p is None else p]
+                                                       for t, k, p in cases], np.float64), **out)
+
+
+# ------------------------------------------------------------------ 3. tiny RQ-VAE + full-size decode/encode
+def gen_vae():
+    hps, dd = C.VAE_TINY
+    m, params = ref_rqvae(hps, dd, seed=31)
+    rng = np.random.default_rng(32)
+    x = np.clip(rng.standard_normal((2, 3, 16, 16), dtype=np.float32), -1, 1)
+    z_e = m.encode(torch.from_numpy(x))
+    out, loss, codes = m(torch.from_numpy(x))
+    dec = m.decode_code(codes)
+    ov = oracle.RQVAEOracle(hps, dd, params)
+    print(f'  vae[tiny] oracle vs ref: encode {rel(ov.encode(x), z_e.numpy()):.2e}, '
+          f'decode_code {rel(ov.decode_code(codes.numpy()), dec.numpy()):.2e}, '
+          f'codes equal {(ov.get_codes(x) == codes.numpy()).mean():.4f}')
+    save('vae_tiny.npz', seed=31, x=x, z_e=z_e.numpy(), codes=codes.numpy().astype(np.int32), decode_code=dec.numpy(),
+         forward_out=out.numpy(), loss=np.float32(loss.item()))
+
+    for tag, (hps, dd) in (('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)):
+        m, params = ref_rqvae(hps, dd, seed=33)
+        rng = np.random.default_rng(34)
+        codes = rng.integers(0, hps['n_embed'], (1, 8, 8, 4))
+        dec = m.decode_code(torch.from_numpy(codes)).numpy()
+        x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
+        z_e = m.encode(torch.from_numpy(x)).numpy()
+        ecodes = m.get_codes(torch.from_numpy(x)).numpy()
+        ov = oracle.RQVAEOracle(hps, dd, params)
+        print(f'  vae[{tag}] oracle vs ref: decode_code {rel(ov.decode_code(codes), dec):.2e}, '
+              f'encode {rel(ov.encode(x), z_e):.2e}; |dec| max {np.abs(dec).max():.3f} std {dec.std():.3f}')
+        save(f'vae_{tag}.npz', seed=33, data_seed=34, codes=codes.astype(np.int32), decode_code=dec.astype(np.float16),
+             z_e=z_e, enc_codes=ecodes.astype(np.int32), dec_absmax=np.float32(np.abs(dec).max()))
+
+
+# ------------------------------------------------------------------ 4. tiny RQ-Transformer
+def gen_rqt():
+    hps, dd = C.VAE_TINY
+    vae, vparams = ref_rqvae(hps, dd, seed=31)
+    cb = vparams['quantizer.codebooks.0.weight'][:-1]
+    for tag, cfg, B in (('tiny', C.RQT_TINY, 3),):
+        m, params = ref_rqt(cfg, seed=41)
+        H, W, D = cfg['block_size']
+        rng = np.random.default_rng(42)
+        codes = rng.integers(0, cfg['vocab_size'], (B, H, W, D))
+        cond = rng.integers(0, cfg['vocab_size_cond'], (B, 1))
+        tc, tcond = torch.from_numpy(codes), torch.from_numpy(cond)
+        logits = m(tc, vae, cond=tcond).numpy()
+        # cached path == uncached path (the reference's built-in self check, transformers.py:352-356)
+        m.init_cache()
+        cl = np.zeros_like(logits)
+        for h in range(H):
+            for w in range(W):
+                for d in range(D):
+                    cl[:, h, w, d] = m.cached_forward(tc[:, :h + 1], vae, cond=tcond, sample_loc=(h, w, d)).numpy()
+        m.init_cache()
+        print(f'  rqt[{tag}] ref cached vs uncached logits: {np.abs(cl - logits).max():.2e}')
+        orc = oracle.RQTransformerOracle(cfg, params)
+        ol = orc.forward(codes, [cb] * D, cond)
+        print(f'  rqt[{tag}] oracle forward vs ref: {np.abs(ol - logits).max():.2e} (|logits| max {np.abs(logits).max():.2f})')
+        orc.init_cache()
+        oc = np.stack([orc.cached_forward(codes[:, :h + 1], [cb] * D, cond, (h, w, d))
+                       for h in range(H) for w in range(W) for d in range(D)], 1).reshape(logits.shape)
+        print(f'  rqt[{tag}] oracle cached vs ref: {np.abs(oc - logits).max():.2e}')
+        # start_loc > 0 prefill path (transformers.py:235-239)
+        m.init_cache()
+        pl = m.cached_forward(tc[:, :2], vae, cond=tcond, sample_loc=(1, 2, 0)).numpy()
+        m.init_cache()
+        print(f'  rqt[{tag}] ref prefill(start_loc=(1,2)) vs teacher-forced: {np.abs(pl - logits[:, 1, 2, 0]).max():.2e}')
+        save(f'rqt_{tag}.npz', seed=41, vae_seed=31, codes=codes.astype(np.int32), cond=cond.astype(np.int32),
+             logits=logits)
+
+
+def gen_param_counts():
+    counts = {}
+    for name in C.PARAM_COUNTS_M:
+        cfg = getattr(C, name)
+        with torch.device('meta'):
+            m = RQTransformer(to_cfg(cfg))
+        n = sum(p.numel() for p in m.parameters())
+        mine = sum(int(np.prod(s)) for s in oracle.rqt_param_shapes(cfg).values())
+        counts[name] = [n, mine]
+        print(f'  {name}: reference {n / 1e6:.1f} M, shape table {mine / 1e6:.1f} M')
+        assert n == mine
+    with open(os.path.join(HERE, 'param_counts.json'), 'w') as f:
+        json.dump(counts, f, indent=1)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'counts']
+    for w in which:
+        print(f'[{w}]')
+        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'counts': gen_param_counts}[w]()

@@ -1,0 +1,112 @@
+"""Pin the numpy oracle against fixtures produced by the reference itself
+(tests/golden/make_golden.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import configs as C
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _rq_inputs(g):
+    rng = np.random.default_rng(int(g['seed']))
+    K, D, N = int(g['K']), int(g['D']), int(g['N'])
+    cb = rng.standard_normal((K, D), dtype=np.float32)
+    x = rng.standard_normal((N // 64, 8, 8, D), dtype=np.float32)
+    return x, cb
+
+
+def test_rq_small(golden):
+    g = golden('rq_small.npz')
+    x, cb = g['x'], g['codebook']
+    quant_list, codes = oracle.rq_quantize(x, [cb] * 4)
+    assert np.array_equal(codes, g['codes'])                       # bit-exact indices
+    assert np.array_equal(np.stack(quant_list), g['quant_list'])   # bit-exact fp32 cumulative quants
+    assert np.array_equal(oracle.rq_embed_code(codes, [cb] * 4), g['quant_list'][-1])
+    assert np.array_equal(oracle.rq_embed_code_with_depth(codes.reshape(-1, 64, 4), [cb] * 4), g['embed_with_depth'])
+    gaps, c64 = oracle.rq_quantize_margins(x, [cb] * 4)
+    assert np.array_equal(c64, g['codes'])
+    np.testing.assert_allclose(gaps, g['gaps'], rtol=1e-4, atol=1e-5)
+
+
+def test_rq_full_size(golden):
+    g = golden('rq_full.npz')
+    x, cb = _rq_inputs(g)
+    quant_list, codes = oracle.rq_quantize(x, [cb] * 4)
+    assert np.array_equal(codes, g['codes'])
+    np.testing.assert_allclose(quant_list[-1].astype(np.float64).sum(-1), g['quant_last_sum'], rtol=0, atol=1e-3)
+
+
+def test_sampler_filters(golden):
+    g = golden('sampler.npz')
+    tie_free = [0, 2, 4, 5, 6, 7]          # rows 1 (rounded logits) and 3 (uniform) have exact ties
+    for i, (t, k, p) in enumerate(g['cases']):
+        ref = g[f'probs_{i}']
+        o = oracle.filtered_probs(g['logits'], t, None if k < 0 else int(k), None if p < 0 else float(p))
+        assert 0.5 * np.abs(o - ref).sum(-1)[tie_free].max() < 2e-6
+        # tie rows: which of several equal probabilities survives top-p is sort-order defined
+        # (SURVEY §3.3); the multiset of kept probabilities is not.
+        assert np.abs(np.sort(o, -1) - np.sort(ref, -1)).sum(-1).max() < 5e-5
+        assert np.array_equal((o > 0).sum(-1), (ref > 0).sum(-1)) or p == 1.0
+
+
+def test_vae_tiny(golden):
+    g = golden('vae_tiny.npz')
+    hps, dd = C.VAE_TINY
+    ov = oracle.RQVAEOracle(hps, dd, oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed'])))
+    np.testing.assert_allclose(ov.encode(g['x']), g['z_e'], rtol=0, atol=2e-5)
+    assert np.array_equal(ov.get_codes(g['x']), g['codes'])
+    np.testing.assert_allclose(ov.decode_code(g['codes']), g['decode_code'], rtol=0, atol=2e-5)
+    out, loss, codes = ov.forward(g['x'])
+    np.testing.assert_allclose(out, g['forward_out'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-5)
+
+
+@pytest.mark.slow
+def test_vae_imagenet_decode(golden):
+    g = golden('vae_imagenet.npz')
+    hps, dd = C.VAE_IMAGENET
+    ov = oracle.RQVAEOracle(hps, dd, oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed'])))
+    dec = ov.decode_code(g['codes'])
+    # fixture is stored as fp16: tolerance = fp16 rounding of |x| <= 4.3
+    np.testing.assert_allclose(dec, g['decode_code'].astype(np.float32), rtol=0, atol=3e-3)
+
+
+def test_rqt_tiny(golden):
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    orc = oracle.RQTransformerOracle(cfg, oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed'])))
+    codes, cond = g['codes'].astype(np.int64), g['cond'].astype(np.int64)
+    np.testing.assert_allclose(orc.forward(codes, [cb] * 4, cond), g['logits'], rtol=0, atol=1e-5)
+    H, W, D = cfg['block_size']
+    orc.init_cache()
+    for h in range(H):
+        for w in range(W):
+            for d in range(D):
+                lg = orc.cached_forward(codes[:, :h + 1], [cb] * 4, cond, (h, w, d))
+                np.testing.assert_allclose(lg, g['logits'][:, h, w, d], rtol=0, atol=1e-5)
+    # start_loc prefill path
+    orc.init_cache()
+    lg = orc.cached_forward(codes[:, :2], [cb] * 4, cond, (1, 2, 0))
+    np.testing.assert_allclose(lg, g['logits'][:, 1, 2, 0], rtol=0, atol=1e-5)
+
+
+def test_param_counts():
+    """README.md:38-47 of the reference: structural known answers."""
+    with open(os.path.join(GOLDEN, 'param_counts.json')) as f:
+        ref = json.load(f)
+    for name, want_m in C.PARAM_COUNTS_M.items():
+        n = sum(int(np.prod(s)) for s in oracle.rqt_param_shapes(getattr(C, name)).values())
+        assert n == ref[name][0]
+        assert abs(n / 1e6 - want_m) < 0.06
+    hps, dd = C.VAE_IMAGENET
+    shapes = oracle.rqvae_param_shapes(hps, dd)
+    n = sum(int(np.prod(s)) for k, s in shapes.items()
+            if 'ema' not in k and not any(k.startswith(f'quantizer.codebooks.{i}.') for i in (1, 2, 3)))
+    assert abs(n / 1e6 - 104.4) < 0.06
