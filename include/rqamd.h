@@ -1,0 +1,140 @@
+/* rqamd.h -- C ABI of librqamd.so: the MI355X (gfx950) RQ-VAE + RQ-Transformer sampling path.
+ *
+ * The reference (kakaobrain/rq-vae-transformer) is pure Python on PyTorch and has no FFI or
+ * operator registry; its "operator API" for this path is the Python method surface
+ * of rqvae.models.  Each entry point below names the reference method(s) it stands
+ * behind (file:line relative to the reference root).  The host-side mirror of those classes lives in
+ * rq-vae-transformer_amd/rqvae/ and binds this ABI with ctypes.
+ *
+ * Conventions
+ *  - plain C: device pointers, sizes, an opaque stream (hipStream_t passed as void*; NULL = stream 0).
+ *  - every call is asynchronous on `stream` unless stated; the library never frees or keeps caller
+ *    buffers beyond the call, except the parameter tables of the engine handles (see *_set_param).
+ *  - return 0 on success, negative rqamd_status otherwise; rqamd_last_error() gives the message
+ *    (thread-local).  Nothing is thrown across the ABI.
+ *  - tensors are dense, row-major, in the layouts the reference methods use.
+ */
+#ifndef RQAMD_H
+#define RQAMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQAMD_ABI_VERSION 1
+
+typedef enum {
+    RQAMD_OK = 0,
+    RQAMD_ERR_INVALID = -1,      /* bad argument / shape (reference raises ValueError / AssertionError) */
+    RQAMD_ERR_UNSUPPORTED = -2,  /* shape outside what the gfx950 kernels implement */
+    RQAMD_ERR_HIP = -3,          /* HIP runtime error */
+    RQAMD_ERR_STATE = -4         /* handle not ready (missing parameters) */
+} rqamd_status;
+
+int rqamd_abi_version(void);
+const char* rqamd_last_error(void);
+
+/* ---- residual quantiser -------------------------------------------------------------------
+ * rqamd_rq_quantize <- RQBottleneck.quantize (rqvae/models/rqvae/quantizations.py:237-271), i.e.
+ * VQEmbedding.compute_distances :43-62 + find_nearest_embedding :64-69 + embed :144-146 fused over
+ * all depths.  x (n_vec, dim) fp32; codebooks[d] (n_embed[d], dim) fp32 WITHOUT the padding row
+ * (pass weight[:-1]); the same pointer repeated = shared codebook.  codes (n_vec, depth) int64;
+ * quant_cum (depth, n_vec, dim) fp32 cumulative quants (quant_list) or NULL.
+ * Distances use the reference's expanded form ||x||^2+||c||^2-2x.c in fp32; ties -> lowest index. */
+int rqamd_rq_quantize(const float* x, const float* const* codebooks, const int* n_embed, int depth,
+                      int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream);
+
+/* rqamd_rq_embed <- RQBottleneck.embed_code :297-311 (mode 0: sum over depth),
+ * embed_code_with_depth :313-334 (mode 1: (n_vec, depth, dim)), and the depth-cumsum the sampler
+ * feeds to head_mlp (transformers.py:157-160; mode 2).  codes (n_vec, depth) int64; out fp32.
+ * Out-of-range codes are an error in the reference (index error); here they clamp to the zero
+ * padding row semantics: code == n_embed selects zeros, anything else out of range -> RQAMD_ERR_INVALID
+ * is NOT detectable asynchronously, so callers validate (the Python mirror asserts). */
+int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,
+                   int64_t n_vec, int dim, int mode, float* out, void* stream);
+
+/* ---- sampler ------------------------------------------------------------------------------
+ * rqamd_sample_logits <- sample_from_logits / top_k_logits / top_p_probs (rqvae/utils/utils.py:60-123):
+ * fp32, /temperature, keep logits >= k-th largest (ties kept), NaN -> -inf, softmax, nucleus filter
+ * (first token whose inclusive cumulative mass reaches p is kept), renormalise, one multinomial draw
+ * per row by the exponential race max_i p_i/E_i (the algorithm torch.multinomial uses for one sample)
+ * on Philox4x32-10 keyed by (seed, offset).  No host synchronisation.  top_k <= 0 or >= vocab: no
+ * top-k; top_p < 0: no nucleus step (top_p = 1.0 still runs it, as the reference does,
+ * transformers.py:323-324).  probs_out (rows, vocab) fp32 receives the filtered distribution
+ * (parity hook) or NULL; samples_out (rows) int64 or NULL. */
+int rqamd_sample_logits(const float* logits, int rows, int vocab, float temperature, int top_k,
+                        float top_p, uint64_t seed, uint64_t offset, int64_t* samples_out,
+                        float* probs_out, void* stream);
+
+/* ---- RQ-VAE encoder / decoder engine -------------------------------------------------------
+ * Handle = packed bf16 weights + activation workspace for Encoder/Decoder (modules.py:10-202),
+ * quant_conv / post_quant_conv (rqvae.py:68-69).  Parameters are pushed by their reference
+ * state_dict names ("decoder.up.3.block.1.conv2.weight", ...), fp32 device pointers in torch layout. */
+typedef struct rqamd_vae rqamd_vae;
+typedef struct {
+    int ch, out_ch, in_channels, resolution, z_channels, num_res_blocks;
+    int n_levels;             /* len(ch_mult) */
+    int ch_mult[8];
+    int n_attn_res;
+    int attn_resolutions[8];
+    int embed_dim;            /* RQVAE embed_dim (quant_conv out / post_quant_conv in) */
+    int double_z;
+} rqamd_vae_config;
+
+int rqamd_vae_create(const rqamd_vae_config* cfg, rqamd_vae** out);
+int rqamd_vae_destroy(rqamd_vae* h);
+/* copies + repacks (fp32 -> bf16, OIHW -> O,kh,kw,I) on `stream`; the source may be freed after
+ * the stream reaches this point. */
+int rqamd_vae_set_param(rqamd_vae* h, const char* name, const float* dev_ptr, const int64_t* shape,
+                        int ndim, void* stream);
+/* rqamd_vae_decode <- RQVAE.decode (rqvae.py:85-89) + Decoder.forward (modules.py:171-202):
+ * z_q (batch, h, w, embed_dim) fp32 NHWC -> out (batch, out_ch, H, W) fp32 NCHW. */
+int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float* out, void* stream);
+/* rqamd_vae_encode <- RQVAE.encode (rqvae.py:80-83) + Encoder.forward (modules.py:73-98):
+ * x (batch, in_channels, H, W) fp32 NCHW -> z_e (batch, h, w, embed_dim) fp32 NHWC. */
+int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* z_e, void* stream);
+
+/* ---- RQ-Transformer sampling engine --------------------------------------------------------
+ * Handle = packed bf16 weights, fixed-capacity KV caches, device-side step state and (optionally)
+ * captured hipGraphs for RQTransformer.sample / cached_forward (transformers.py:190-369),
+ * AttentionStack/AttentionBlock/MultiSelfAttention (attentions.py:39-169) and the classifier. */
+typedef struct rqamd_rqt rqamd_rqt;
+typedef struct {
+    int embed_dim, n_head;
+    int n_layer_body, n_layer_head;
+    int vocab_size;           /* shared classifier / codebook size */
+    int input_embed_dim;      /* codebook dim fed to input_mlp/head_mlp */
+    int vocab_size_cond, block_size_cond;
+    int H, W, D;              /* block_size */
+    int gelu_v2;              /* attentions.py:25-36: 0 = exact erf GELU ('v1'), 1 = x*sigmoid(1.702x) */
+} rqamd_rqt_config;
+
+int rqamd_rqt_create(const rqamd_rqt_config* cfg, rqamd_rqt** out);
+int rqamd_rqt_destroy(rqamd_rqt* h);
+int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* dev_ptr, const int64_t* shape,
+                        int ndim, void* stream);
+/* rqamd_rqt_sample <- RQTransformer.sample (transformers.py:294-369) with cached=True:
+ * partial (batch,H,W,D) int64 (not modified); cond (batch, block_size_cond) int64 or NULL (zeros);
+ * codebooks[d] (n_embed, input_embed_dim) fp32 without padding row (model_aux.get_code_emb_with_depth);
+ * top_k[D] / top_p[D] per-depth lists already normalised as transformers.py:314-330 does;
+ * codes_out (batch,H,W,D) int64.  use_graph != 0 replays one captured hipGraph per (h,w). */
+int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, int batch,
+                     const float* const* codebooks, int start_h, int start_w, float temperature,
+                     const int* top_k, const float* top_p, uint64_t seed, uint64_t offset,
+                     int use_graph, int64_t* codes_out, void* stream);
+/* rqamd_rqt_logits <- the same cached_forward stepping (transformers.py:190-287) driven
+ * teacher-forced over given codes, returning every step's logits: logits_out (batch,H,W,D,vocab) fp32.
+ * This is the parity hook against RQTransformer.forward (transformers.py:113-188). */
+int rqamd_rqt_logits(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
+                     const float* const* codebooks, float* logits_out, void* stream);
+/* timing hook for bench.py: average device time (ms) of the engine's weight-streaming GEMM launches
+ * during the last rqamd_rqt_sample call is not observable from outside the stream, so the engine can
+ * bracket every GEMM launch of one call with HIP events (profile != 0 disables graphs for that call). */
+int rqamd_rqt_set_profile(rqamd_rqt* h, int profile);
+int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_launches,
+                          double* gemm_bytes_total, double* gemm_flops_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQAMD_H */

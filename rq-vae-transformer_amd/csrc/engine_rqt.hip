@@ -1,0 +1,505 @@
+// engine_rqt.hip -- RQ-Transformer sampling engine (host side of the decode loop, gfx950).
+//
+// Stands behind RQTransformer.sample / cached_forward (rqvae/models/rqtransformer/transformers.py:190-369),
+// AttentionStack.cached_forward / AttentionBlock.cached_forward / MultiSelfAttention.forward
+// (attentions.py:60-104,134-142,162-165) and the classifier (transformers.py:90-99,278-285).
+//
+// Differences from the reference's eager loop, none of which change the math beyond rounding:
+//  * only the NEW position is embedded (the reference re-embeds the whole prefix every step,
+//    transformers.py:218-225,249-257); sum_d (W e_d + b) is computed as W (sum_d e_d) + D*b,
+//  * q/k/v projections are one GEMM over the row-concatenated weight [query;key;value],
+//  * the KV cache has fixed capacity and is appended in place (the reference torch.cat's it, :75-76),
+//  * residual adds, split-K reduction and LayerNorm are one kernel (resid_ln),
+//  * every step-dependent quantity (spatial position, RNG offset) lives in device memory, so the
+//    per-position launch sequence (1 body step + D head steps + D sampler calls) is identical for
+//    every position and can be captured once as a hipGraph and replayed H*W-1 times; the sampler has
+//    no host synchronisation (the reference syncs once per step, rqvae/utils/utils.py:103).
+//  * weights are bf16 (fp32 accumulate, fp32 residual stream / LayerNorm / softmax / logits).
+#include <string.h>
+#include <string>
+#include <vector>
+#include "gemm.h"
+#include "rq_common.h"
+#include "rqt_kernels.h"
+
+struct RqtLayer {
+    bf16_t *wqkv, *wproj, *wfc1, *wfc2;
+    float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
+    bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
+};
+
+struct GemmProfile {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double bytes = 0, flops = 0;
+    double ms_total = 0;
+    int64_t launches = 0;
+};
+
+struct rqamd_rqt {
+    rqamd_rqt_config cfg;
+    int E, HW, D, V, Din, cond_len, Tbody;
+    DevBuf arena;                 // all parameters
+    std::vector<RqtLayer> body, head;
+    bf16_t *w_in, *w_headin, *w_cls;
+    float *b_in, *b_headin, *b_cls, *cls_lnw, *cls_lnb;
+    float *cond_emb, *pos_cond, *pos_hw, *pos_d;
+    float *body_in_bias, *head_in_bias;   // [HW][E], [D][E] derived tables
+    bool tables_dirty = true;
+    std::vector<std::string> seen;
+    size_t n_required = 0;
+
+    // workspace for `cap` rows
+    int cap = 0;
+    DevBuf ws, kv;
+    float *x, *xh, *slabs, *logits;
+    bf16_t *y, *qkv, *ya, *hbuf, *ain;
+    int64_t *xs, *cond;
+    int* st;            // [0] = spatial position
+    uint64_t* rng;      // {seed, offset}
+    int max_slabs = 8;
+
+    // graph cache
+    hipGraphExec_t gexec = nullptr;
+    struct Key { int B; float T; int tk[8]; float tp[8]; const float* cb[8]; void* stream; } gkey;
+    bool gvalid = false;
+
+    GemmProfile prof;
+};
+
+// -------------------------------------------------------------------------------------------------
+__global__ void bias_table_kernel(const float* bias, float scale, const float* pos, float* out, int rows, int E) {
+    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)rows * E) return;
+    int e = (int)(gid % E);
+    out[gid] = scale * bias[e] + pos[gid];
+}
+__global__ void set_rng_kernel(uint64_t* rng, uint64_t seed, uint64_t offset) {
+    if (threadIdx.x == 0) { rng[0] = seed; rng[1] = offset; }
+}
+
+static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+
+extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
+    if (!c || !out) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: null argument");
+    if (c->embed_dim != c->n_head * 64)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: head_dim must be 64 (embed_dim=%d n_head=%d)", c->embed_dim, c->n_head);
+    if (c->embed_dim % 64 || c->input_embed_dim % 64 || c->embed_dim > 4096)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: embed_dim / input_embed_dim must be multiples of 64, embed_dim <= 4096");
+    if (c->n_layer_body < 1 || c->n_layer_head < 1)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: needs >= 1 body and head layer (depth-1 'vqgan' variants unsupported)");
+    if (c->D < 1 || c->D > 8 || c->H < 1 || c->W < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: bad block_size");
+    rqamd_rqt* h = new rqamd_rqt();
+    h->cfg = *c;
+    h->E = c->embed_dim; h->HW = c->H * c->W; h->D = c->D; h->V = c->vocab_size; h->Din = c->input_embed_dim;
+    h->cond_len = c->block_size_cond < 1 ? 1 : c->block_size_cond;
+    h->Tbody = h->HW + h->cond_len - 1;
+    if (h->Tbody > 256) { delete h; return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: context %d > 256", h->Tbody); }
+    const size_t E = h->E, V = h->V, Din = h->Din;
+    const int vc = c->vocab_size_cond < 1 ? 1 : c->vocab_size_cond;
+    const size_t per_layer = al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2) + al(3 * E * 4) + al(4 * E * 4) + 6 * al(E * 4);
+    size_t total = per_layer * (c->n_layer_body + c->n_layer_head) + 2 * al(E * Din * 2) + al(V * E * 2) + 4 * al(E * 4) + al(V * 4)
+                   + al(vc * E * 4) + al(h->cond_len * E * 4) + 2 * al(h->HW * E * 4) + 2 * al(h->D * E * 4);
+    if (h->arena.reserve(total) != RQAMD_OK) { delete h; return RQAMD_ERR_HIP; }
+    char* p = (char*)h->arena.p;
+    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
+    auto mk = [&](std::vector<RqtLayer>& v, int n) {
+        v.resize(n);
+        for (auto& L : v) {
+            L.wqkv = (bf16_t*)take(3 * E * E * 2); L.wproj = (bf16_t*)take(E * E * 2);
+            L.wfc1 = (bf16_t*)take(4 * E * E * 2); L.wfc2 = (bf16_t*)take(4 * E * E * 2);
+            L.bqkv = (float*)take(3 * E * 4); L.bfc1 = (float*)take(4 * E * 4);
+            L.bproj = (float*)take(E * 4); L.bfc2 = (float*)take(E * 4);
+            L.ln1w = (float*)take(E * 4); L.ln1b = (float*)take(E * 4); L.ln2w = (float*)take(E * 4); L.ln2b = (float*)take(E * 4);
+            L.kc = L.vc = nullptr;
+        }
+    };
+    mk(h->body, c->n_layer_body);
+    mk(h->head, c->n_layer_head);
+    h->w_in = (bf16_t*)take(E * Din * 2); h->w_headin = (bf16_t*)take(E * Din * 2); h->w_cls = (bf16_t*)take(V * E * 2);
+    h->b_in = (float*)take(E * 4); h->b_headin = (float*)take(E * 4); h->cls_lnw = (float*)take(E * 4); h->cls_lnb = (float*)take(E * 4);
+    h->b_cls = (float*)take(V * 4);
+    h->cond_emb = (float*)take(vc * E * 4); h->pos_cond = (float*)take(h->cond_len * E * 4);
+    h->pos_hw = (float*)take(h->HW * E * 4); h->body_in_bias = (float*)take(h->HW * E * 4);
+    h->pos_d = (float*)take(h->D * E * 4); h->head_in_bias = (float*)take(h->D * E * 4);
+    h->n_required = 4 + 4 + 4 + 12 * 2 * 0;   // filled below
+    h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + 4 /*mlps*/ + 4 /*classifier*/ + (size_t)16 * (c->n_layer_body + c->n_layer_head);
+    *out = h;
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_rqt_destroy(rqamd_rqt* h) {
+    if (!h) return RQAMD_OK;
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto e : h->prof.ev) (void)hipEventDestroy(e);
+    delete h;
+    return RQAMD_OK;
+}
+
+static long numel(const int64_t* shape, int ndim) {
+    long n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+}
+
+extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* src, const int64_t* shape, int ndim, void* stream) {
+    if (!h || !name || !src || !shape) return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = numel(shape, ndim);
+    const long E = h->E;
+    std::string s(name);
+    auto expect = [&](long want) -> int {
+        if (n != want) return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param(%s): %ld elements, expected %ld", name, n, want);
+        return RQAMD_OK;
+    };
+    auto f32copy = [&](float* dst, long want) -> int {
+        RQ_TRY(expect(want));
+        RQ_HIP(hipMemcpyAsync(dst, src, want * 4, hipMemcpyDeviceToDevice, st));
+        return RQAMD_OK;
+    };
+    auto bf16copy = [&](bf16_t* dst, long want) -> int {
+        RQ_TRY(expect(want));
+        return rq_launch_cvt_bf16(src, dst, want, st);
+    };
+    int rc = RQAMD_OK;
+    bool known = true;
+    const int vc = h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond;
+    if (s == "pos_emb_cond") rc = f32copy(h->pos_cond, h->cond_len * E);
+    else if (s == "pos_emb_hw") rc = f32copy(h->pos_hw, h->HW * E);
+    else if (s == "pos_emb_d") rc = f32copy(h->pos_d, h->D * E);
+    else if (s == "cond_emb.weight") rc = f32copy(h->cond_emb, vc * E);
+    else if (s == "input_mlp.weight") rc = bf16copy(h->w_in, E * h->Din);
+    else if (s == "input_mlp.bias") rc = f32copy(h->b_in, E);
+    else if (s == "head_mlp.weight") rc = bf16copy(h->w_headin, E * h->Din);
+    else if (s == "head_mlp.bias") rc = f32copy(h->b_headin, E);
+    else if (s == "classifier.layer_norm.weight") rc = f32copy(h->cls_lnw, E);
+    else if (s == "classifier.layer_norm.bias") rc = f32copy(h->cls_lnb, E);
+    else if (s == "classifier.linear.weight") rc = bf16copy(h->w_cls, (long)h->V * E);
+    else if (s == "classifier.linear.bias") rc = f32copy(h->b_cls, h->V);
+    else if (s.rfind("cond_classifier.", 0) == 0) return RQAMD_OK;     // forward()-only head (transformers.py:150-153)
+    else {
+        std::vector<RqtLayer>* stack = nullptr;
+        size_t off = 0;
+        if (s.rfind("body_transformer.blocks.", 0) == 0) { stack = &h->body; off = strlen("body_transformer.blocks."); }
+        else if (s.rfind("head_transformer.blocks.", 0) == 0) { stack = &h->head; off = strlen("head_transformer.blocks."); }
+        if (!stack) known = false;
+        else {
+            size_t dot = s.find('.', off);
+            int li = atoi(s.substr(off, dot - off).c_str());
+            if (dot == std::string::npos || li < 0 || li >= (int)stack->size())
+                return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param: bad layer index in %s", name);
+            RqtLayer& L = (*stack)[li];
+            std::string leaf = s.substr(dot + 1);
+            if (leaf == "ln1.weight") rc = f32copy(L.ln1w, E);
+            else if (leaf == "ln1.bias") rc = f32copy(L.ln1b, E);
+            else if (leaf == "ln2.weight") rc = f32copy(L.ln2w, E);
+            else if (leaf == "ln2.bias") rc = f32copy(L.ln2b, E);
+            else if (leaf == "attn.query.weight") rc = bf16copy(L.wqkv, E * E);
+            else if (leaf == "attn.key.weight") rc = bf16copy(L.wqkv + E * E, E * E);
+            else if (leaf == "attn.value.weight") rc = bf16copy(L.wqkv + 2 * E * E, E * E);
+            else if (leaf == "attn.query.bias") rc = f32copy(L.bqkv, E);
+            else if (leaf == "attn.key.bias") rc = f32copy(L.bqkv + E, E);
+            else if (leaf == "attn.value.bias") rc = f32copy(L.bqkv + 2 * E, E);
+            else if (leaf == "attn.proj.weight") rc = bf16copy(L.wproj, E * E);
+            else if (leaf == "attn.proj.bias") rc = f32copy(L.bproj, E);
+            else if (leaf == "mlp.0.weight") rc = bf16copy(L.wfc1, 4 * E * E);
+            else if (leaf == "mlp.0.bias") rc = f32copy(L.bfc1, 4 * E);
+            else if (leaf == "mlp.2.weight") rc = bf16copy(L.wfc2, 4 * E * E);
+            else if (leaf == "mlp.2.bias") rc = f32copy(L.bfc2, E);
+            else known = false;
+        }
+    }
+    if (!known) return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param: unknown parameter %s", name);
+    if (rc != RQAMD_OK) return rc;
+    bool dup = false;
+    for (auto& k : h->seen) if (k == s) { dup = true; break; }
+    if (!dup) h->seen.push_back(s);
+    h->tables_dirty = true;
+    return RQAMD_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+static int ensure_batch(rqamd_rqt* h, int B) {
+    if (B <= h->cap) return RQAMD_OK;
+    const size_t E = h->E, V = h->V;
+    const size_t rows = (size_t)B;
+    size_t total = 2 * al(rows * E * 4) + al((size_t)h->max_slabs * rows * E * 4) + al(rows * V * 4) + 2 * al(rows * E * 2) + al(rows * 3 * E * 2)
+                   + al(rows * 4 * E * 2) + al(rows * h->Din * 2) + al(rows * h->HW * h->D * 8) + al(rows * h->cond_len * 8) + al(64) + al(64);
+    RQ_TRY(h->ws.reserve(total));
+    char* p = (char*)h->ws.p;
+    auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
+    h->x = (float*)take(rows * E * 4); h->xh = (float*)take(rows * E * 4);
+    h->slabs = (float*)take((size_t)h->max_slabs * rows * E * 4);
+    h->logits = (float*)take(rows * V * 4);
+    h->y = (bf16_t*)take(rows * E * 2); h->ya = (bf16_t*)take(rows * E * 2);
+    h->qkv = (bf16_t*)take(rows * 3 * E * 2); h->hbuf = (bf16_t*)take(rows * 4 * E * 2);
+    h->ain = (bf16_t*)take(rows * h->Din * 2);
+    h->xs = (int64_t*)take(rows * h->HW * h->D * 8); h->cond = (int64_t*)take(rows * h->cond_len * 8);
+    h->st = (int*)take(64); h->rng = (uint64_t*)take(64);
+    // KV caches: body [rows][nh][Tbody][64] x2 per layer, head Tcap = D
+    const size_t kvb = al(rows * E * h->Tbody * 2), kvh = al(rows * E * h->D * 2);
+    RQ_TRY(h->kv.reserve(2 * kvb * h->body.size() + 2 * kvh * h->head.size()));
+    char* q = (char*)h->kv.p;
+    for (auto& L : h->body) { L.kc = (bf16_t*)q; q += kvb; L.vc = (bf16_t*)q; q += kvb; }
+    for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; }
+    h->cap = B;
+    h->gvalid = false;
+    return RQAMD_OK;
+}
+
+static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
+    if (h->seen.size() < h->n_required)
+        return rq_fail(RQAMD_ERR_STATE, "rqt: only %zu of %zu parameters set", h->seen.size(), h->n_required);
+    if (!h->tables_dirty) return RQAMD_OK;
+    long n = (long)h->HW * h->E;
+    RQ_LAUNCH(bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->b_in, (float)h->D, h->pos_hw, h->body_in_bias, h->HW, h->E);
+    n = (long)h->D * h->E;
+    RQ_LAUNCH(bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->b_headin, 1.0f, h->pos_d, h->head_in_bias, h->D, h->E);
+    RQ_TRY(rq_check_launch("bias_table_kernel"));
+    h->tables_dirty = false;
+    h->gvalid = false;
+    return RQAMD_OK;
+}
+
+// one weight-streaming GEMM of the decode step; returns slab count for partial epilogues
+static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, int epi,
+                     const float* bias, const int* bias_step, int bias_stride, void* out, int ldo, int* n_slabs, hipStream_t st) {
+    GemmArgs a{};
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cfg.gelu_v2;
+    a.bias = bias; a.bias_step = bias_step; a.bias_stride = bias_stride; a.out = out; a.ldo = ldo;
+    int bm, bn, sk;
+    rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk);
+    if (sk > h->max_slabs) sk = h->max_slabs;
+    a.splitk = sk;
+    if (n_slabs) *n_slabs = sk;
+    GemmProfile& pf = h->prof;
+    if (pf.on) {
+        if (pf.used + 2 > pf.ev.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; RQ_HIP(hipEventCreate(&e)); pf.ev.push_back(e); }
+        }
+        RQ_HIP(hipEventRecord(pf.ev[pf.used], st));
+    }
+    RQ_TRY(rq_gemm_launch(a, bm, bn, st));
+    if (pf.on) {
+        RQ_HIP(hipEventRecord(pf.ev[pf.used + 1], st));
+        pf.used += 2;
+        pf.bytes += (double)N * K * 2 + (double)M * K * 2 + (double)M * N * (epi >= EPI_F32 ? 4.0 * sk : 2.0);
+        pf.flops += 2.0 * M * N * K;
+    }
+    return RQAMD_OK;
+}
+
+struct Pending { const float* slabs; int n; const float* bias; };   // un-reduced output of the previous GEMM
+
+// one transformer block on `rows` single-token rows; x is the fp32 residual stream (updated lazily:
+// `pend` carries the previous block's fc2 partials + bias into this block's first resid_ln)
+static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& pend, const float* addvec, int rows,
+                     const int* step, int step_off, int Tcap, hipStream_t st) {
+    const int E = h->E;
+    ResidLnArgs r{};
+    r.x_in = x_in; r.x_out = x; r.slabs = pend.slabs; r.n_slabs = pend.n; r.bias = pend.bias; r.addvec = addvec;
+    r.gamma = L.ln1w; r.beta = L.ln1b; r.y = h->y; r.rows = rows; r.E = E; r.eps = 1e-5f;
+    RQ_TRY(rq_launch_resid_ln(r, st));
+    RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
+    AttnDecodeArgs at{};
+    at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
+    at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
+    RQ_TRY(rq_launch_attn_decode(at, st));
+    int ns = 1;
+    RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st));
+    ResidLnArgs r2{};
+    r2.x_in = x; r2.x_out = x; r2.slabs = h->slabs; r2.n_slabs = ns; r2.bias = L.bproj;
+    r2.gamma = L.ln2w; r2.beta = L.ln2b; r2.y = h->y; r2.rows = rows; r2.E = E; r2.eps = 1e-5f;
+    RQ_TRY(rq_launch_resid_ln(r2, st));
+    RQ_TRY(step_gemm(h, h->y, E, L.wfc1, rows, 4 * E, E, EPI_BF16_GELU, L.bfc1, nullptr, 0, h->hbuf, 4 * E, nullptr, st));
+    RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st));
+    pend.slabs = h->slabs; pend.n = ns; pend.bias = L.bfc2;
+    return RQAMD_OK;
+}
+
+struct StepCtx {
+    int B;
+    const float* const* codebooks;
+    float temperature;
+    const int* top_k;
+    const float* top_p;
+    bool sample;           // run the sampler (else teacher-forced)
+    float* logits_out;     // teacher-forced: (B,HW,D,V)
+};
+
+// body stack for the token whose input is already in h->x; leaves the last fc2 un-reduced in `pend`
+static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, Pending& pend, hipStream_t st) {
+    pend = Pending{nullptr, 0, nullptr};
+    for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, step, step_off, h->Tbody, st));
+    return RQAMD_OK;
+}
+
+static int embed_gemm(rqamd_rqt* h, const StepCtx& c, int pos_off, int n_depth, const bf16_t* W, const float* bias_tab,
+                      int bias_row_off, bool bias_by_pos, float* out, hipStream_t st) {
+    EmbedTokArgs e{};
+    e.xs = h->xs; e.pos = h->st; e.pos_off = pos_off; e.n_depth = n_depth; e.rows = c.B; e.HW = h->HW; e.D = h->D; e.dim = h->Din;
+    e.out = h->ain;
+    for (int d = 0; d < h->D; ++d) { e.cb[d] = c.codebooks[d]; e.K[d] = h->V; }
+    RQ_TRY(rq_launch_embed_tokens(e, st));
+    return step_gemm(h, h->ain, h->Din, W, c.B, h->E, h->Din, EPI_F32, bias_tab + (long)bias_row_off * h->E,
+                     bias_by_pos ? h->st : nullptr, h->E, out, h->E, nullptr, st);
+}
+
+// everything that happens at one spatial position >= 1 (position read from h->st[0] on the device)
+static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, bool do_head, int host_pos, hipStream_t st) {
+    const int E = h->E, B = c.B;
+    Pending pend;
+    if (first_pos) {
+        RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, h->cond_len - 1, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
+                                    h->pos_cond, h->x, B, E, st));
+    } else {
+        // token = sum_d input_mlp(e_d) + pos_emb_hw[pos-1]  (transformers.py:218-225)
+        RQ_TRY(embed_gemm(h, c, -1, h->D, h->w_in, h->body_in_bias, -1, true, h->x, st));
+    }
+    RQ_TRY(body_stack(h, B, h->st, h->cond_len - 1, pend, st));
+    if (!do_head) {
+        // keep the residual stream consistent is unnecessary: the next position overwrites h->x
+        return RQAMD_OK;
+    }
+    for (int d = 0; d < h->D; ++d) {
+        Pending hp;
+        const float* addvec = nullptr;
+        float* x_in = h->xh;
+        if (d == 0) {
+            // head token 0 = spatial context + pos_emb_d[0]; the context is body x + last fc2 (+bias)
+            hp = pend; addvec = h->pos_d; x_in = h->x;
+        } else {
+            // head token d = head_mlp(cumsum_{j<d} e_j) + pos_emb_d[d]  (transformers.py:249-267)
+            RQ_TRY(embed_gemm(h, c, 0, d, h->w_headin, h->head_in_bias, d, false, h->xh, st));
+            hp = Pending{nullptr, 0, nullptr};
+        }
+        for (size_t li = 0; li < h->head.size(); ++li) {
+            RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, h->D, st));
+        }
+        ResidLnArgs r{};
+        r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
+        r.gamma = h->cls_lnw; r.beta = h->cls_lnb; r.y = h->y; r.rows = B; r.E = E; r.eps = 1e-5f;
+        RQ_TRY(rq_launch_resid_ln(r, st));
+        RQ_TRY(step_gemm(h, h->y, E, h->w_cls, B, h->V, E, EPI_F32, h->b_cls, nullptr, 0, h->logits, h->V, nullptr, st));
+        if (c.sample) {
+            SampleArgs s{};
+            s.logits = h->logits; s.rows = B; s.V = h->V; s.temperature = c.temperature; s.top_k = c.top_k[d]; s.top_p = c.top_p[d];
+            s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;
+            RQ_TRY(rq_launch_sample(s, st));
+        } else if (c.logits_out) {
+            float* dst = c.logits_out + ((long)host_pos * h->D + d) * h->V;
+            RQ_HIP(hipMemcpy2DAsync(dst, (size_t)h->HW * h->D * h->V * 4, h->logits, (size_t)h->V * 4, (size_t)h->V * 4, B,
+                                    hipMemcpyDeviceToDevice, st));
+        }
+    }
+    return RQAMD_OK;
+}
+
+static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const int64_t* cond, int start_idx, bool use_graph,
+                   int64_t* codes_out, hipStream_t st) {
+    const int B = c.B;
+    RQ_TRY(ensure_batch(h, B));
+    RQ_TRY(finalize_tables(h, st));
+    RQ_HIP(hipMemcpyAsync(h->xs, partial, (size_t)B * h->HW * h->D * 8, hipMemcpyDeviceToDevice, st));
+    if (cond) RQ_HIP(hipMemcpyAsync(h->cond, cond, (size_t)B * h->cond_len * 8, hipMemcpyDeviceToDevice, st));
+    else RQ_HIP(hipMemsetAsync(h->cond, 0, (size_t)B * h->cond_len * 8, st));
+    RQ_TRY(rq_launch_set_int(h->st, 0, st));
+    // conditioning prefix (text tokens): tokens 0..cond_len-2 only fill the body KV cache (transformers.py:235-239)
+    for (int i = 0; i + 1 < h->cond_len; ++i) {
+        RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, i, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
+                                    h->pos_cond, h->x, B, h->E, st));
+        Pending pend;
+        RQ_TRY(body_stack(h, B, nullptr, i, pend, st));
+    }
+    for (int pos = 0; pos < h->HW; ++pos) {
+        const bool do_head = pos >= start_idx;
+        const bool graphable = use_graph && c.sample && do_head && pos >= 1 && !h->prof.on;
+        if (graphable) {
+            if (!h->gvalid) {
+                if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+                hipGraph_t g = nullptr;
+                hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+                if (e == hipSuccess) {
+                    int rc = position_sequence(h, c, false, true, pos, st);
+                    if (rc == RQAMD_OK) rc = rq_launch_add_int(h->st, 1, st);
+                    hipError_t e2 = hipStreamEndCapture(st, &g);
+                    if (rc != RQAMD_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                    if (e2 != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e2));
+                    e2 = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    if (e2 != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+                    h->gvalid = true;
+                } else {
+                    use_graph = false;    // capture unavailable: fall through to eager launches
+                }
+            }
+            if (h->gvalid) {
+                RQ_HIP(hipGraphLaunch(h->gexec, st));
+                continue;
+            }
+        }
+        RQ_TRY(position_sequence(h, c, pos == 0, do_head, pos, st));
+        RQ_TRY(rq_launch_add_int(h->st, 1, st));
+    }
+    if (codes_out) RQ_HIP(hipMemcpyAsync(codes_out, h->xs, (size_t)B * h->HW * h->D * 8, hipMemcpyDeviceToDevice, st));
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, int batch,
+                                const float* const* codebooks, int start_h, int start_w, float temperature,
+                                const int* top_k, const float* top_p, uint64_t seed, uint64_t offset,
+                                int use_graph, int64_t* codes_out, void* stream) {
+    if (!h || !partial || !codebooks || !top_k || !top_p || !codes_out) return rq_fail(RQAMD_ERR_INVALID, "rqt_sample: null argument");
+    if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_sample: batch < 1");
+    if (!(temperature > 0.f)) return rq_fail(RQAMD_ERR_INVALID, "rqt_sample: temperature must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    RQ_TRY(ensure_batch(h, batch));
+    StepCtx c{};
+    c.B = batch; c.codebooks = codebooks; c.temperature = temperature; c.top_k = top_k; c.top_p = top_p; c.sample = true;
+    // graph cache key: anything baked into kernel arguments
+    rqamd_rqt::Key k{};
+    k.B = batch; k.T = temperature; k.stream = stream;
+    for (int d = 0; d < h->D; ++d) { k.tk[d] = top_k[d]; k.tp[d] = top_p[d]; k.cb[d] = codebooks[d]; }
+    if (!h->gvalid || memcmp(&k, &h->gkey, sizeof(k)) != 0) { h->gvalid = false; h->gkey = k; }
+    RQ_LAUNCH(set_rng_kernel, dim3(1), dim3(64), 0, st, h->rng, seed, offset);
+    h->prof.used = 0; h->prof.bytes = 0; h->prof.flops = 0;
+    int start_idx = start_h * h->cfg.W + start_w;
+    if (start_idx < 0) start_idx = 0;
+    RQ_TRY(run_all(h, c, partial, cond, start_idx, use_graph != 0, codes_out, st));
+    if (h->prof.on) {
+        RQ_HIP(hipStreamSynchronize(st));
+        double ms = 0;
+        for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
+            float t = 0.f;
+            RQ_HIP(hipEventElapsedTime(&t, h->prof.ev[i], h->prof.ev[i + 1]));
+            ms += t;
+        }
+        h->prof.ms_total = ms;
+        h->prof.launches = (int64_t)(h->prof.used / 2);
+    }
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_rqt_logits(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
+                                const float* const* codebooks, float* logits_out, void* stream) {
+    if (!h || !codes || !codebooks || !logits_out) return rq_fail(RQAMD_ERR_INVALID, "rqt_logits: null argument");
+    if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_logits: batch < 1");
+    StepCtx c{};
+    c.B = batch; c.codebooks = codebooks; c.temperature = 1.f; c.sample = false; c.logits_out = logits_out;
+    return run_all(h, c, codes, cond, 0, false, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int rqamd_rqt_set_profile(rqamd_rqt* h, int profile) {
+    if (!h) return rq_fail(RQAMD_ERR_INVALID, "null handle");
+    h->prof.on = profile != 0;
+    return RQAMD_OK;
+}
+extern "C" int rqamd_rqt_get_profile(rqamd_rqt* h, double* ms, int64_t* launches, double* bytes, double* flops) {
+    if (!h) return rq_fail(RQAMD_ERR_INVALID, "null handle");
+    if (ms) *ms = h->prof.ms_total;
+    if (launches) *launches = h->prof.launches;
+    if (bytes) *bytes = h->prof.bytes;
+    if (flops) *flops = h->prof.flops;
+    return RQAMD_OK;
+}

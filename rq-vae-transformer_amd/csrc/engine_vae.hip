@@ -1,0 +1,314 @@
+// engine_vae.hip -- RQ-VAE encoder / decoder engine (host side, gfx950).
+//
+// Stands behind RQVAE.encode / RQVAE.decode (rqvae/models/rqvae/rqvae.py:80-89), Encoder.forward /
+// Decoder.forward (modules.py:73-98,171-202), ResnetBlock._forward (layers.py:100-120),
+// AttnBlock.forward (:158-182), Upsample / Downsample (:31-35,50-57).
+//
+// Layout and precision: activations NHWC bf16 between layers, fp32 accumulation, GroupNorm statistics
+// in fp32; every convolution is the implicit-GEMM MFMA kernel of gemm.h with bias / residual fused in
+// the epilogue; nearest-2x upsampling and the (0,1,0,1) zero pad of the stride-2 downsample are folded
+// into the conv's gather.  The drivers decode one image per call (main_sampling_fid.py:223,
+// measure_throughput/__main__.py:299-300); here any batch is accepted and processed in chunks that keep
+// the five activation buffers bounded.
+#include <string.h>
+#include <stdlib.h>
+#include <map>
+#include <memory>
+#include <string>
+#include "gemm.h"
+#include "rq_common.h"
+#include "rqt_kernels.h"
+#include "vae_kernels.h"
+
+struct rqamd_vae {
+    rqamd_vae_config cfg;
+    std::map<std::string, std::unique_ptr<DevBuf>> params;
+    DevBuf ws, part;
+    bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap_elems = 0;
+    int chunk = 0;
+    int chunk_max = 32;
+    std::string missing;
+};
+
+static int vae_level_res(const rqamd_vae_config& c, int level) { return c.resolution >> level; }
+static bool vae_has_attn(const rqamd_vae_config& c, int res) {
+    for (int i = 0; i < c.n_attn_res; ++i)
+        if (c.attn_resolutions[i] == res) return true;
+    return false;
+}
+
+extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
+    if (!c || !out) return rq_fail(RQAMD_ERR_INVALID, "vae_create: null argument");
+    if (c->n_levels < 1 || c->n_levels > 8 || c->n_attn_res < 0 || c->n_attn_res > 8) return rq_fail(RQAMD_ERR_INVALID, "vae_create: bad config");
+    if (c->ch % 64 != 0 || c->z_channels % 64 != 0 || c->embed_dim % 64 != 0)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "vae_create: ch / z_channels / embed_dim must be multiples of 64");
+    if (c->in_channels > 4 || c->out_ch > 4) return rq_fail(RQAMD_ERR_UNSUPPORTED, "vae_create: in/out channels > 4");
+    if (c->resolution % (1 << (c->n_levels - 1)) != 0) return rq_fail(RQAMD_ERR_INVALID, "vae_create: resolution not divisible");
+    rqamd_vae* h = new rqamd_vae();
+    h->cfg = *c;
+    if (const char* e = getenv("RQAMD_VAE_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 1024) h->chunk_max = v; }
+    *out = h;
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_vae_destroy(rqamd_vae* h) {
+    delete h;
+    return RQAMD_OK;
+}
+
+static DevBuf* vae_slot(rqamd_vae* h, const std::string& name, size_t bytes) {
+    auto& u = h->params[name];
+    if (!u) u.reset(new DevBuf());
+    if (u->reserve(bytes) != RQAMD_OK) return nullptr;
+    return u.get();
+}
+
+extern "C" int rqamd_vae_set_param(rqamd_vae* h, const char* name, const float* src, const int64_t* shape, int ndim, void* stream) {
+    if (!h || !name || !src || !shape) return rq_fail(RQAMD_ERR_INVALID, "vae_set_param: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    std::string s(name);
+    if (s.rfind("quantizer.", 0) == 0) return RQAMD_OK;      // codebooks travel separately (rqamd_rq_*)
+    if (ndim == 4) {
+        const int O = (int)shape[0], I = (int)shape[1], kh = (int)shape[2], kw = (int)shape[3];
+        const size_t n = (size_t)O * I * kh * kw;
+        if (s == "encoder.conv_in.weight" || s == "decoder.conv_out.weight") {
+            DevBuf* d = vae_slot(h, s, n * 4);
+            if (!d) return RQAMD_ERR_HIP;
+            return rq_launch_repack_conv(src, d->p, O, I, kh, kw, s[0] == 'e' ? 1 : 2, st);
+        }
+        // attention q/k/v 1x1 convs are fused into one [3C][C] GEMM weight
+        for (int which = 0; which < 3; ++which) {
+            const char* leaf = which == 0 ? ".q.weight" : which == 1 ? ".k.weight" : ".v.weight";
+            const size_t ll = strlen(leaf);
+            if (s.size() > ll && s.compare(s.size() - ll, ll, leaf) == 0 && kh == 1) {
+                std::string fused = s.substr(0, s.size() - ll) + ".qkv.weight";
+                DevBuf* d = vae_slot(h, fused, 3 * n * 2);
+                if (!d) return RQAMD_ERR_HIP;
+                return rq_launch_repack_conv(src, d->as<bf16_t>() + which * n, O, I, 1, 1, 0, st);
+            }
+        }
+        DevBuf* d = vae_slot(h, s, n * 2);
+        if (!d) return RQAMD_ERR_HIP;
+        return rq_launch_repack_conv(src, d->p, O, I, kh, kw, 0, st);
+    }
+    if (ndim == 1) {
+        const size_t n = (size_t)shape[0];
+        for (int which = 0; which < 3; ++which) {
+            const char* leaf = which == 0 ? ".q.bias" : which == 1 ? ".k.bias" : ".v.bias";
+            const size_t ll = strlen(leaf);
+            if (s.size() > ll && s.compare(s.size() - ll, ll, leaf) == 0) {
+                std::string fused = s.substr(0, s.size() - ll) + ".qkv.bias";
+                DevBuf* d = vae_slot(h, fused, 3 * n * 4);
+                if (!d) return RQAMD_ERR_HIP;
+                RQ_HIP(hipMemcpyAsync(d->as<float>() + which * n, src, n * 4, hipMemcpyDeviceToDevice, st));
+                return RQAMD_OK;
+            }
+        }
+        DevBuf* d = vae_slot(h, s, n * 4);
+        if (!d) return RQAMD_ERR_HIP;
+        RQ_HIP(hipMemcpyAsync(d->p, src, n * 4, hipMemcpyDeviceToDevice, st));
+        return RQAMD_OK;
+    }
+    return rq_fail(RQAMD_ERR_INVALID, "vae_set_param(%s): unexpected rank %d", name, ndim);
+}
+
+// -------------------------------------------------------------------------------------------------
+struct VaeRun {
+    rqamd_vae* h;
+    hipStream_t st;
+    int B;
+    int err = RQAMD_OK;
+    bf16_t *X, *Y, *T1, *T2, *T3;
+
+    void* P(const std::string& name) {
+        auto it = h->params.find(name);
+        if (it == h->params.end() || !it->second || !it->second->p) {
+            if (err == RQAMD_OK) err = rq_fail(RQAMD_ERR_STATE, "vae: parameter %s was never set", name.c_str());
+            return nullptr;
+        }
+        return it->second->p;
+    }
+    void swap() { bf16_t* t = X; X = Y; Y = t; }
+
+    // src: NHWC [B][Hin>>ups][Win>>ups][Cin]  ->  dst [B][Hout][Wout][Cout]
+    void conv(const std::string& name, const bf16_t* src, void* dst, int Hin, int Win, int Cin, int Cout, int ks, int stride, int ups,
+              int epi, const bf16_t* resid) {
+        if (err) return;
+        const bf16_t* w = (const bf16_t*)P(name + ".weight");
+        const float* b = (const float*)P(name + ".bias");
+        if (err) return;
+        int Hout = Hin, Wout = Win, pad = ks / 2;
+        if (stride == 2) { Hout = Hin / 2; Wout = Win / 2; pad = 0; }      // F.pad(0,1,0,1) + conv(s2, p0), layers.py:50-54
+        GemmArgs a{};
+        a.A = src; a.W = w; a.M = B * Hout * Wout; a.N = Cout; a.K = ks * ks * Cin; a.lda = Cin;
+        a.conv = (ks == 3 || stride != 1 || ups) ? 1 : 0;
+        a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.ksize = ks; a.stride = stride; a.pad = pad; a.ups = ups;
+        a.epi = epi; a.bias = b; a.out = dst; a.ldo = Cout; a.resid = resid; a.ldr = Cout; a.splitk = 1;
+        const int bm = a.M >= 128 ? 128 : 64;
+        const int bn = (Cout % 128 == 0) ? 128 : 64;
+        err = rq_gemm_launch(a, bm, bn, st);
+    }
+    void norm(const std::string& name, const bf16_t* src, bf16_t* dst, int HW, int C, int silu) {
+        if (err) return;
+        const float* g = (const float*)P(name + ".weight");
+        const float* b = (const float*)P(name + ".bias");
+        if (err) return;
+        err = rq_launch_groupnorm(src, dst, h->part.as<float>(), g, b, B, HW, C, silu, st);
+    }
+    // ResnetBlock._forward (layers.py:100-120): X -> Y, then swap
+    void res(const std::string& name, int H, int W, int Cin, int Cout) {
+        norm(name + ".norm1", X, T1, H * W, Cin, 1);
+        conv(name + ".conv1", T1, T2, H, W, Cin, Cout, 3, 1, 0, EPI_BF16, nullptr);
+        norm(name + ".norm2", T2, T1, H * W, Cout, 1);
+        const bf16_t* sc = X;
+        if (Cin != Cout) {
+            conv(name + ".nin_shortcut", X, T3, H, W, Cin, Cout, 1, 1, 0, EPI_BF16, nullptr);
+            sc = T3;
+        }
+        conv(name + ".conv2", T1, Y, H, W, Cout, Cout, 3, 1, 0, EPI_BF16_RESID, sc);
+        swap();
+    }
+    // AttnBlock.forward (layers.py:158-182): X -> Y, then swap
+    void attn(const std::string& name, int H, int W, int C) {
+        norm(name + ".norm", X, T1, H * W, C, 0);
+        conv(name + ".qkv", T1, T2, H, W, C, 3 * C, 1, 1, 0, EPI_BF16, nullptr);
+        if (err) return;
+        err = rq_launch_vae_attn(T2, T1, B, H * W, C, st);
+        conv(name + ".proj_out", T1, Y, H, W, C, C, 1, 1, 0, EPI_BF16_RESID, X);
+        swap();
+    }
+};
+
+static int vae_prepare(rqamd_vae* h, int chunk) {
+    const rqamd_vae_config& c = h->cfg;
+    size_t per_img = 0;
+    for (int l = 0; l < c.n_levels; ++l) {
+        size_t hw = (size_t)vae_level_res(c, l) * vae_level_res(c, l);
+        size_t cl = (size_t)c.ch * c.ch_mult[l];
+        size_t cn = (l + 1 < c.n_levels) ? (size_t)c.ch * c.ch_mult[l + 1] : cl;
+        size_t cm = cl > cn ? cl : cn;
+        if ((size_t)c.z_channels > cm) cm = c.z_channels;
+        if (vae_has_attn(c, vae_level_res(c, l))) cm *= 3;
+        if (hw * cm > per_img) per_img = hw * cm;
+    }
+    const int lowres = vae_level_res(c, c.n_levels - 1);
+    size_t mid = (size_t)lowres * lowres * c.ch * c.ch_mult[c.n_levels - 1] * 3;
+    if (mid > per_img) per_img = mid;
+    if (chunk <= h->chunk && h->buf[0]) return RQAMD_OK;
+    const size_t elems = per_img * chunk;
+    const size_t bytes = (elems * 2 + 255) & ~(size_t)255;
+    RQ_TRY(h->ws.reserve(bytes * 5));
+    for (int i = 0; i < 5; ++i) h->buf[i] = (bf16_t*)((char*)h->ws.p + bytes * i);
+    RQ_TRY(h->part.reserve((size_t)chunk * RQ_GN_MAX_CHUNK * 32 * 2 * 4));
+    h->cap_elems = elems;
+    h->chunk = chunk;
+    return RQAMD_OK;
+}
+
+static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipStream_t st) {
+    const rqamd_vae_config& c = h->cfg;
+    VaeRun r{h, st, B};
+    r.X = h->buf[0]; r.Y = h->buf[1]; r.T1 = h->buf[2]; r.T2 = h->buf[3]; r.T3 = h->buf[4];
+    const int nl = c.n_levels;
+    int res = vae_level_res(c, nl - 1);
+    int block_in = c.ch * c.ch_mult[nl - 1];
+    // z_q NHWC fp32 -> bf16; post_quant_conv (1x1, rqvae.py:87); Decoder.conv_in
+    RQ_TRY(rq_launch_cvt_bf16(z_q, r.T1, (long)B * res * res * c.embed_dim, st));
+    r.conv("post_quant_conv", r.T1, r.X, res, res, c.embed_dim, c.z_channels, 1, 1, 0, EPI_BF16, nullptr);
+    r.conv("decoder.conv_in", r.X, r.Y, res, res, c.z_channels, block_in, 3, 1, 0, EPI_BF16, nullptr);
+    r.swap();
+    r.res("decoder.mid.block_1", res, res, block_in, block_in);
+    r.attn("decoder.mid.attn_1", res, res, block_in);
+    r.res("decoder.mid.block_2", res, res, block_in, block_in);
+    for (int l = nl - 1; l >= 0; --l) {
+        const int block_out = c.ch * c.ch_mult[l];
+        const std::string up = "decoder.up." + std::to_string(l);
+        for (int ib = 0; ib < c.num_res_blocks + 1; ++ib) {
+            r.res(up + ".block." + std::to_string(ib), res, res, block_in, block_out);
+            block_in = block_out;
+            if (vae_has_attn(c, res)) r.attn(up + ".attn." + std::to_string(ib), res, res, block_in);
+        }
+        if (l != 0) {
+            res *= 2;   // nearest x2 folded into the conv gather (layers.py:31-35)
+            r.conv(up + ".upsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 1, 1, EPI_BF16, nullptr);
+            r.swap();
+        }
+    }
+    r.norm("decoder.norm_out", r.X, r.T1, res * res, block_in, 1);
+    if (r.err) return r.err;
+    const float* w = (const float*)r.P("decoder.conv_out.weight");
+    const float* b = (const float*)r.P("decoder.conv_out.bias");
+    if (r.err) return r.err;
+    return rq_launch_conv_out3(r.T1, w, b, out, B, res, res, block_in, c.out_ch, st);
+}
+
+static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStream_t st) {
+    const rqamd_vae_config& c = h->cfg;
+    VaeRun r{h, st, B};
+    r.X = h->buf[0]; r.Y = h->buf[1]; r.T1 = h->buf[2]; r.T2 = h->buf[3]; r.T3 = h->buf[4];
+    const int nl = c.n_levels;
+    int res = c.resolution;
+    {
+        const float* w = (const float*)r.P("encoder.conv_in.weight");
+        const float* b = (const float*)r.P("encoder.conv_in.bias");
+        if (r.err) return r.err;
+        RQ_TRY(rq_launch_conv_in3(x, w, b, r.X, B, res, res, c.in_channels, c.ch, st));
+    }
+    int block_in = c.ch;
+    for (int l = 0; l < nl; ++l) {
+        const int block_out = c.ch * c.ch_mult[l];
+        const std::string dn = "encoder.down." + std::to_string(l);
+        for (int ib = 0; ib < c.num_res_blocks; ++ib) {
+            r.res(dn + ".block." + std::to_string(ib), res, res, block_in, block_out);
+            block_in = block_out;
+            if (vae_has_attn(c, res)) r.attn(dn + ".attn." + std::to_string(ib), res, res, block_in);
+        }
+        if (l != nl - 1) {
+            r.conv(dn + ".downsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 2, 0, EPI_BF16, nullptr);
+            r.swap();
+            res /= 2;
+        }
+    }
+    r.res("encoder.mid.block_1", res, res, block_in, block_in);
+    r.attn("encoder.mid.attn_1", res, res, block_in);
+    r.res("encoder.mid.block_2", res, res, block_in, block_in);
+    r.norm("encoder.norm_out", r.X, r.T1, res * res, block_in, 1);
+    const int zc = c.z_channels * (c.double_z ? 2 : 1);
+    r.conv("encoder.conv_out", r.T1, r.Y, res, res, block_in, zc, 3, 1, 0, EPI_BF16, nullptr);
+    // quant_conv 1x1 (rqvae.py:82) -> fp32 NHWC
+    r.conv("quant_conv", r.Y, z_e, res, res, zc, c.embed_dim, 1, 1, 0, EPI_F32, nullptr);
+    return r.err;
+}
+
+extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float* out, void* stream) {
+    if (!h || !z_q || !out) return rq_fail(RQAMD_ERR_INVALID, "vae_decode: null argument");
+    if (batch < 0) return rq_fail(RQAMD_ERR_INVALID, "vae_decode: batch < 0");
+    const rqamd_vae_config& c = h->cfg;
+    const int lowres = vae_level_res(c, c.n_levels - 1);
+    const int chunk = batch < h->chunk_max ? batch : h->chunk_max;
+    if (batch == 0) return RQAMD_OK;
+    RQ_TRY(vae_prepare(h, chunk));
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
+        RQ_TRY(decode_chunk(h, z_q + (size_t)b0 * lowres * lowres * c.embed_dim, n,
+                            out + (size_t)b0 * c.out_ch * c.resolution * c.resolution, (hipStream_t)stream));
+    }
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* z_e, void* stream) {
+    if (!h || !x || !z_e) return rq_fail(RQAMD_ERR_INVALID, "vae_encode: null argument");
+    if (batch < 0) return rq_fail(RQAMD_ERR_INVALID, "vae_encode: batch < 0");
+    const rqamd_vae_config& c = h->cfg;
+    const int lowres = vae_level_res(c, c.n_levels - 1);
+    const int chunk = batch < h->chunk_max ? batch : h->chunk_max;
+    if (batch == 0) return RQAMD_OK;
+    RQ_TRY(vae_prepare(h, chunk));
+    for (int b0 = 0; b0 < batch; b0 += chunk) {
+        const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
+        RQ_TRY(encode_chunk(h, x + (size_t)b0 * c.in_channels * c.resolution * c.resolution, n,
+                            z_e + (size_t)b0 * lowres * lowres * c.embed_dim, (hipStream_t)stream));
+    }
+    return RQAMD_OK;
+}

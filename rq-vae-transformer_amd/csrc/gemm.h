@@ -1,0 +1,215 @@
+// gemm.h -- bf16 MFMA GEMM with fused epilogues; also the implicit-GEMM conv (gfx950).
+//
+//   C[M,N] = A[M,K] . W[N,K]^T  (+bias, +GELU | +residual | fp32 | split-K partial slabs)
+//
+// W is always a torch nn.Linear / repacked Conv2d weight: [N][K] row-major bf16 (K contiguous), so
+// both operands are K-contiguous and fragments come out of LDS as single ds_read_b128.
+// A is either a dense [M][lda] bf16 matrix (transformer decode steps: M = batch rows) or an NHWC
+// bf16 feature map gathered on the fly (conv 3x3 / 1x1, stride 1 / 2, optional folded nearest-2x
+// upsample): row m = output pixel, K = taps x Cin, one 64-wide K tile never straddles a tap
+// (Cin % 64 == 0).
+//
+// Replaces, on the reference side: nn.Linear in MultiSelfAttention / AttentionBlock.mlp / classifier /
+// input_mlp / head_mlp (rqvae/models/rqtransformer/attentions.py:48-55,117-122, transformers.py:68-94)
+// and nn.Conv2d in Encoder/Decoder/ResnetBlock/AttnBlock/Upsample/Downsample
+// (rqvae/models/rqvae/layers.py:20-182, modules.py:23,67,123,165), F.interpolate(nearest, x2)
+// (layers.py:32) and F.pad(0,1,0,1) (layers.py:52-53).
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 64, wave tile (BM/2) x (BN/2) built from
+// v_mfma_f32_32x32x16_bf16; LDS double-buffered, register-staged (global_load_dwordx4 -> ds_write_b128)
+// with the next tile's loads issued before the current tile's MFMAs; 16-byte-chunk XOR swizzle
+// (chunk ^ ((row>>1)&7)) makes both the b128 writes and the fragment reads bank-conflict free.
+#pragma once
+#include "rq_hip.h"
+
+enum GemmEpi {
+    EPI_BF16 = 0,         // out bf16 = acc + bias
+    EPI_BF16_GELU = 1,    // out bf16 = gelu(acc + bias)
+    EPI_BF16_RESID = 2,   // out bf16 = acc + bias + resid(bf16)
+    EPI_F32 = 3,          // out f32  = acc + bias
+    EPI_F32_PARTIAL = 4,  // out f32 slab[blockIdx.z] = acc (split-K partial; consumer reduces)
+};
+
+struct GemmArgs {
+    const bf16_t* A;
+    const bf16_t* W;
+    int M, N, K;
+    int lda;
+    // conv gather (conv != 0): A is NHWC [n_img][Hs][Ws][Cin], Hs = Hin >> ups
+    int conv, Hin, Win, Cin, Hout, Wout, ksize, stride, pad, ups;
+    // epilogue
+    int epi, gelu_v2;
+    const float* bias;       // [N] (or [steps][N] when bias_step != nullptr)
+    const int* bias_step;    // device-side step index selecting the bias row
+    int bias_stride;
+    void* out;
+    int ldo;
+    const bf16_t* resid;
+    int ldr;
+    int splitk;
+};
+
+static __device__ __forceinline__ float rq_gelu(float x, int v2) {
+    if (v2) return x / (1.0f + __expf(-1.702f * x));
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element offset in a [rows][64] bf16 tile
+    return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    RQ_DYN_SMEM(smem);
+    bf16_t* sA = (bf16_t*)smem;              // [2][BM*64]
+    bf16_t* sB = sA + 2 * BM * BK;           // [2][BN*64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kt_total = p.K / BK;
+    const int per = (kt_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = (kt0 + per < kt_total) ? kt0 + per : kt_total;
+
+    const int chunk = tid & 7, lrow = tid >> 3;
+
+    // per-row gather bases (A)
+    long a_base[A_IT];     // element offset of (row, k=0) for dense; pixel decomposition for conv
+    int a_oy[A_IT], a_ox[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < p.M;
+        if (p.conv) {
+            int hw = p.Hout * p.Wout;
+            int img = m / hw, rem = m - img * hw;
+            a_oy[i] = rem / p.Wout;
+            a_ox[i] = rem - a_oy[i] * p.Wout;
+            a_base[i] = (long)img * (p.Hin >> p.ups) * (p.Win >> p.ups) * p.Cin;
+        } else {
+            a_oy[i] = a_ox[i] = 0;
+            a_base[i] = (long)m * p.lda;
+        }
+    }
+    const bf16_t* w_ptr[B_IT];
+    bool w_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        int n = n0 + lrow + 32 * i;
+        w_ok[i] = n < p.N;
+        w_ptr[i] = p.W + (long)(w_ok[i] ? n : 0) * p.K + chunk * 8;
+    }
+
+    rq_u128 ra[A_IT], rb[B_IT];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        int dy = 0, dx = 0, ci0 = k0;
+        if (p.conv) {
+            int tap = k0 / p.Cin;
+            ci0 = k0 - tap * p.Cin;
+            dy = tap / p.ksize - p.pad;
+            dx = tap % p.ksize - p.pad;
+        }
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            bool ok = a_ok[i];
+            long off;
+            if (p.conv) {
+                int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
+                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                off = a_base[i] + ((long)(iy >> p.ups) * (p.Win >> p.ups) + (ix >> p.ups)) * p.Cin + ci0 + chunk * 8;
+            } else {
+                off = a_base[i] + k0 + chunk * 8;
+            }
+            ra[i] = ok ? ld128(p.A + off) : zero128();
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[i] = w_ok[i] ? ld128(w_ptr[i] + k0) : zero128();
+    };
+    auto store_tile = [&](int buf) {
+        bf16_t* a = sA + buf * BM * BK;
+        bf16_t* b = sB + buf * BN * BK;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) st128(a + swz_off(lrow + 32 * i, chunk), ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) st128(b + swz_off(lrow + 32 * i, chunk), rb[i]);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+    }
+    rq_syncthreads();
+    const int frow = lane & 31, fk = lane >> 5;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_tile(kt + 1);
+        const bf16_t* a = sA + buf * BM * BK;
+        const bf16_t* b = sB + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(a + swz_off(wm * WM + i * 32 + frow, ks * 2 + fk)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(b + swz_off(wn * WN + j * 32 + frow, ks * 2 + fk)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
+        }
+        if (more) store_tile(buf ^ 1);
+        rq_syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const int epi = p.epi;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 32 + (lane & 31);
+            const float bv = (bias && n < p.N && epi != EPI_F32_PARTIAL) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M || n >= p.N) continue;
+                float v = acc[i][j][r] + bv;
+                const long o = (long)m * p.ldo + n;
+                if (epi == EPI_BF16) {
+                    ((bf16_t*)p.out)[o] = f32_to_bf16(v);
+                } else if (epi == EPI_BF16_GELU) {
+                    ((bf16_t*)p.out)[o] = f32_to_bf16(rq_gelu(v, p.gelu_v2));
+                } else if (epi == EPI_BF16_RESID) {
+                    v += bf16_to_f32(p.resid[(long)m * p.ldr + n]);
+                    ((bf16_t*)p.out)[o] = f32_to_bf16(v);
+                } else if (epi == EPI_F32) {
+                    ((float*)p.out)[o] = v;
+                } else {
+                    ((float*)p.out)[(long)blockIdx.z * p.M * p.ldo + o] = v;
+                }
+            }
+        }
+}
+
+// host-side launcher (gemm.hip)
+int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
+// picks (BM, BN, splitk) for a weight-streaming decode GEMM; returns splitk actually used via args
+void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk);

@@ -1,0 +1,319 @@
+// quantize.hip -- residual quantiser: fused nearest-codebook search over all depths (gfx950).
+//
+// Reference: RQBottleneck.quantize (rqvae/models/rqvae/quantizations.py:237-271) =
+//   depth x { VQEmbedding.compute_distances :43-62 (||r||^2 + ||c||^2 - 2 r.c^T via addmm, fp32),
+//             find_nearest_embedding :64-69 (argmin, first minimum), embed :144-146,
+//             residual.sub_(quant); aggregated.add_(quant) :264-265 }
+// plus embed_code :297-311 / embed_code_with_depth :313-334 (rq_embed_kernel below).
+//
+// The reference materialises an (N x K) fp32 distance matrix per depth (268 MB at 64 images) and
+// re-reads it for argmin.  Here one workgroup owns 64 vectors for the whole depth loop: the residual
+// lives in LDS (fp32, exact), the codebook streams through LDS in [128 codes][64 dims] chunks
+// (double-buffered, coalesced 256-B row segments), the r.c^T contraction runs on the exact-f32
+// matrix pipe (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain), every lane keeps a running
+// (distance, index) minimum for its code column, and the minimum is wavefront-reduced with
+// lowest-index tie-break.  Distances never leave registers; HBM traffic is the algorithmic minimum
+// (x in, codes/quants out, codebook from L2/MALL).
+//
+// Lane map of one 4-MFMA group (k-permutation is free as long as A and B agree): lane (i = l&31,
+// half = l>>5) loads float4 r[i][8q+4*half .. +3] and c[j][8q+4*half .. +3]; MFMA m of the group
+// consumes component m of both, so half 0 contributes dim 8q+m and half 1 dim 8q+4+m.
+#include "rq_common.h"
+
+#define RQ_MAX_DEPTH 8
+struct RqQuantArgs {
+    const float* x;
+    const float* cb[RQ_MAX_DEPTH];
+    const float* cn[RQ_MAX_DEPTH];     // ||c||^2 per code
+    int K[RQ_MAX_DEPTH];
+    int depth, dim;
+    long n_vec;
+    int64_t* codes;
+    float* quant_cum;                  // (depth, n_vec, dim) or null
+};
+
+constexpr int QT_M = 64;     // vectors per workgroup
+constexpr int QT_N = 128;    // codes per tile (4 waves x 32)
+constexpr int QT_K = 64;     // dims per staged chunk
+
+__global__ void rq_code_norm_kernel(const float* cb, int K, int dim, float* cn) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float* c = cb + (long)k * dim;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int d = 0; d < dim; d += 4) {
+        s0 = fmaf(c[d], c[d], s0);
+        s1 = fmaf(c[d + 1], c[d + 1], s1);
+        s2 = fmaf(c[d + 2], c[d + 2], s2);
+        s3 = fmaf(c[d + 3], c[d + 3], s3);
+    }
+    cn[k] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
+    RQ_DYN_SMEM(smem);
+    const int D = p.dim;
+    const int RS = D + 4;                 // residual row stride (floats): odd multiple of 16 B
+    constexpr int CS = QT_K + 4;          // chunk row stride
+    float* sR = (float*)smem;                         // [64][RS]
+    float* sC = sR + QT_M * RS;                       // [2][128][CS]
+    float* sXn = sC + 2 * QT_N * CS;                  // [64]
+    float* sRedV = sXn + QT_M;                        // [4][64]
+    int* sRedI = (int*)(sRedV + 4 * QT_M);            // [4][64]
+    int* sCode = sRedI + 4 * QT_M;                    // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long v0 = (long)blockIdx.x * QT_M;
+    const int urow = tid >> 2, useg = tid & 3;        // update-phase mapping: 4 threads per vector
+    const long uvec = v0 + urow;
+    const bool uok = uvec < p.n_vec;
+    const int nf4 = D / 16;                           // float4s per thread in the update phase
+
+    // ---- load x into the LDS residual, ||x||^2
+    {
+        float ss = 0.f;
+        for (int i = 0; i < nf4; ++i) {
+            int f = useg + 4 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (uok) v = *(const f32x4*)(p.x + uvec * D + f * 4);
+            *(f32x4*)(sR + urow * RS + f * 4) = v;
+            ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
+        }
+        ss += rq_shfl_xor(ss, 1);
+        ss += rq_shfl_xor(ss, 2);
+        if (useg == 0) sXn[urow] = ss;
+    }
+    rq_syncthreads();
+
+    const int fi = lane & 31, fh = lane >> 5;
+    const int nchunk = D / QT_K;
+    const int srow = tid >> 4, sf4 = tid & 15;        // staging: 16 threads x float4 per 64-dim row
+
+    for (int dep = 0; dep < p.depth; ++dep) {
+        const float* cb = p.cb[dep];
+        const float* cn = p.cn[dep];
+        const int K = p.K[dep];
+        const int ntile = (K + QT_N - 1) / QT_N;
+        const int nstep = ntile * nchunk;
+
+        float bestv[2][16];
+        int besti[2][16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { bestv[h][r] = __int_as_float(0x7f800000); besti[h][r] = 0; }
+
+        f32x4 stage[8];
+        auto load_chunk = [&](int step) {
+            int tile = step / nchunk, c = step - tile * nchunk;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int code = tile * QT_N + srow + 16 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (code < K) v = *(const f32x4*)(cb + (long)code * D + c * QT_K + sf4 * 4);
+                stage[i] = v;
+            }
+        };
+        auto store_chunk = [&](int buf) {
+            float* dst = sC + buf * QT_N * CS;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(f32x4*)(dst + (srow + 16 * i) * CS + sf4 * 4) = stage[i];
+        };
+
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+        load_chunk(0);
+        store_chunk(0);
+        rq_syncthreads();
+        for (int step = 0; step < nstep; ++step) {
+            const int buf = step & 1;
+            const int tile = step / nchunk, c = step - tile * nchunk;
+            const bool more = step + 1 < nstep;
+            if (more) load_chunk(step + 1);
+            const float* cT = sC + buf * QT_N * CS + (wave * 32 + fi) * CS + 4 * fh;
+            const float* r0 = sR + fi * RS + c * QT_K + 4 * fh;
+            const float* r1 = r0 + 32 * RS;
+#pragma unroll
+            for (int q = 0; q < QT_K / 8; ++q) {
+                f32x4 b = *(const f32x4*)(cT + 8 * q);
+                f32x4 a0 = *(const f32x4*)(r0 + 8 * q);
+                f32x4 a1 = *(const f32x4*)(r1 + 8 * q);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    acc0 = rq_mfma_32x32x2_f32(a0[m], b[m], acc0);
+                    acc1 = rq_mfma_32x32x2_f32(a1[m], b[m], acc1);
+                }
+            }
+            if (c == nchunk - 1) {
+                // distances of this lane's code column against its 32 rows
+                const int code = tile * QT_N + wave * 32 + fi;
+                const bool valid = code < K;
+                const float cnv = valid ? cn[code] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    float d0 = fmaf(-2.0f, acc0[r], sXn[row] + cnv);
+                    float d1 = fmaf(-2.0f, acc1[r], sXn[row + 32] + cnv);
+                    if (valid && d0 < bestv[0][r]) { bestv[0][r] = d0; besti[0][r] = code; }
+                    if (valid && d1 < bestv[1][r]) { bestv[1][r] = d1; besti[1][r] = code; }
+                    acc0[r] = 0.f;
+                    acc1[r] = 0.f;
+                }
+            }
+            if (more) store_chunk(buf ^ 1);
+            rq_syncthreads();
+        }
+
+        // ---- wavefront (value, index) min-reduction over the 32 code columns of each half
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = bestv[h][r];
+                int ix = besti[h][r];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) {
+                    float ov = rq_shfl_xor(v, m);
+                    int oi = rq_shfl_xor_i(ix, m);
+                    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                if (fi == 0) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * h;
+                    sRedV[wave * QT_M + row] = v;
+                    sRedI[wave * QT_M + row] = ix;
+                }
+            }
+        rq_syncthreads();
+        if (tid < QT_M) {
+            float v = sRedV[tid];
+            int ix = sRedI[tid];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                float ov = sRedV[w * QT_M + tid];
+                int oi = sRedI[w * QT_M + tid];
+                if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            sCode[tid] = ix;
+            if (v0 + tid < p.n_vec) p.codes[(v0 + tid) * p.depth + dep] = (int64_t)ix;
+        }
+        rq_syncthreads();
+
+        // ---- residual -= c[code]; aggregated += c[code]; new ||r||^2   (quantizations.py:264-267)
+        {
+            const float* q = cb + (long)sCode[urow] * D;
+            float ss = 0.f;
+            for (int i = 0; i < nf4; ++i) {
+                int f = useg + 4 * i;
+                f32x4 qv = *(const f32x4*)(q + f * 4);
+                f32x4 rv = *(f32x4*)(sR + urow * RS + f * 4);
+                rv = rv - qv;
+                *(f32x4*)(sR + urow * RS + f * 4) = rv;
+                ss = fmaf(rv[0], rv[0], ss); ss = fmaf(rv[1], rv[1], ss); ss = fmaf(rv[2], rv[2], ss); ss = fmaf(rv[3], rv[3], ss);
+                if (p.quant_cum && uok) {
+                    f32x4 agg = qv;
+                    if (dep > 0) agg = *(const f32x4*)(p.quant_cum + ((long)(dep - 1) * p.n_vec + uvec) * D + f * 4) + qv;
+                    *(f32x4*)(p.quant_cum + ((long)dep * p.n_vec + uvec) * D + f * 4) = agg;
+                }
+            }
+            ss += rq_shfl_xor(ss, 1);
+            ss += rq_shfl_xor(ss, 2);
+            if (useg == 0) sXn[urow] = ss;
+        }
+        rq_syncthreads();
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// embed_code (mode 0: sum over depth), embed_code_with_depth (mode 1), depth-cumsum (mode 2)
+struct RqEmbedArgs {
+    const int64_t* codes;
+    const float* cb[RQ_MAX_DEPTH];
+    int K[RQ_MAX_DEPTH];
+    int depth, dim, mode;
+    long n_vec;
+    float* out;
+};
+
+__global__ void rq_embed_kernel(RqEmbedArgs p) {
+    const int f4_per_vec = p.dim / 4;
+    long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= p.n_vec * f4_per_vec) return;
+    long v = gid / f4_per_vec;
+    int f = (int)(gid - v * f4_per_vec);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < p.depth; ++d) {
+        long code = p.codes[v * p.depth + d];
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+        if (code >= 0 && code < p.K[d]) e = *(const f32x4*)(p.cb[d] + code * p.dim + f * 4);   // row K = zero padding
+        if (p.mode == 1) {
+            *(f32x4*)(p.out + ((v * p.depth + d) * p.dim) + f * 4) = e;
+        } else {
+            acc = (d == 0) ? e : acc + e;          // depth-ordered fp32 sum, as cat(...).sum(-2) / cumsum
+            if (p.mode == 2) *(f32x4*)(p.out + ((v * p.depth + d) * p.dim) + f * 4) = acc;
+        }
+    }
+    if (p.mode == 0) *(f32x4*)(p.out + v * p.dim + f * 4) = acc;
+}
+
+// -------------------------------------------------------------------------------------------------
+static DevBuf g_cn_buf;   // ||c||^2 scratch (per process; calls on one stream at a time)
+
+extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, const int* n_embed, int depth,
+                                 int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream) {
+    if (n_vec == 0) return RQAMD_OK;
+    if (!x || !codebooks || !n_embed || !codes) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: null argument");
+    if (depth < 1 || depth > RQ_MAX_DEPTH) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: depth %d not in 1..%d", depth, RQ_MAX_DEPTH);
+    if (dim % 64 != 0 || dim < 64 || dim > 256)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: dim %d must be 64, 128, 192 or 256", dim);
+    if (n_vec == 0) return RQAMD_OK;
+    if (n_vec < 0) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: n_vec < 0");
+    hipStream_t st = (hipStream_t)stream;
+    RqQuantArgs a{};
+    size_t total = 0;
+    for (int d = 0; d < depth; ++d) {
+        if (n_embed[d] < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: empty codebook");
+        total += (size_t)n_embed[d];
+    }
+    RQ_TRY(g_cn_buf.reserve(total * sizeof(float)));
+    size_t off = 0;
+    for (int d = 0; d < depth; ++d) {
+        a.cb[d] = codebooks[d];
+        a.K[d] = n_embed[d];
+        int shared = -1;
+        for (int e = 0; e < d; ++e)
+            if (codebooks[e] == codebooks[d] && n_embed[e] == n_embed[d]) { shared = e; break; }
+        if (shared >= 0) { a.cn[d] = a.cn[shared]; continue; }
+        float* cn = g_cn_buf.as<float>() + off;
+        off += n_embed[d];
+        RQ_LAUNCH(rq_code_norm_kernel, dim3((n_embed[d] + 255) / 256), dim3(256), 0, st, codebooks[d], n_embed[d], dim, cn);
+        a.cn[d] = cn;
+    }
+    a.x = x; a.depth = depth; a.dim = dim; a.n_vec = n_vec; a.codes = codes; a.quant_cum = quant_cum;
+    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float)
+                        + (4 * QT_M + QT_M) * sizeof(int);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    RQ_LAUNCH(rq_quantize_kernel, dim3((unsigned)((n_vec + QT_M - 1) / QT_M)), dim3(256), smem, st, a);
+    return rq_check_launch("rq_quantize_kernel");
+}
+
+extern "C" int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,
+                              int64_t n_vec, int dim, int mode, float* out, void* stream) {
+    if (n_vec == 0) return RQAMD_OK;
+    if (!codes || !codebooks || !n_embed || !out) return rq_fail(RQAMD_ERR_INVALID, "rq_embed: null argument");
+    if (depth < 1 || depth > RQ_MAX_DEPTH) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_embed: depth %d not in 1..%d", depth, RQ_MAX_DEPTH);
+    if (dim % 4 != 0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_embed: dim %d must be a multiple of 4", dim);
+    if (mode < 0 || mode > 2) return rq_fail(RQAMD_ERR_INVALID, "rq_embed: mode %d", mode);
+    if (n_vec == 0) return RQAMD_OK;
+    RqEmbedArgs a{};
+    for (int d = 0; d < depth; ++d) { a.cb[d] = codebooks[d]; a.K[d] = n_embed[d]; }
+    a.codes = codes; a.depth = depth; a.dim = dim; a.mode = mode; a.n_vec = n_vec; a.out = out;
+    long work = n_vec * (dim / 4);
+    RQ_LAUNCH(rq_embed_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return rq_check_launch("rq_embed_kernel");
+}

@@ -1,0 +1,56 @@
+// rq_common.h -- host-side helpers shared by the librqamd translation units.
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include "rq_hip.h"
+#include "../../include/rqamd.h"
+
+extern thread_local char rq_err_buf[512];
+
+static inline int rq_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(rq_err_buf, sizeof(rq_err_buf), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline int rq_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return RQAMD_OK;
+}
+
+#define RQ_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+#define RQ_TRY(call)                \
+    do {                            \
+        int s_ = (call);            \
+        if (s_ != RQAMD_OK) return s_; \
+    } while (0)
+
+// device buffer with RAII (engine-owned workspace)
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n) {
+        if (n <= bytes) return RQAMD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        bytes = n;
+        return RQAMD_OK;
+    }
+    template <typename T> T* as() const { return (T*)p; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};

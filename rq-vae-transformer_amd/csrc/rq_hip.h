@@ -1,0 +1,92 @@
+// rq_hip.h -- device/host prelude shared by every kernel file of librqamd (gfx950 only).
+//
+// Product builds go through hipcc (--offload-arch=gfx950).  tests/emu/ compiles the very same
+// kernel sources for the host with -DRQ_EMU against a fiber-based wave64/workgroup emulator, so
+// that index math can be checked in the CPU-only container; that build is test infrastructure and
+// never ships (see tests/emu/README.md).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef RQ_EMU
+#include "rq_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// vector / fragment types
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef unsigned short bf16_t;                                // raw bf16 bits
+
+#define RQ_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// bf16 <-> f32 (round-to-nearest-even), usable on host and device
+static inline __host__ __device__ float bf16_to_f32(bf16_t v) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)v) << 16;
+    return c.f;
+}
+static inline __host__ __device__ bf16_t f32_to_bf16(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static inline __host__ __device__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-collective wrappers (one spelling for hipcc and the emulator)
+#ifndef RQ_EMU
+static __device__ __forceinline__ f32x16 rq_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x4 rq_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x16 rq_mfma_32x32x2_f32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+static __device__ __forceinline__ float rq_shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+static __device__ __forceinline__ int rq_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
+static __device__ __forceinline__ float rq_shfl(float v, int lane) { return __shfl(v, lane, 64); }
+static __device__ __forceinline__ int rq_shfl_i(int v, int lane) { return __shfl(v, lane, 64); }
+static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
+#define RQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define RQ_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// wave reductions
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += rq_shfl_xor(v, m);
+    return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, rq_shfl_xor(v, m));
+    return v;
+}
+static __device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += rq_shfl_xor_i(v, m);
+    return v;
+}
+
+// 16-byte global/LDS access helpers
+struct __attribute__((aligned(16))) rq_u128 { uint32_t x, y, z, w; };
+static __device__ __forceinline__ rq_u128 ld128(const void* p) { return *(const rq_u128*)p; }
+static __device__ __forceinline__ void st128(void* p, rq_u128 v) { *(rq_u128*)p = v; }
+static __device__ __forceinline__ rq_u128 zero128() { rq_u128 z; z.x = z.y = z.z = z.w = 0; return z; }
+static __device__ __forceinline__ bf16x8 as_bf16x8(rq_u128 v) {
+    union { rq_u128 u; bf16x8 b; } c; c.u = v; return c.b;
+}

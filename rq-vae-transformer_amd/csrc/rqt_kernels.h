@@ -1,0 +1,75 @@
+// rqt_kernels.h -- non-GEMM kernels of the RQ-Transformer decode step (gfx950).
+//
+// Reference call sites (rqvae/models/rqtransformer/):
+//   resid_ln_kernel     <- x + attn / x + mlp residual adds and nn.LayerNorm (attentions.py:126-142,
+//                          transformers.py:91); also reduces the split-K partial slabs of the
+//                          producing GEMM (launch-boundary reduce) and adds its bias
+//   attn_decode_kernel  <- MultiSelfAttention.forward with caching=True (attentions.py:60-104):
+//                          KV append (torch.cat :75-76), q.(k^T/sqrt(hs)) :87, causal mask :88-91,
+//                          softmax :92, att.v :95 -- one wavefront per (batch row, head)
+//   embed_tokens_kernel <- model_aux.get_code_emb_with_depth + .sum(-2) / cumsum(-2)
+//                          (transformers.py:109-111,218-225,249-257), only for the NEW position
+//   cond_embed_kernel   <- cond_emb(cond) + pos_emb_cond (transformers.py:224)
+//   sample_kernel       <- sample_from_logits (rqvae/utils/utils.py:82-123), no host sync
+#pragma once
+#include "rq_hip.h"
+
+struct ResidLnArgs {
+    const float* x_in;      // [rows][E]
+    float* x_out;           // [rows][E] (may alias x_in); may be null when only y is wanted
+    const float* slabs;     // [n_slabs][rows][E] split-K partials of the producing GEMM, or null
+    int n_slabs;
+    const float* bias;      // [E] bias of the producing GEMM, or null
+    const float* addvec;    // [E] broadcast add (positional embedding), or null
+    const float* gamma;     // LayerNorm weight/bias; null => no LN output
+    const float* beta;
+    bf16_t* y;              // [rows][E] bf16 LN output
+    int rows, E;
+    float eps;
+};
+
+struct AttnDecodeArgs {
+    const bf16_t* qkv;      // [rows][3E]: q | k | v, head h at columns h*64..h*64+63 of each third
+    bf16_t* kc;             // K cache [rows][nh][8][Tcap][8]   (chunk-major: coalesced per-key reads)
+    bf16_t* vc;             // V cache [rows][nh][Tcap][64]
+    bf16_t* y;              // [rows][E]
+    const int* step;        // device-side step counter (or null)
+    int step_off;           // t = *step + step_off = number of cached keys before this token
+    int rows, nh, E, Tcap;
+};
+
+struct EmbedTokArgs {
+    const int64_t* xs;      // [rows][HW][D] codes
+    const float* cb[8];     // per-depth codebooks (K, dim), padding row excluded
+    int K[8];
+    const int* pos;         // device-side spatial position
+    int pos_off;            // position read = *pos + pos_off
+    int n_depth;            // sum over depths [0, n_depth)
+    int rows, HW, D, dim;
+    bf16_t* out;            // [rows][dim]
+};
+
+struct SampleArgs {
+    const float* logits;    // [rows][V]
+    int rows, V;
+    float temperature;
+    int top_k;              // <=0 or >=V: off
+    float top_p;            // <0: off
+    const uint64_t* rng;    // device {seed, offset}; or null -> seed/offset below
+    uint64_t seed, offset;
+    const int* pos;         // device-side spatial position (or null)
+    int d, D;               // depth index / depth count: draw counter = offset + (*pos * D + d)
+    int64_t* out;           // samples: out[row * out_stride + (*pos * D + d)] (pos null -> out[row*out_stride])
+    long out_stride;
+    float* probs_out;       // [rows][V] filtered distribution, or null
+};
+
+int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s);
+int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int rq_launch_embed_tokens(const EmbedTokArgs& a, hipStream_t s);
+int rq_launch_cond_embed(const int64_t* cond, int cond_stride, int cond_idx, const float* cond_emb, int vocab_cond,
+                         const float* pos_emb_cond, float* x, int rows, int E, hipStream_t s);
+int rq_launch_sample(const SampleArgs& a, hipStream_t s);
+int rq_launch_cvt_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
+int rq_launch_set_int(int* p, int v, hipStream_t s);
+int rq_launch_add_int(int* p, int v, hipStream_t s);

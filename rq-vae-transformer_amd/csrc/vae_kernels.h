@@ -1,0 +1,12 @@
+// vae_kernels.h -- launchers of the non-GEMM RQ-VAE kernels (see vae_kernels.hip)
+#pragma once
+#include "rq_hip.h"
+
+#define RQ_GN_MAX_CHUNK 64
+
+int rq_launch_groupnorm(const bf16_t* x, bf16_t* y, float* part, const float* gamma, const float* beta, int B, int HW, int C,
+                        int silu, hipStream_t s);
+int rq_launch_vae_attn(const bf16_t* qkv, bf16_t* out, int B, int T, int C, hipStream_t s);
+int rq_launch_conv_in3(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);
+int rq_launch_conv_out3(const bf16_t* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);
+int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int kw, int mode, hipStream_t s);

@@ -1,0 +1,314 @@
+// vae_kernels.hip -- non-GEMM kernels of the RQ-VAE encoder/decoder (gfx950).  Activations are
+// NHWC bf16 between layers (fp32 accumulation everywhere), so channel vectors are contiguous 16-B
+// chunks and every kernel below moves whole chunks.
+//
+// Reference call sites (rqvae/models/rqvae/):
+//   gn_stats / gn_apply  <- Normalize = GroupNorm(32, C, eps=1e-6) + nonlinearity = SiLU (layers.py:11-17)
+//   vae_attn_kernel      <- AttnBlock.forward (layers.py:158-182): softmax(q k^T * C^-0.5) v, single head
+//   conv_in3_kernel      <- Encoder.conv_in (modules.py:23-27): 3 -> ch, reads the NCHW fp32 image
+//   conv_out3_kernel     <- Decoder.conv_out (modules.py:165-169): ch -> 3, writes the NCHW fp32 image
+//   repack_conv_kernel   <- nn.Conv2d weight (O,I,kh,kw) fp32 -> [O][kh][kw][I] bf16 (GEMM "W[N][K]")
+#include "rq_common.h"
+#include "vae_kernels.h"
+
+static __device__ __forceinline__ void unpack8v(rq_u128 u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+
+// -------------------------------------------------------------------------------------------------
+// GroupNorm statistics: partial (sum, sumsq) per (image, pixel-chunk, group); deterministic order.
+// grid (nchunk, B), 256 threads; thread t owns channel chunk cc = t % (C/8) and pixels prow, prow+PR, ...
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, float* part, int HW, int C, int nchunk) {
+    __shared__ float sp[256][8];
+    const int tid = threadIdx.x, CC = C / 8, PR = 256 / CC;
+    const int cc = tid % CC, prow = tid / CC;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (HW + nchunk - 1) / nchunk;
+    const int p0 = chunk * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    const int gs = C / 32;                      // channels per group: 2, 4, 8, 16, ...
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    if (prow < PR)
+        for (int px = p0 + prow; px < p1; px += PR) {
+            float f[8];
+            unpack8v(ld128(x + ((long)b * HW + px) * C + cc * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] = fmaf(f[e], f[e], ss[e]); }
+        }
+    // fold the 8 channels into this thread's groups: npt = max(1, 8/gs) (sum, sumsq) pairs
+    const int sub = gs >= 8 ? 8 : gs;           // channels per pair
+    const int npt = 8 / sub;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float a = 0.f, q = 0.f;
+        if (k < npt)
+            for (int e = 0; e < sub; ++e) { a += s[k * sub + e]; q += ss[k * sub + e]; }
+        sp[tid][2 * k] = a;
+        sp[tid][2 * k + 1] = q;
+    }
+    rq_syncthreads();
+    if (tid < 32) {
+        const int g = tid;
+        float a = 0.f, q = 0.f;
+        if (gs >= 8) {
+            const int c0 = g * gs / 8, c1 = c0 + gs / 8;      // channel chunks of this group
+            for (int r = 0; r < PR; ++r)
+                for (int c = c0; c < c1; ++c) { a += sp[r * CC + c][0]; q += sp[r * CC + c][1]; }
+        } else {
+            const int c = g * gs / 8, k = (g * gs % 8) / gs;
+            for (int r = 0; r < PR; ++r) { a += sp[r * CC + c][2 * k]; q += sp[r * CC + c][2 * k + 1]; }
+        }
+        float* o = part + (((long)b * nchunk + chunk) * 32 + g) * 2;
+        o[0] = a;
+        o[1] = q;
+    }
+}
+
+// apply: y = (x - mean) * rstd * gamma + beta, optional SiLU; grid (nblk, B)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, const float* part, const float* gamma, const float* beta,
+                                                       bf16_t* y, int HW, int C, int nchunk, float eps, int silu) {
+    __shared__ float smean[32], srstd[32];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < 32) {
+        float a = 0.f, q = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            const float* o = part + (((long)b * nchunk + c) * 32 + tid) * 2;
+            a += o[0];
+            q += o[1];
+        }
+        const float n = (float)HW * (float)(C / 32);
+        const float mean = a / n;
+        float var = q / n - mean * mean;
+        if (var < 0.f) var = 0.f;
+        smean[tid] = mean;
+        srstd[tid] = 1.0f / sqrtf(var + eps);
+    }
+    rq_syncthreads();
+    const int CC = C / 8, gs = C / 32;
+    const long nvec = (long)HW * CC;
+    for (long i = (long)blockIdx.x * 256 + tid; i < nvec; i += (long)gridDim.x * 256) {
+        const int cc = (int)(i % CC);
+        const long off = ((long)b * HW) * C + i * 8;
+        float f[8];
+        unpack8v(ld128(x + off), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = cc * 8 + e, g = ch / gs;
+            float v = (f[e] - smean[g]) * srstd[g] * gamma[ch] + beta[ch];
+            if (silu) v = v / (1.0f + __expf(-v));
+            f[e] = v;
+        }
+        rq_u128 o;
+        o.x = pack_bf16x2(f[0], f[1]); o.y = pack_bf16x2(f[2], f[3]); o.z = pack_bf16x2(f[4], f[5]); o.w = pack_bf16x2(f[6], f[7]);
+        st128(y + off, o);
+    }
+}
+
+int rq_launch_groupnorm(const bf16_t* x, bf16_t* y, float* part, const float* gamma, const float* beta, int B, int HW, int C,
+                        int silu, hipStream_t s) {
+    if (C % 32 != 0 || C % 8 != 0 || 256 % (C / 8) != 0 || C > 2048)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "groupnorm: channels %d unsupported (need 64,128,256,512,1024,2048)", C);
+    int nchunk = HW / 64;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > RQ_GN_MAX_CHUNK) nchunk = RQ_GN_MAX_CHUNK;
+    RQ_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, HW, C, nchunk);
+    RQ_TRY(rq_check_launch("gn_stats_kernel"));
+    long nvec = (long)HW * C / 8;
+    int nblk = (int)((nvec + 1023) / 1024);
+    if (nblk < 1) nblk = 1;
+    if (nblk > 256) nblk = 256;
+    RQ_LAUNCH(gn_apply_kernel, dim3(nblk, B), dim3(256), 0, s, x, part, gamma, beta, y, HW, C, nchunk, 1e-6f, silu);
+    return rq_check_launch("gn_apply_kernel");
+}
+
+// -------------------------------------------------------------------------------------------------
+// single-head spatial attention: one wavefront per query token.  qkv [B*T][3C] bf16 -> out [B*T][C]
+template <int NB>   // key blocks of 64: T <= 64*NB
+__global__ __launch_bounds__(256) void vae_attn_kernel(const bf16_t* qkv, bf16_t* out, int B, int T, int C, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long qi = (long)blockIdx.x * 4 + wave;        // global query index
+    if (qi >= (long)B * T) return;
+    const long b = qi / T;
+    const bf16_t* base = qkv + b * T * 3 * C;
+    const bf16_t* q = qkv + qi * 3 * C;
+    float sc[NB];
+    float mx = -__int_as_float(0x7f800000);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = nb * 64 + lane;
+        float s = -__int_as_float(0x7f800000);
+        if (j < T) {
+            const bf16_t* k = base + (long)j * 3 * C + C;
+            float dot = 0.f;
+            for (int c = 0; c < C; c += 8) {
+                float qf[8], kf[8];
+                unpack8v(ld128(q + c), qf);
+                unpack8v(ld128(k + c), kf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+            }
+            s = dot * scale;
+        }
+        sc[nb] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = nb * 64 + lane;
+        sc[nb] = (j < T) ? expf(sc[nb] - mx) : 0.f;
+        sum += sc[nb];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    // out[c] = sum_j p_j v_j[c]; lane owns channel chunks lane, lane+64, ... (8 channels each)
+    const int nch = C / 8;
+    for (int ch0 = 0; ch0 < nch; ch0 += 64) {
+        const int ch = ch0 + lane;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            for (int jl = 0; jl < 64; ++jl) {
+                const int j = nb * 64 + jl;
+                const float pj = rq_shfl(sc[nb], jl) * inv;
+                if (j < T && ch < nch) {
+                    float vf[8];
+                    unpack8v(ld128(base + (long)j * 3 * C + 2 * C + ch * 8), vf);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+                }
+            }
+        }
+        if (ch < nch) {
+            rq_u128 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+            st128(out + qi * C + ch * 8, o);
+        }
+    }
+}
+
+int rq_launch_vae_attn(const bf16_t* qkv, bf16_t* out, int B, int T, int C, hipStream_t s) {
+    if (C % 8 != 0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "vae attention: C %d", C);
+    const float scale = 1.0f / sqrtf((float)C);      // int(c)**(-0.5), layers.py:170
+    dim3 grid((unsigned)(((long)B * T + 3) / 4));
+    if (T <= 64) RQ_LAUNCH(vae_attn_kernel<1>, grid, dim3(256), 0, s, qkv, out, B, T, C, scale);
+    else if (T <= 256) RQ_LAUNCH(vae_attn_kernel<4>, grid, dim3(256), 0, s, qkv, out, B, T, C, scale);
+    else if (T <= 1024) RQ_LAUNCH(vae_attn_kernel<16>, grid, dim3(256), 0, s, qkv, out, B, T, C, scale);
+    else return rq_fail(RQAMD_ERR_UNSUPPORTED, "vae attention: %d tokens > 1024", T);
+    return rq_check_launch("vae_attn_kernel");
+}
+
+// -------------------------------------------------------------------------------------------------
+// Encoder.conv_in: x NCHW fp32 (Cin <= 4) -> y NHWC bf16 (Cout).  w: [ky][kx][ci][co] fp32.
+__global__ __launch_bounds__(256) void conv_in3_kernel(const float* x, const float* w, const float* bias, bf16_t* y,
+                                                       int B, int H, int W, int Cin, int Cout) {
+    RQ_DYN_SMEM(smem);
+    float* sw = (float*)smem;                      // [9*Cin][Cout]
+    for (int i = threadIdx.x; i < 9 * Cin * Cout; i += 256) sw[i] = w[i];
+    rq_syncthreads();
+    const int CC = Cout / 8;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)B * H * W * CC) return;
+    const int cc = (int)(gid % CC);
+    const long pix = gid / CC;
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bias[cc * 8 + e];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float v = x[(((long)b * Cin + ci) * H + iy) * W + ix];
+                const float* wr = sw + ((ky * 3 + kx) * Cin + ci) * Cout + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
+            }
+        }
+    rq_u128 o;
+    o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]); o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+    st128(y + pix * Cout + cc * 8, o);
+}
+
+int rq_launch_conv_in3(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+    if (Cout % 8 != 0 || Cin > 4 || 9 * Cin * Cout * 4 > 60000) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_in: Cin %d Cout %d", Cin, Cout);
+    const long n = (long)B * H * W * (Cout / 8);
+    RQ_LAUNCH(conv_in3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), (size_t)9 * Cin * Cout * 4, s, x, w, bias, y, B, H, W, Cin, Cout);
+    return rq_check_launch("conv_in3_kernel");
+}
+
+// Decoder.conv_out: x NHWC bf16 (Cin) -> y NCHW fp32 (Cout <= 4).  w: [co][ky][kx][ci] fp32.
+// 8 lanes per output pixel, each owning channel chunks l8, l8+8, ...; partials reduced by xor-shuffles.
+__global__ __launch_bounds__(256) void conv_out3_kernel(const bf16_t* x, const float* w, const float* bias, float* y,
+                                                        int B, int H, int W, int Cin, int Cout) {
+    RQ_DYN_SMEM(smem);
+    float* sw = (float*)smem;                      // [Cout][9][Cin]
+    for (int i = threadIdx.x; i < Cout * 9 * Cin; i += 256) sw[i] = w[i];
+    rq_syncthreads();
+    const int l8 = threadIdx.x & 7;
+    long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool ok = pix < (long)B * H * W;
+    if (!ok) pix = 0;
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nch = Cin / 8;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const bf16_t* src = x + (((long)b * H + iy) * W + ix) * Cin;
+            for (int ch = l8; ch < nch; ch += 8) {
+                float f[8];
+                unpack8v(ld128(src + ch * 8), f);
+                for (int co = 0; co < Cout; ++co) {
+                    const float* wr = sw + (co * 9 + ky * 3 + kx) * Cin + ch * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[co] = fmaf(f[e], wr[e], acc[co]);
+                }
+            }
+        }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) {
+        acc[co] += rq_shfl_xor(acc[co], 1);
+        acc[co] += rq_shfl_xor(acc[co], 2);
+        acc[co] += rq_shfl_xor(acc[co], 4);
+    }
+    if (ok && l8 < Cout) y[(((long)b * Cout + l8) * H + oy) * W + ox] = acc[l8] + bias[l8];
+}
+
+int rq_launch_conv_out3(const bf16_t* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+    if (Cin % 8 != 0 || Cout > 4 || Cout * 9 * Cin * 4 > 60000) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_out: Cin %d Cout %d", Cin, Cout);
+    const long n = (long)B * H * W;
+    RQ_LAUNCH(conv_out3_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), (size_t)Cout * 9 * Cin * 4, s, x, w, bias, y, B, H, W, Cin, Cout);
+    return rq_check_launch("conv_out3_kernel");
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight repacks.  mode 0: (O,I,kh,kw) fp32 -> [O][kh][kw][I] bf16; mode 1: -> [kh][kw][I][O] fp32 (conv_in);
+// mode 2: -> [O][kh][kw][I] fp32 (conv_out)
+__global__ void repack_conv_kernel(const float* src, void* dst, int O, int I, int kh, int kw, int mode) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)O * I * kh * kw;
+    if (gid >= n) return;
+    // gid enumerates the source layout
+    const int x = (int)(gid % kw), yk = (int)((gid / kw) % kh), i = (int)((gid / ((long)kw * kh)) % I), o = (int)(gid / ((long)kw * kh * I));
+    const float v = src[gid];
+    if (mode == 0) ((bf16_t*)dst)[(((long)o * kh + yk) * kw + x) * I + i] = f32_to_bf16(v);
+    else if (mode == 1) ((float*)dst)[(((long)yk * kw + x) * I + i) * O + o] = v;
+    else ((float*)dst)[(((long)o * kh + yk) * kw + x) * I + i] = v;
+}
+
+int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int kw, int mode, hipStream_t s) {
+    const long n = (long)O * I * kh * kw;
+    RQ_LAUNCH(repack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, O, I, kh, kw, mode);
+    return rq_check_launch("repack_conv_kernel");
+}

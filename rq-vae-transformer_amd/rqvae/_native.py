@@ -1,0 +1,264 @@
+"""ctypes binding of librqamd.so (include/rqamd.h) -- the only bridge between the Python mirror of the
+reference's ``rqvae.models`` API and the gfx950 kernels.
+
+There is no CPU path: if the library (or a GPU tensor) is missing this module raises.  PyTorch is used
+for device memory and streams only; every argument crossing the ABI is a raw pointer / size."""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, 'librqamd.so')
+
+_lib = None
+_allow_host_pointers = False   # flipped only by the emulator tests (tests/emu), never by product code
+
+
+class RqamdError(RuntimeError):
+    pass
+
+
+class VaeConfig(C.Structure):
+    _fields_ = [('ch', C.c_int), ('out_ch', C.c_int), ('in_channels', C.c_int), ('resolution', C.c_int),
+                ('z_channels', C.c_int), ('num_res_blocks', C.c_int), ('n_levels', C.c_int), ('ch_mult', C.c_int * 8),
+                ('n_attn_res', C.c_int), ('attn_resolutions', C.c_int * 8), ('embed_dim', C.c_int), ('double_z', C.c_int)]
+
+
+class RqtConfig(C.Structure):
+    _fields_ = [('embed_dim', C.c_int), ('n_head', C.c_int), ('n_layer_body', C.c_int), ('n_layer_head', C.c_int),
+                ('vocab_size', C.c_int), ('input_embed_dim', C.c_int), ('vocab_size_cond', C.c_int),
+                ('block_size_cond', C.c_int), ('H', C.c_int), ('W', C.c_int), ('D', C.c_int), ('gelu_v2', C.c_int)]
+
+
+_SIGS = {
+    'rqamd_abi_version': (C.c_int, []),
+    'rqamd_last_error': (C.c_char_p, []),
+    'rqamd_rq_quantize': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
+                                 C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_sample_logits': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_vae_create': (C.c_int, [C.POINTER(VaeConfig), C.POINTER(C.c_void_p)]),
+    'rqamd_vae_destroy': (C.c_int, [C.c_void_p]),
+    'rqamd_vae_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    'rqamd_vae_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_vae_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_create': (C.c_int, [C.POINTER(RqtConfig), C.POINTER(C.c_void_p)]),
+    'rqamd_rqt_destroy': (C.c_int, [C.c_void_p]),
+    'rqamd_rqt_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    'rqamd_rqt_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int,
+                                   C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_set_profile': (C.c_int, [C.c_void_p, C.c_int]),
+    'rqamd_rqt_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double)]),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def _bind(path):
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.rqamd_abi_version() != 1:
+        raise RqamdError(f'{path}: ABI version {lib.rqamd_abi_version()} != 1')
+    return lib
+
+
+def lib():
+    """The loaded librqamd.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RqamdError(f'{LIB_PATH} not found: build it with `python rq-vae-transformer_amd/build.py` '
+                             '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _load_for_testing(path, allow_host_pointers):
+    """tests/emu only: bind another build of the same sources (the host emulator)."""
+    global _lib, _allow_host_pointers
+    _lib = _bind(path)
+    _allow_host_pointers = allow_host_pointers
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = lib().rqamd_last_error().decode(errors='replace')
+        if status == -1:
+            raise ValueError(msg)
+        if status == -2:
+            raise NotImplementedError(msg)
+        raise RqamdError(f'librqamd status {status}: {msg}')
+
+
+def ptr(t, dtype=None):
+    """Raw device pointer of a contiguous tensor (validated)."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _allow_host_pointers:
+        raise RqamdError('librqamd needs CUDA(HIP) tensors on an MI355X; got a CPU tensor (no CPU fallback exists)')
+    if not t.is_contiguous():
+        raise ValueError('non-contiguous tensor passed to librqamd')
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f'expected {dtype}, got {t.dtype}')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def _ptr_array(tensors, dtype=torch.float32):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t, dtype).value
+    return arr
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+# ---------------------------------------------------------------------------------------------- free functions
+def rq_quantize(x, codebooks, want_quants=True):
+    """x (n_vec, dim) fp32; codebooks: list of (K_i, dim) fp32 (padding row excluded).
+    -> codes (n_vec, depth) int64, quant_cum (depth, n_vec, dim) fp32 or None."""
+    n_vec, dim = x.shape
+    depth = len(codebooks)
+    codes = torch.empty((n_vec, depth), dtype=torch.int64, device=x.device)
+    quants = torch.empty((depth, n_vec, dim), dtype=torch.float32, device=x.device) if want_quants else None
+    check(lib().rqamd_rq_quantize(ptr(x, torch.float32), _ptr_array(codebooks), _int_array([c.shape[0] for c in codebooks]),
+                                  depth, n_vec, dim, ptr(codes), ptr(quants), stream_of(x)))
+    return codes, quants
+
+
+def rq_embed(codes, codebooks, mode):
+    """codes (n_vec, depth) int64 -> mode 0: (n_vec, dim); 1: (n_vec, depth, dim); 2: depth-cumsum."""
+    n_vec, depth = codes.shape
+    dim = codebooks[0].shape[1]
+    shape = (n_vec, dim) if mode == 0 else (n_vec, depth, dim)
+    out = torch.empty(shape, dtype=torch.float32, device=codes.device)
+    check(lib().rqamd_rq_embed(ptr(codes, torch.int64), _ptr_array(codebooks), _int_array([c.shape[0] for c in codebooks]),
+                               depth, n_vec, dim, mode, ptr(out), stream_of(codes)))
+    return out
+
+
+def sample_logits(logits, temperature=1.0, top_k=None, top_p=None, seed=0, offset=0, want_probs=False, want_samples=True):
+    rows, vocab = logits.shape
+    samples = torch.empty((rows,), dtype=torch.int64, device=logits.device) if want_samples else None
+    probs = torch.empty((rows, vocab), dtype=torch.float32, device=logits.device) if want_probs else None
+    check(lib().rqamd_sample_logits(ptr(logits, torch.float32), rows, vocab, float(temperature),
+                                    0 if top_k is None else int(top_k), -1.0 if top_p is None else float(top_p),
+                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(samples), ptr(probs),
+                                    stream_of(logits)))
+    return samples, probs
+
+
+# ---------------------------------------------------------------------------------------------- engines
+class _Engine:
+    _create = _destroy = _set = None
+
+    def __init__(self, cfg_struct):
+        self._h = C.c_void_p()
+        check(getattr(lib(), self._create)(C.byref(cfg_struct), C.byref(self._h)))
+
+    def set_param(self, name, tensor):
+        t = tensor.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        check(getattr(lib(), self._set)(self._h, name.encode(), ptr(t, torch.float32), shape, t.dim(), stream_of(t)))
+        if t.is_cuda:
+            t.record_stream(torch.cuda.current_stream(t.device))
+
+    def close(self):
+        if self._h is not None and self._h.value and _lib is not None:
+            getattr(_lib, self._destroy)(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VaeEngine(_Engine):
+    _create, _destroy, _set = 'rqamd_vae_create', 'rqamd_vae_destroy', 'rqamd_vae_set_param'
+
+    def __init__(self, ddconfig, embed_dim):
+        c = VaeConfig()
+        c.ch, c.out_ch, c.in_channels = ddconfig['ch'], ddconfig['out_ch'], ddconfig['in_channels']
+        c.resolution, c.z_channels, c.num_res_blocks = ddconfig['resolution'], ddconfig['z_channels'], ddconfig['num_res_blocks']
+        mult, attn = list(ddconfig['ch_mult']), list(ddconfig['attn_resolutions'])
+        if len(mult) > 8 or len(attn) > 8:
+            raise NotImplementedError('more than 8 resolution levels')
+        c.n_levels, c.n_attn_res = len(mult), len(attn)
+        for i, m in enumerate(mult):
+            c.ch_mult[i] = int(m)
+        for i, a in enumerate(attn):
+            c.attn_resolutions[i] = int(a)
+        c.embed_dim, c.double_z = int(embed_dim), int(bool(ddconfig.get('double_z', True)))
+        self.cfg = c
+        super().__init__(c)
+
+    def decode(self, z_q):
+        """z_q (B,h,w,embed_dim) fp32 NHWC -> (B,out_ch,H,W) fp32"""
+        B = z_q.shape[0]
+        out = torch.empty((B, self.cfg.out_ch, self.cfg.resolution, self.cfg.resolution), dtype=torch.float32, device=z_q.device)
+        check(lib().rqamd_vae_decode(self._h, ptr(z_q, torch.float32), B, ptr(out), stream_of(z_q)))
+        return out
+
+    def encode(self, x):
+        """x (B,in_channels,H,W) fp32 -> z_e (B,h,w,embed_dim) fp32 NHWC"""
+        B = x.shape[0]
+        lr = self.cfg.resolution >> (self.cfg.n_levels - 1)
+        out = torch.empty((B, lr, lr, self.cfg.embed_dim), dtype=torch.float32, device=x.device)
+        check(lib().rqamd_vae_encode(self._h, ptr(x, torch.float32), B, ptr(out), stream_of(x)))
+        return out
+
+
+class RqtEngine(_Engine):
+    _create, _destroy, _set = 'rqamd_rqt_create', 'rqamd_rqt_destroy', 'rqamd_rqt_set_param'
+
+    def __init__(self, *, embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
+                 block_size_cond, block_size, gelu_v2=False):
+        c = RqtConfig(embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
+                      block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2))
+        self.cfg = c
+        super().__init__(c)
+
+    def sample(self, partial, cond, codebooks, start_loc, temperature, top_k, top_p, seed, offset, use_graph):
+        B = partial.shape[0]
+        out = torch.empty_like(partial)
+        D = self.cfg.D
+        check(lib().rqamd_rqt_sample(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
+                                     int(start_loc[0]), int(start_loc[1]), float(temperature), _int_array(top_k[:D]),
+                                     (C.c_float * D)(*[float(p) for p in top_p[:D]]), int(seed) & (2 ** 64 - 1),
+                                     int(offset) & (2 ** 64 - 1), int(bool(use_graph)), ptr(out), stream_of(partial)))
+        return out
+
+    def logits(self, codes, cond, codebooks):
+        B = codes.shape[0]
+        c = self.cfg
+        out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
+        check(lib().rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
+                                     ptr(out), stream_of(codes)))
+        return out
+
+    def set_profile(self, on):
+        check(lib().rqamd_rqt_set_profile(self._h, int(bool(on))))
+
+    def get_profile(self):
+        ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib().rqamd_rqt_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)))
+        return dict(gemm_ms_total=ms.value, gemm_launches=n.value, gemm_bytes=by.value, gemm_flops=fl.value)

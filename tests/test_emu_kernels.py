@@ -1,0 +1,174 @@
+"""CPU-only checks of the HIP kernel SOURCES through the host emulator (tests/emu): same .hip files,
+same C ABI, same ctypes binding, executed by fibers instead of a GPU, compared against the oracle and
+the reference-generated golden fixtures.  These tests exist because the build container has no GPU;
+the authoritative parity tests are the `-m gpu` ones (tests/test_gpu_*.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import configs as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = os.environ.get('RQ_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason='no host clang++ for the emulator build')
+
+
+@pytest.fixture(scope='module')
+def nat():
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'emu'))
+    import build_emu
+    path = build_emu.build()
+    from rqvae import _native
+    saved = (_native._lib, _native._allow_host_pointers)
+    _native._load_for_testing(path, allow_host_pointers=True)
+    yield _native
+    _native._lib, _native._allow_host_pointers = saved
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_emu_rq_quantize_and_embed(nat, golden):
+    g = golden('rq_small.npz')
+    x, cb = T(g['x'].reshape(-1, 64)), T(g['codebook'])
+    codes, quants = nat.rq_quantize(x, [cb] * 4)
+    assert np.array_equal(codes.numpy().reshape(g['codes'].shape), g['codes'])
+    np.testing.assert_array_equal(quants.numpy().reshape(g['quant_list'].shape), g['quant_list'])
+    codes_only, none = nat.rq_quantize(x, [cb] * 4, want_quants=False)
+    assert none is None and torch.equal(codes_only, codes)
+    e0 = nat.rq_embed(codes, [cb] * 4, 0).numpy()
+    np.testing.assert_array_equal(e0.reshape(g['quant_list'][-1].shape), g['quant_list'][-1])
+    e1 = nat.rq_embed(codes, [cb] * 4, 1).numpy()
+    np.testing.assert_array_equal(e1.reshape(g['embed_with_depth'].shape), g['embed_with_depth'])
+    e2 = nat.rq_embed(codes, [cb] * 4, 2).numpy()
+    np.testing.assert_array_equal(e2, np.cumsum(e1, 1, dtype=np.float32))
+
+
+def test_emu_rq_quantize_ragged(nat):
+    """n_vec not a multiple of the 64-vector tile, K not a multiple of the 128-code tile, unshared codebooks."""
+    rng = np.random.default_rng(5)
+    cbs = [rng.standard_normal((k, 128), dtype=np.float32) for k in (130, 70, 257)]
+    x = rng.standard_normal((1, 5, 15, 128), dtype=np.float32)
+    codes, quants = nat.rq_quantize(T(x.reshape(-1, 128)), [T(c) for c in cbs])
+    oq, oc = oracle.rq_quantize(x, cbs)
+    gaps, _ = oracle.rq_quantize_margins(x, cbs)
+    assert gaps.min() > 1e-3
+    assert np.array_equal(codes.numpy().reshape(oc.shape), oc)
+    np.testing.assert_allclose(quants.numpy().reshape(3, 1, 5, 15, 128), np.stack(oq), rtol=0, atol=1e-6)
+    assert nat.rq_quantize(T(np.zeros((0, 128), np.float32)), [T(c) for c in cbs])[0].shape == (0, 3)
+
+
+@pytest.mark.parametrize('case', [0, 2, 3, 4, 6, 7])
+def test_emu_sampler_filter(nat, golden, case):
+    g = golden('sampler.npz')
+    t, k, p = g['cases'][case]
+    _, probs = nat.sample_logits(T(g['logits']), t, None if k < 0 else int(k), None if p < 0 else float(p),
+                                 want_probs=True, want_samples=False)
+    ref = g[f'probs_{case}']
+    o = probs.numpy()
+    tie_free = [0, 2, 4, 5, 6, 7]
+    assert 0.5 * np.abs(o - ref).sum(-1)[tie_free].max() < 1e-5
+    assert np.abs(np.sort(o, -1) - np.sort(ref, -1)).sum(-1).max() < 1e-4
+    assert np.array_equal((o > 0).sum(-1), (ref > 0).sum(-1))
+
+
+def test_emu_sampler_draws(nat):
+    """Draw statistics of the exponential-race sampler against the filtered distribution."""
+    rng = np.random.default_rng(3)
+    logits = np.tile((2.0 * rng.standard_normal((1, 40))).astype(np.float32), (64, 1))
+    probs = oracle.filtered_probs(logits[:1], 1.0, 10, 0.9)[0]
+    counts = np.zeros(40)
+    for rep in range(6):
+        s, _ = nat.sample_logits(T(logits), 1.0, 10, 0.9, seed=7, offset=rep)
+        counts += np.bincount(s.numpy(), minlength=40)
+    assert counts[probs == 0].sum() == 0
+    n = counts.sum()
+    chi2 = (((counts - n * probs) ** 2) / (n * probs + 1e-12))[probs > 0].sum()
+    assert chi2 < 40.0        # 9 dof would be ~9; generous bound, catches a broken RNG/argmax
+    s1, _ = nat.sample_logits(T(logits), 1.0, 10, 0.9, seed=7, offset=0)
+    s2, _ = nat.sample_logits(T(logits), 1.0, 10, 0.9, seed=7, offset=0)
+    assert torch.equal(s1, s2)
+
+
+def _rqt_engine(nat, cfg, params):
+    eng = nat.RqtEngine(embed_dim=cfg['embed_dim'], n_head=cfg['body']['block']['n_head'], n_layer_body=cfg['body']['n_layer'],
+                        n_layer_head=cfg['head']['n_layer'], vocab_size=cfg['vocab_size'], input_embed_dim=cfg['input_embed_dim'],
+                        vocab_size_cond=cfg['vocab_size_cond'], block_size_cond=cfg['block_size_cond'],
+                        block_size=cfg['block_size'], gelu_v2=cfg.get('gelu', 'v1') == 'v2')
+    for k, v in params.items():
+        eng.set_param(k, T(v))
+    return eng
+
+
+def test_emu_rqt_tiny_logits(nat, golden):
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    eng = _rqt_engine(nat, cfg, params)
+    codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
+    logits = eng.logits(codes, cond, [T(cb)] * 4).numpy()
+    err = np.abs(logits - g['logits'])
+    print('emu rqt tiny logits: max err %.4f mean err %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01          # bf16 weights/activations vs fp32 reference, |logits| <= 2.4
+
+
+def test_emu_rqt_tiny_sample(nat, golden):
+    """sample(): teacher-forcing the sampled codes back through the logits path must reproduce, at every
+    step, a distribution under which the sampled code has non-zero filtered probability."""
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    eng = _rqt_engine(nat, cfg, params)
+    cond = T(g['cond'].astype(np.int64))
+    partial = torch.zeros((3, 4, 4, 4), dtype=torch.int64)
+    out = eng.sample(partial, cond, [T(cb)] * 4, (0, 0), 1.0, [5] * 4, [0.9] * 4, seed=11, offset=0, use_graph=False)
+    assert out.shape == partial.shape and int(out.min()) >= 0 and int(out.max()) < cfg['vocab_size']
+    assert int(partial.abs().sum()) == 0                      # input untouched (transformers.py:332 clones)
+    out2 = eng.sample(partial, cond, [T(cb)] * 4, (0, 0), 1.0, [5] * 4, [0.9] * 4, seed=11, offset=0, use_graph=False)
+    assert torch.equal(out, out2)                             # same (seed, offset) -> same codes
+    logits = eng.logits(out, cond, [T(cb)] * 4).numpy()
+    for h in range(4):
+        for w in range(4):
+            for d in range(4):
+                pr = oracle.filtered_probs(logits[:, h, w, d], 1.0, 5, 0.9)
+                sel = pr[np.arange(3), out[:, h, w, d].numpy()]
+                assert (sel > 0).all()
+    # start_loc: rows before it are kept from partial_sample (transformers.py:347-348)
+    part2 = out.clone()
+    part2[:, 2:] = 0
+    out3 = eng.sample(part2, cond, [T(cb)] * 4, (2, 0), 1.0, [5] * 4, [0.9] * 4, seed=11, offset=0, use_graph=False)
+    assert torch.equal(out3[:, :2], out[:, :2])
+
+
+def _vae_engine(nat, hps, dd, params):
+    eng = nat.VaeEngine(dd, hps['embed_dim'])
+    for k, v in params.items():
+        if not k.startswith('quantizer.'):
+            eng.set_param(k, T(v))
+    return eng
+
+
+def test_emu_vae_tiny(nat, golden):
+    g = golden('vae_tiny.npz')
+    hps, dd = C.VAE_TINY
+    params = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed']))
+    eng = _vae_engine(nat, hps, dd, params)
+    cb = params['quantizer.codebooks.0.weight'][:-1]
+    z_q = oracle.rq_embed_code(g['codes'], [cb] * 4)
+    dec = eng.decode(T(z_q)).numpy()
+    err = np.abs(dec - g['decode_code'])
+    print('emu vae tiny decode: max err %.4f mean %.5f (|ref| max %.3f)' % (err.max(), err.mean(), np.abs(g['decode_code']).max()))
+    assert err.max() < 0.05 and err.mean() < 0.008
+    z_e = eng.encode(T(g['x'])).numpy()
+    err = np.abs(z_e - g['z_e'])
+    print('emu vae tiny encode: max err %.4f mean %.5f (|ref| max %.3f)' % (err.max(), err.mean(), np.abs(g['z_e']).max()))
+    assert err.max() < 0.05 and err.mean() < 0.008
