@@ -1,0 +1,210 @@
+"""Stage-2 model: API mirror of rqvae/models/rqtransformer/transformers.py:34-369 of the reference.
+
+``sample`` keeps the reference signature (transformers.py:294-308) and semantics -- partial_sample is
+cloned not mutated, rows before start_loc are kept, per-depth top-k/top-p lists, cond None -> zeros --
+but the 256-step loop runs inside librqamd's sampling engine (csrc/engine_rqt.hip): one C call enqueues
+the whole loop on a side stream, replaying one captured hipGraph per spatial position, with the
+sampler on the device (no host sync per step).  Weights are bf16, accumulation / residual stream /
+LayerNorm / softmax / logits fp32 (the reference's ``amp`` flag selects fp16 autocast; it is accepted
+and ignored here, BASELINE.json asks for bf16)."""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _native
+from .._sync import push_all, signature
+from ..interfaces import Stage2Model
+from .attentions import AttentionStack
+from .configs import resolve
+
+
+class _AttrView(dict):
+    """resolved config with attribute access (the reference keeps an OmegaConf node in self.config)"""
+    __getattr__ = dict.__getitem__
+
+    def copy(self):
+        return _attr(dict(self))
+
+
+def _attr(d):
+    return _AttrView({k: _attr(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+class RQTransformer(Stage2Model):
+
+    def __init__(self, config):
+        super().__init__()
+        cfg = resolve(config)
+        if len(cfg['block_size']) != 3:
+            raise ValueError("incompatible block size")
+        self.block_size = torch.Size(cfg['block_size'])
+        if isinstance(cfg['vocab_size'], int):
+            cfg['vocab_size'] = [cfg['vocab_size']] * cfg['block_size'][2]
+        if cfg['shared_tok_emb'] or cfg['shared_cls_emb']:
+            assert [cfg['vocab_size'][0]] * len(cfg['vocab_size']) == list(cfg['vocab_size'])
+        self.config = _attr(cfg)
+        self.vocab_size = list(cfg['vocab_size'])
+        if not (cfg['input_emb_vqvae'] and cfg['head_emb_vqvae'] and cfg['shared_cls_emb'] and cfg['cumsum_depth_ctx']):
+            # every released config sets these (configs/**/stage2/*.yaml:13-18); TupleEmbedding / BatchLinear
+            # variants (primitives.py) are not part of the accelerated path
+            raise NotImplementedError('RQTransformer without input_emb_vqvae/head_emb_vqvae/shared_cls_emb/cumsum_depth_ctx')
+        E = cfg['embed_dim']
+        self.vocab_size_cond = max(cfg['vocab_size_cond'], 1)
+        self.block_size_cond = max(cfg['block_size_cond'], 1)
+        assert not (self.block_size_cond > 1 and self.vocab_size_cond == 1)
+        self.cond_emb = nn.Embedding(self.vocab_size_cond, E)
+        self.tok_emb = None
+        self.input_mlp = nn.Linear(cfg['input_embed_dim'], E)
+        self.head_mlp = nn.Linear(cfg['input_embed_dim'], E)
+        self.pos_emb_cond = nn.Parameter(torch.zeros(1, self.block_size_cond, E))
+        self.pos_emb_hw = nn.Parameter(torch.zeros(1, self.block_size[0] * self.block_size[1], E))
+        self.pos_emb_d = nn.Parameter(torch.zeros(1, self.block_size[2], E))
+        self.pos_emb_cond.data.normal_(mean=0.0, std=0.02)
+        self.pos_emb_hw.data.normal_(mean=0.0, std=0.02)
+        self.pos_emb_d.data.normal_(mean=0.0, std=0.02)
+        self.embed_drop = nn.Dropout(cfg['embd_pdrop'], inplace=True)
+        self.body_transformer = AttentionStack(cfg['body'])
+        self.head_transformer = AttentionStack(cfg['head'])
+        self.classifier = nn.Sequential(OrderedDict([
+            ('layer_norm', nn.LayerNorm(E)),
+            ('linear', nn.Linear(E, cfg['vocab_size'][0])),
+        ]))
+        if cfg['block_size_cond'] > 1:
+            self.cond_classifier = nn.Sequential(OrderedDict([
+                ('layer_norm', nn.LayerNorm(E)),
+                ('linear', nn.Linear(E, cfg['vocab_size_cond'])),
+            ]))
+        self._cache = None
+        self._engine = None
+        self._engine_sig = None
+        self._side_stream = None
+        self.use_graph = os.environ.get('RQAMD_GRAPH', '1') != '0'
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _eng(self):
+        sig = signature(self)
+        if self._engine is None or sig != self._engine_sig:
+            if self._engine is None:
+                c = self.config
+                if c.body.block.gelu != c.head.block.gelu:
+                    raise NotImplementedError('different GELU variants in body and head')
+                if c.body.block.n_head != c.head.block.n_head:
+                    raise NotImplementedError('different head counts in body and head')
+                self._engine = _native.RqtEngine(
+                    embed_dim=c.embed_dim, n_head=c.body.block.n_head, n_layer_body=c.body.n_layer, n_layer_head=c.head.n_layer,
+                    vocab_size=self.vocab_size[0], input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
+                    block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=c.body.block.gelu == 'v2')
+            push_all(self, self._engine)
+            self._engine_sig = sig
+        return self._engine
+
+    @staticmethod
+    def _codebooks(model_aux):
+        """model_aux.get_code_emb_with_depth is the only thing the reference uses model_aux for
+        (transformers.py:109-111); the engine gathers from the same tables directly."""
+        if model_aux is None or not hasattr(model_aux, 'quantizer'):
+            raise ValueError('model_aux must be the RQVAE whose codebook embeds the codes (input_emb_vqvae=True)')
+        return model_aux.quantizer.codebook_list()
+
+    def _cond(self, cond, B, device):
+        if cond is None:
+            return None                                  # engine zero-fills (transformers.py:208-209)
+        return cond.reshape(B, self.block_size_cond).to(device=device, dtype=torch.long).contiguous()
+
+    def _on_side_stream(self, device, fn):
+        """hipGraph capture is illegal on the legacy default stream, so the engine runs on its own stream,
+        ordered after / before the caller's current stream."""
+        if device.type != 'cuda':
+            return fn()
+        cur = torch.cuda.current_stream(device)
+        if self._side_stream is None or self._side_stream.device != device:
+            self._side_stream = torch.cuda.Stream(device=device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = fn()
+        cur.wait_stream(side)
+        out.record_stream(cur)
+        return out
+
+    # ------------------------------------------------------------------ reference API
+    def init_cache(self):
+        """transformers.py:289-292 -- caches are engine-side and reset by every sample()/forward()."""
+        self._cache = {'spatial_ctx_hw': None}
+
+    def embed_with_model_aux(self, xs, model_aux):
+        xs_emb, _ = model_aux.get_code_emb_with_depth(xs)
+        return xs_emb
+
+    @torch.no_grad()
+    def forward(self, xs, model_aux=None, cond=None, amp=False):
+        """transformers.py:113-188: teacher-forced logits (B,H,W,D,V) fp32, computed by stepping the
+        engine's cached path over the given codes (identical to the uncached pass up to rounding --
+        the reference's own cached==uncached invariant, transformers.py:352-356)."""
+        if self.block_size_cond > 1:
+            raise NotImplementedError('cond_logits of text-conditioned forward() (training-side, transformers.py:150-153)')
+        (B, H, W, D) = xs.shape
+        assert torch.Size([H, W, D]) == self.block_size
+        eng = self._eng()
+        cbs = self._codebooks(model_aux)
+        codes = xs.to(torch.long).contiguous()
+        c = self._cond(cond, B, xs.device)
+        return self._on_side_stream(xs.device, lambda: eng.logits(codes, c, cbs))
+
+    @torch.no_grad()
+    def sample(self, partial_sample, model_aux=None, cond=None, start_loc=(0, 0), temperature=1.0, top_k=None, top_p=None,
+               amp=False, cached=True, is_tqdm=False, desc="Sampling", fast=True):
+        """transformers.py:294-369"""
+        assert self.block_size == partial_sample.shape[1:]
+        (H, W, D) = self.block_size
+        if top_k is None:
+            top_k_list = [self.vocab_size[i] for i in range(D)]
+        elif isinstance(top_k, int):
+            top_k_list = [min(top_k, self.vocab_size[i]) for i in range(D)]
+        elif len(top_k) == 1:
+            top_k_list = [min(top_k[0], self.vocab_size[i]) for i in range(D)]
+        else:
+            top_k_list = [min(top_k[i], self.vocab_size[i]) for i in range(D)]
+        if top_p is None:
+            top_p_list = [1.0 for _ in range(D)]
+        elif isinstance(top_p, float):
+            top_p_list = [min(top_p, 1.0) for _ in range(D)]
+        elif len(top_p) == 1:
+            top_p_list = [min(top_p[0], 1.0) for _ in range(D)]
+        else:
+            top_p_list = [min(top_p[i], 1.0) for i in range(D)]
+        B = partial_sample.shape[0]
+        device = partial_sample.device
+        eng = self._eng()
+        cbs = self._codebooks(model_aux)
+        xs = partial_sample.to(torch.long).contiguous()
+        c = self._cond(cond, B, device)
+        seed, offset = self._draw_rng(device, H * W * D)
+        out = self._on_side_stream(device, lambda: eng.sample(xs, c, cbs, start_loc, temperature, top_k_list, top_p_list,
+                                                              seed, offset, self.use_graph))
+        return out
+
+    @staticmethod
+    def _draw_rng(device, n_steps):
+        """(seed, offset) of the device's default generator, advanced past this call: set_seed(seed + rank)
+        in the drivers (main_sampling_fid.py:166-169) therefore makes sampling reproducible per rank."""
+        if device.type == 'cuda':
+            gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        else:
+            gen = torch.default_generator
+        seed = gen.initial_seed()
+        try:
+            offset = gen.get_offset()
+            gen.set_offset(offset + 4 * ((n_steps + 3) // 4))
+        except (RuntimeError, AttributeError):
+            offset = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) * 4     # CPU generator (emulator tests)
+        return seed, offset
+
+    def compute_loss(self, logits, targets, use_soft_target=False):
+        """transformers.py:371-382 (hard targets; soft targets are training-side)."""
+        if use_soft_target:
+            raise NotImplementedError('soft-target cross entropy (RQ-Transformer training) is out of scope')
+        return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), targets.reshape(-1))

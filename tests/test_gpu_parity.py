@@ -1,0 +1,329 @@
+"""Parity tests proper: the HIP path (librqamd.so through the C ABI) on a real MI355X against
+(a) golden fixtures produced by the reference itself (tests/golden/), (b) the numpy oracle on the same
+seeded inputs, (c) size-independent properties at full BASELINE sizes.  Run with `-m gpu`.
+
+Tolerances.  Integer work (code indices, gathers, fp32 residual arithmetic of the quantiser) is
+bit-exact.  The transformer and the conv stack compute in bf16 with fp32 accumulation against an fp32
+reference; the bounds below are ~4x the error measured for the same kernels on the fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import configs as C
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def nat():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from rqvae import _native
+    _native.lib()                      # raises if librqamd.so is missing: no fallback
+    return _native
+
+
+def G(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ quantiser
+def test_rq_quantize_golden_small(nat, golden):
+    g = golden('rq_small.npz')
+    x, cb = G(g['x'].reshape(-1, 64)), G(g['codebook'])
+    codes, quants = nat.rq_quantize(x, [cb] * 4)
+    assert np.array_equal(N(codes).reshape(g['codes'].shape), g['codes'])
+    np.testing.assert_array_equal(N(quants).reshape(g['quant_list'].shape), g['quant_list'])
+    np.testing.assert_array_equal(N(nat.rq_embed(codes, [cb] * 4, 0)).reshape(g['quant_list'][-1].shape), g['quant_list'][-1])
+    np.testing.assert_array_equal(N(nat.rq_embed(codes, [cb] * 4, 1)).reshape(g['embed_with_depth'].shape), g['embed_with_depth'])
+
+
+def test_rq_quantize_golden_full_size(nat, golden):
+    """K=16384, D=256 (ImageNet RQ-VAE codebook shape), 16 images: every top-2 gap in the fixture is
+    > 5e-3, far above the 3e-4 fp32 distance noise, so all 4096 codes must match the reference."""
+    g = golden('rq_full.npz')
+    rng = np.random.default_rng(int(g['seed']))
+    cb = rng.standard_normal((int(g['K']), int(g['D'])), dtype=np.float32)
+    x = rng.standard_normal((int(g['N']), int(g['D'])), dtype=np.float32)
+    codes, quants = nat.rq_quantize(G(x), [G(cb)] * 4)
+    codes = N(codes).reshape(g['codes'].shape)
+    unamb = np.minimum.accumulate(g['gaps'] > 1e-3, axis=-1)
+    assert unamb.all()
+    assert np.array_equal(codes, g['codes'])
+    np.testing.assert_allclose(N(quants[-1]).astype(np.float64).sum(-1).reshape(g['quant_last_sum'].shape), g['quant_last_sum'],
+                               rtol=0, atol=1e-3)
+
+
+def test_rq_quantize_ragged_unshared(nat):
+    rng = np.random.default_rng(5)
+    cbs = [rng.standard_normal((k, 128), dtype=np.float32) for k in (130, 70, 257)]
+    x = rng.standard_normal((1, 5, 15, 128), dtype=np.float32)
+    codes, quants = nat.rq_quantize(G(x.reshape(-1, 128)), [G(c) for c in cbs])
+    oq, oc = oracle.rq_quantize(x, cbs)
+    assert np.array_equal(N(codes).reshape(oc.shape), oc)
+    np.testing.assert_allclose(N(quants).reshape(3, 1, 5, 15, 128), np.stack(oq), rtol=0, atol=1e-6)
+    assert nat.rq_quantize(torch.zeros((0, 128), device=DEV), [G(c) for c in cbs])[0].shape == (0, 3)
+
+
+def test_rq_quantize_properties_large(nat):
+    """256 images x 64 vectors, K=16384: size-independent properties (the oracle would take minutes)."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    cb = torch.randn((16384, 256), device=DEV, generator=gen)
+    x = torch.randn((256 * 64, 256), device=DEV, generator=gen)
+    codes, quants = nat.rq_quantize(x, [cb] * 4)
+    assert int(codes.min()) >= 0 and int(codes.max()) < 16384
+    # embed_code(codes) == quant_list[-1] bit-exactly (reference invariant)
+    assert torch.equal(nat.rq_embed(codes, [cb] * 4, 0), quants[-1])
+    # cumulative quants are the depth-cumsum of the per-depth embeddings
+    assert torch.equal(nat.rq_embed(codes, [cb] * 4, 2).permute(1, 0, 2).contiguous(), quants)
+    # permutation equivariance: tile placement must not matter
+    perm = torch.randperm(x.shape[0], device=DEV, generator=gen)
+    codes_p, _ = nat.rq_quantize(x[perm].contiguous(), [cb] * 4, want_quants=False)
+    assert torch.equal(codes_p, codes[perm])
+    # depth 0 is plain VQ: brute-force torch check on a slice (expanded form, fp32)
+    sl = x[:512]
+    d = (sl * sl).sum(1, keepdim=True) + (cb * cb).sum(1)[None] - 2.0 * sl @ cb.T
+    top2 = torch.topk(d, 2, dim=1, largest=False)
+    clear = (top2.values[:, 1] - top2.values[:, 0]) > 1e-3
+    assert torch.equal(codes[:512, 0][clear], top2.indices[:, 0][clear])
+    # a codeword quantises to itself with zero residual at depth 0
+    c2, q2 = nat.rq_quantize(cb[:640].contiguous(), [cb] * 4)
+    assert torch.equal(c2[:, 0], torch.arange(640, device=DEV))
+    assert torch.equal(q2[0], cb[:640])
+
+
+# ------------------------------------------------------------------------------------------------ sampler
+def test_sampler_filters_golden(nat, golden):
+    g = golden('sampler.npz')
+    tie_free = [0, 2, 4, 5, 6, 7]
+    for i, (t, k, p) in enumerate(g['cases']):
+        _, probs = nat.sample_logits(G(g['logits']), t, None if k < 0 else int(k), None if p < 0 else float(p),
+                                     want_probs=True, want_samples=False)
+        o, ref = N(probs), g[f'probs_{i}']
+        assert 0.5 * np.abs(o - ref).sum(-1)[tie_free].max() < 1e-5, i
+        assert np.abs(np.sort(o, -1) - np.sort(ref, -1)).sum(-1).max() < 1e-4, i
+        if p != 1.0:
+            assert np.array_equal((o > 0).sum(-1), (ref > 0).sum(-1)), i
+
+
+def test_sampler_full_vocab_vs_oracle(nat):
+    rng = np.random.default_rng(8)
+    logits = (2.5 * rng.standard_normal((16, 16384))).astype(np.float32)
+    for t, k, p in ((1.0, None, None), (1.0, 16384, 1.0), (1.0, 1024, 0.95), (0.9, 200, 0.5)):
+        _, probs = nat.sample_logits(G(logits), t, k, p, want_probs=True, want_samples=False)
+        ref = oracle.filtered_probs(logits, t, k, p)
+        tv = 0.5 * np.abs(N(probs) - ref).sum(-1).max()
+        assert tv < 2e-5, (t, k, p, tv)
+
+
+def test_sampler_draws(nat):
+    rng = np.random.default_rng(3)
+    row = (2.0 * rng.standard_normal((1, 64))).astype(np.float32)
+    logits = G(np.tile(row, (4096, 1)))
+    probs = oracle.filtered_probs(row, 1.0, 10, 0.9)[0]
+    s, _ = nat.sample_logits(logits, 1.0, 10, 0.9, seed=7, offset=0)
+    counts = np.bincount(N(s), minlength=64).astype(np.float64)
+    assert counts[probs == 0].sum() == 0
+    chi2 = (((counts - 4096 * probs) ** 2) / (4096 * probs + 1e-12))[probs > 0].sum()
+    assert chi2 < 35.0, chi2                    # ~9 dof
+    s2, _ = nat.sample_logits(logits, 1.0, 10, 0.9, seed=7, offset=0)
+    s3, _ = nat.sample_logits(logits, 1.0, 10, 0.9, seed=7, offset=4)
+    assert torch.equal(s, s2) and not torch.equal(s, s3)
+
+
+# ------------------------------------------------------------------------------------------------ transformer
+def _models(vae_cfg, rqt_cfg, vae_seed, rqt_seed):
+    from rqvae.models.rqvae import RQVAE
+    from rqvae.models.rqtransformer import RQTransformer
+    hps, dd = vae_cfg
+    vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
+    vparams = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), vae_seed)
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in vparams.items()}, strict=True)
+    ar, aparams = None, None
+    if rqt_cfg is not None:
+        ar = RQTransformer(rqt_cfg)
+        aparams = oracle.make_params(oracle.rqt_param_shapes(rqt_cfg), rqt_seed)
+        ar.load_state_dict({k: torch.from_numpy(v) for k, v in aparams.items()}, strict=True)
+        ar = ar.to(DEV).eval()
+    return vae.to(DEV).eval(), vparams, ar, aparams
+
+
+def test_rqt_tiny_logits_golden(nat, golden):
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    logits = N(ar(G(g['codes'], torch.long), vae, cond=G(g['cond'], torch.long)))
+    err = np.abs(logits - g['logits'])
+    print('rqt tiny logits: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01
+
+
+def test_rqt_real_width_logits_vs_oracle(nat):
+    """E=1536 / 24 heads / V=16384 (the 1.4B layer shapes), 2 body + 1 head layers, B=3."""
+    cfg = C.RQT_WIDE
+    vae, vparams, ar, aparams = _models(C.VAE_TINY, None, 31, 0)
+    from rqvae.models.rqtransformer import RQTransformer
+    rng = np.random.default_rng(9)
+    cb = rng.standard_normal((16384, 256), dtype=np.float32)
+    ar = RQTransformer(cfg)
+    aparams = oracle.make_params(oracle.rqt_param_shapes(cfg), 51)
+    ar.load_state_dict({k: torch.from_numpy(v) for k, v in aparams.items()})
+    ar = ar.to(DEV).eval()
+
+    class Aux:                                       # minimal model_aux: only its codebook is used
+        class quantizer:
+            @staticmethod
+            def codebook_list():
+                return [G(cb)] * 4
+    codes = rng.integers(0, 16384, (3, 8, 8, 4))
+    cond = rng.integers(0, 1000, (3, 1))
+    logits = N(ar(G(codes, torch.long), Aux, cond=G(cond, torch.long)))
+    ref = oracle.RQTransformerOracle(cfg, aparams).forward(codes, [cb] * 4, cond)
+    err = np.abs(logits - ref)
+    scale = np.abs(ref).max()
+    print('rqt wide logits: max err %.4f mean %.5f |ref|max %.3f' % (err.max(), err.mean(), scale))
+    assert err.max() < 0.03 * max(scale, 1.0) + 0.02 and err.mean() < 0.004 * max(scale, 1.0) + 0.003
+
+
+def test_rqt_sample_semantics(nat, golden):
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    cond = G(g['cond'], torch.long)
+    partial = torch.zeros((3, 4, 4, 4), dtype=torch.long, device=DEV)
+    outs = {}
+    for graph in (False, True):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(123)
+        a = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+        torch.cuda.manual_seed_all(123)
+        b = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+        assert torch.equal(a, b)                      # seed-reproducible
+        c = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+        assert not torch.equal(a, c)                  # generator advanced
+        outs[graph] = a
+    assert torch.equal(outs[False], outs[True])       # hipGraph replay == eager launches
+    out = outs[True]
+    assert out.dtype == torch.long and out.shape == partial.shape and int(partial.abs().sum()) == 0
+    assert int(out.min()) >= 0 and int(out.max()) < 500
+    logits = N(ar(out, vae, cond=cond))               # teacher-force the sample back
+    for h in range(4):
+        for w in range(4):
+            for d in range(4):
+                pr = oracle.filtered_probs(logits[:, h, w, d], 1.0, 5, 0.9)
+                assert (pr[np.arange(3), N(out[:, h, w, d])] > 0).all()
+    part2 = out.clone()
+    part2[:, 2:] = 0
+    torch.cuda.manual_seed_all(5)
+    out3 = ar.sample(part2, vae, cond=cond, start_loc=(2, 0), top_k=[5, 5, 5, 5], top_p=[0.9])
+    assert torch.equal(out3[:, :2], out[:, :2])
+    with pytest.raises(AssertionError):
+        ar.sample(torch.zeros((3, 8, 8, 4), dtype=torch.long, device=DEV), vae)
+    # cond=None -> zeros (transformers.py:208-209)
+    torch.cuda.manual_seed_all(5)
+    o1 = ar.sample(partial, vae)
+    torch.cuda.manual_seed_all(5)
+    o2 = ar.sample(partial, vae, cond=torch.zeros((3, 1), dtype=torch.long, device=DEV))
+    assert torch.equal(o1, o2)
+
+
+def test_rqt_batch_invariance(nat, golden):
+    """rows are independent: logits of a row do not depend on which batch it sits in (tile placement)."""
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    rng = np.random.default_rng(1)
+    codes = G(rng.integers(0, 500, (70, 4, 4, 4)), torch.long)
+    cond = G(rng.integers(0, 10, (70, 1)), torch.long)
+    full = ar(codes, vae, cond=cond)
+    part = ar(codes[64:].contiguous(), vae, cond=cond[64:].contiguous())
+    assert torch.equal(full[64:], part)
+
+
+# ------------------------------------------------------------------------------------------------ RQ-VAE
+def test_vae_tiny_golden(nat, golden):
+    g = golden('vae_tiny.npz')
+    vae, _, _, _ = _models(C.VAE_TINY, None, int(g['seed']), 0)
+    dec = N(vae.decode_code(G(g['codes'], torch.long)))
+    err = np.abs(dec - g['decode_code'])
+    print('vae tiny decode_code: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01
+    z_e = N(vae.encode(G(g['x'])))
+    err = np.abs(z_e - g['z_e'])
+    print('vae tiny encode: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.05 and err.mean() < 0.008
+    out, loss, codes = vae(G(g['x']))
+    assert out.shape == (2, 3, 16, 16) and codes.shape == (2, 8, 8, 4) and codes.dtype == torch.long
+    assert abs(float(loss) - float(g['loss'])) < 0.05 * float(g['loss']) + 1e-3
+    agree = (N(codes) == g['codes']).mean()
+    print('vae tiny get_codes agreement with the fp32 reference: %.3f' % agree)
+    assert agree > 0.8
+    with pytest.raises(AssertionError):
+        vae.decode_code(torch.zeros((1, 4, 4, 4), dtype=torch.long, device=DEV))
+
+
+@pytest.mark.parametrize('tag,cfg', [('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)])
+def test_vae_full_size_golden(nat, golden, tag, cfg):
+    """Released RQ-VAE shapes (104.4 M params, 256x256): decode_code and encode vs the reference fp32
+    outputs on seeded weights.  Pixel tolerance: |err| <= 0.08 max, <= 0.012 mean on outputs of range
+    about [-4, 4] (std 0.3) -- bf16 activations through ~70 layers."""
+    g = golden(f'vae_{tag}.npz')
+    vae, vparams, _, _ = _models(cfg, None, int(g['seed']), 0)
+    dec = N(vae.decode_code(G(g['codes'], torch.long)))
+    ref = g['decode_code'].astype(np.float32)
+    err = np.abs(dec - ref)
+    print(f'vae {tag} decode_code: max err %.4f mean %.5f (|ref| max %.2f, std %.3f)' % (err.max(), err.mean(), np.abs(ref).max(), ref.std()))
+    assert err.max() < 0.08 and err.mean() < 0.012
+    rng = np.random.default_rng(int(g['data_seed']))
+    rng.integers(0, cfg[0]['n_embed'], (1, 8, 8, 4))
+    x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
+    z_e = N(vae.encode(G(x)))
+    err = np.abs(z_e - g['z_e'])
+    print(f'vae {tag} encode: max err %.4f mean %.5f (|ref| max %.2f)' % (err.max(), err.mean(), np.abs(g['z_e']).max()))
+    assert err.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and err.mean() < 0.01
+    codes = N(vae.get_codes(G(x)))
+    cb = vparams['quantizer.codebooks.0.weight'][:-1]
+    gaps, _ = oracle.rq_quantize_margins(g['z_e'], [cb] * 4)
+    clear = np.minimum.accumulate(gaps > 0.5, axis=-1)       # margin well above the bf16 encoder error
+    agree = (codes == g['enc_codes'])[clear].mean() if clear.any() else 1.0
+    print(f'vae {tag} get_codes: agreement on clear-margin codes %.3f (%d of %d clear)' % (agree, clear.sum(), clear.size))
+    assert agree > 0.9
+
+
+def test_vae_batch_invariance_and_chunking(nat, golden):
+    g = golden('vae_tiny.npz')
+    vae, _, _, _ = _models(C.VAE_TINY, None, int(g['seed']), 0)
+    rng = np.random.default_rng(2)
+    codes = G(rng.integers(0, 500, (37, 8, 8, 4)), torch.long)      # 37 > chunk of 32: two chunks
+    full = vae.decode_code(codes)
+    one = torch.cat([vae.decode_code(codes[i:i + 1]) for i in (0, 31, 32, 36)])
+    assert torch.equal(full[[0, 31, 32, 36]], one)
+    x = G(np.clip(rng.standard_normal((5, 3, 16, 16), dtype=np.float32), -1, 1))
+    assert torch.equal(vae.encode(x)[3:4], vae.encode(x[3:4].contiguous()))
+
+
+def test_create_model_and_state_dict_roundtrip(nat):
+    from rqvae.models import create_model
+    from rqvae.utils.config import Config, augment_arch_defaults
+    hps, dd = C.VAE_TINY
+    m, ema = create_model(augment_arch_defaults(Config({'type': 'rq-vae', 'hparams': hps, 'ddconfig': dd, 'checkpointing': False})))
+    assert ema is None and list(m.code_shape) == [8, 8, 4]
+    ar, _ = create_model(augment_arch_defaults(Config(C.RQT_TINY)))
+    assert ar.get_block_size() == torch.Size([4, 4, 4]) and ar.block_size_cond == 1
+    with pytest.raises(ValueError):
+        create_model(Config({'type': 'nope'}))
+    m = m.to(DEV).eval()
+    codes = torch.randint(0, 500, (2, 8, 8, 4), device=DEV)
+    a = m.decode_code(codes)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        m.decoder.conv_out.bias.add_(1.0)             # in-place edit must reach the engine
+    b = m.decode_code(codes)
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+    m.load_state_dict(sd)
+    assert torch.equal(m.decode_code(codes), a)
