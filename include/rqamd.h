@@ -134,6 +134,14 @@ int rqamd_rqt_set_profile(rqamd_rqt* h, int profile);
 int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_launches,
                           double* gemm_bytes_total, double* gemm_flops_total);
 
+/* ---- diagnostics ------------------------------------------------------------------------------
+ * One raw launch of the engines' bf16 MFMA GEMM: out[M,N] = A[M,K] . W[N,K]^T (+bias), both operands bf16
+ * K-contiguous (W = nn.Linear.weight layout).  epi: 0 bf16 out, 1 bf16 + GELU, 3 fp32 out, 4 fp32 split-K
+ * partial slabs out[splitk][M][N] (no bias).  bm/bn <= 0: the engine's own tile choice.  Used by the
+ * kernel-level parity test and scripts/gemm_bench.py; not part of the reference-facing surface. */
+int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
+                        void* out, int bm, int bn, int splitk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@
 //
 // Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 64, wave tile (BM/2) x (BN/2) built from
 // v_mfma_f32_32x32x16_bf16; LDS double-buffered, register-staged (global_load_dwordx4 -> ds_write_b128)
-// with the next tile's loads issued before the current tile's MFMAs; 16-byte-chunk XOR swizzle
+// with the loads of the next TWO K-tiles in flight behind the current tile's MFMAs; XCD-aware tile order; 16-byte-chunk XOR swizzle
 // (chunk ^ ((row>>1)&7)) makes both the b128 writes and the fragment reads bank-conflict free.
 #pragma once
 #include "rq_hip.h"
@@ -58,7 +58,7 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int BK = 64;
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -70,7 +70,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // tile id -> (m-tile, n-tile).  Blocks are dispatched round-robin over the 8 XCDs (private L2s), so
+    // the m-tiles that share one weight tile are given ids 8 apart: same XCD, back to back.
+    const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
+    int mt, nt;
+    {
+        const int id = blockIdx.x;
+        if ((NT & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            nt = (slot / MT) * 8 + xcd;
+            mt = slot - (slot / MT) * MT;
+        } else {
+            mt = id / NT;
+            nt = id - mt * NT;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
     const int kt_total = p.K / BK;
     const int per = (kt_total + p.splitk - 1) / p.splitk;
     const int kt0 = blockIdx.z * per;
@@ -78,65 +93,71 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int chunk = tid & 7, lrow = tid >> 3;
 
-    // per-row gather bases (A)
-    long a_base[A_IT];     // element offset of (row, k=0) for dense; pixel decomposition for conv
+    // Per-row gather bases.  Loads are UNCONDITIONAL (addresses clamped into the tensor): a predicated
+    // load becomes an exec-masked branch and hipcc then drains vmcnt(0) at every join, which serialises
+    // the whole pipeline on memory latency.  Rows >= M / >= N only feed outputs that are never stored;
+    // conv padding taps must contribute zeros, so their validity mask is applied when the registers are
+    // written to LDS, after the (counted) wait.
+    long a_base[A_IT];     // element offset of (row, k=0) for dense; image base for conv
     int a_oy[A_IT], a_ox[A_IT];
-    bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < p.M;
-        if (p.conv) {
+        if (m > p.M - 1) m = p.M - 1;
+        if (CONV) {
             int hw = p.Hout * p.Wout;
             int img = m / hw, rem = m - img * hw;
             a_oy[i] = rem / p.Wout;
             a_ox[i] = rem - a_oy[i] * p.Wout;
-            a_base[i] = (long)img * (p.Hin >> p.ups) * (p.Win >> p.ups) * p.Cin;
+            a_base[i] = (long)img * (p.Hin >> p.ups) * (p.Win >> p.ups) * p.Cin + chunk * 8;
         } else {
             a_oy[i] = a_ox[i] = 0;
-            a_base[i] = (long)m * p.lda;
+            a_base[i] = (long)m * p.lda + chunk * 8;
         }
     }
     const bf16_t* w_ptr[B_IT];
-    bool w_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         int n = n0 + lrow + 32 * i;
-        w_ok[i] = n < p.N;
-        w_ptr[i] = p.W + (long)(w_ok[i] ? n : 0) * p.K + chunk * 8;
+        if (n > p.N - 1) n = p.N - 1;
+        w_ptr[i] = p.W + (long)n * p.K + chunk * 8;
     }
 
-    rq_u128 ra[A_IT], rb[B_IT];
-    auto load_tile = [&](int kt) {
+    // returns the validity mask of the A rows (bit i = tap inside the image); dense GEMM: all ones
+    auto load_tile = [&](int kt, rq_u128* ra, rq_u128* rb) -> unsigned {
         const int k0 = kt * BK;
-        int dy = 0, dx = 0, ci0 = k0;
-        if (p.conv) {
-            int tap = k0 / p.Cin;
-            ci0 = k0 - tap * p.Cin;
-            dy = tap / p.ksize - p.pad;
-            dx = tap % p.ksize - p.pad;
-        }
+        unsigned mask = 0xffffffffu;
+        if (CONV) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin;
+            const int dy = tap / p.ksize - p.pad, dx = tap % p.ksize - p.pad;
+            mask = 0;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            bool ok = a_ok[i];
-            long off;
-            if (p.conv) {
+            for (int i = 0; i < A_IT; ++i) {
                 int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
-                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                off = a_base[i] + ((long)(iy >> p.ups) * (p.Win >> p.ups) + (ix >> p.ups)) * p.Cin + ci0 + chunk * 8;
-            } else {
-                off = a_base[i] + k0 + chunk * 8;
+                const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                mask |= (ok ? 1u : 0u) << i;
+                iy = iy < 0 ? 0 : (iy >= p.Hin ? p.Hin - 1 : iy);
+                ix = ix < 0 ? 0 : (ix >= p.Win ? p.Win - 1 : ix);
+                ra[i] = ld128(p.A + a_base[i] + ((long)(iy >> p.ups) * (p.Win >> p.ups) + (ix >> p.ups)) * p.Cin + ci0);
             }
-            ra[i] = ok ? ld128(p.A + off) : zero128();
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) ra[i] = ld128(p.A + a_base[i] + k0);
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = w_ok[i] ? ld128(w_ptr[i] + k0) : zero128();
+        for (int i = 0; i < B_IT; ++i) rb[i] = ld128(w_ptr[i] + k0);
+        return mask;
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const rq_u128* ra, const rq_u128* rb, unsigned mask) {
         bf16_t* a = sA + buf * BM * BK;
         bf16_t* b = sB + buf * BN * BK;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) st128(a + swz_off(lrow + 32 * i, chunk), ra[i]);
+        for (int i = 0; i < A_IT; ++i) {
+            rq_u128 v = ra[i];
+            if (CONV && !((mask >> i) & 1u)) v = zero128();
+            st128(a + swz_off(lrow + 32 * i, chunk), v);
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) st128(b + swz_off(lrow + 32 * i, chunk), rb[i]);
     };
@@ -149,16 +170,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-    }
-    rq_syncthreads();
     const int frow = lane & 31, fk = lane >> 5;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        if (more) load_tile(kt + 1);
+    auto compute = [&](int buf) {
         const bf16_t* a = sA + buf * BM * BK;
         const bf16_t* b = sB + buf * BN * BK;
 #pragma unroll
@@ -173,8 +186,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+
+    // Two register sets keep two K-tiles of global loads in flight (tile t+1 landing, tile t+2 issued)
+    // while tile t is multiplied out of LDS.  The loop body is branch-free apart from the trip count: loads
+    // past the last tile re-read the last tile (harmless), so the compiler can use counted vmcnt waits.
+    rq_u128 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
+    unsigned mk0 = 0, mk1 = 0;
+    const int nk = kt1 - kt0, last = kt1 - 1;
+    if (nk > 0) {
+        mk0 = load_tile(kt0, ra0, rb0);
+        mk1 = load_tile(kt0 + 1 < kt1 ? kt0 + 1 : last, ra1, rb1);
+        store_tile(0, ra0, rb0, mk0);
         rq_syncthreads();
+        // whole pairs, no exit from the middle of the body: a mid-loop break adds a CFG edge into the loop
+        // header along which hipcc's waitcnt pass sees the first half's loads pending, and it then drains
+        // them at the top of every iteration (vmcnt(1) in the ISA) -- that serialised the pipeline.
+        const int npair = nk >> 1;
+        for (int pi = 0; pi < npair; ++pi) {
+            const int i = 2 * pi;
+            // even tile in LDS buffer 0; set 0 is free, set 1 holds tile i+1
+            mk0 = load_tile(kt0 + i + 2 < kt1 ? kt0 + i + 2 : last, ra0, rb0);
+            rq_sched_barrier();      // keep the loads above the MFMAs: hipcc sinks them below the LDS writes otherwise
+            compute(0);
+            store_tile(1, ra1, rb1, mk1);
+            rq_syncthreads();
+            // odd tile in LDS buffer 1; set 1 is free, set 0 holds tile i+2
+            mk1 = load_tile(kt0 + i + 3 < kt1 ? kt0 + i + 3 : last, ra1, rb1);
+            rq_sched_barrier();
+            compute(1);
+            store_tile(0, ra0, rb0, mk0);
+            rq_syncthreads();
+        }
+        if (nk & 1) compute(0);      // odd tile count: the last tile already sits in buffer 0
     }
 
     // ------------------------------------------------------------------ epilogue

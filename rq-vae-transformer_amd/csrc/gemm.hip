@@ -2,17 +2,21 @@
 #include "gemm.h"
 #include "rq_common.h"
 
-template <int BM, int BN>
-static int launch_t(const GemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, bool CONV>
+static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN>), grid, dim3(256), smem, stream, a);
+    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), 1, a.splitk);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, CONV>), grid, dim3(256), smem, stream, a);
     return rq_check_launch("gemm_bf16_kernel");
+}
+template <int BM, int BN>
+static int launch_t(const GemmArgs& a, hipStream_t stream) {
+    return a.conv ? launch_c<BM, BN, true>(a, stream) : launch_c<BM, BN, false>(a, stream);
 }
 
 int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
@@ -32,21 +36,45 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
 }
 
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk) {
+    // Measured on MI355X (scripts/gemm_bench.py, profiles/r01_gemm_bench.md): for the decode-step shapes
+    // (M = batch rows 64..1024, N,K in 1536..16384) the smallest tile that keeps the grid at <= 768
+    // workgroups (3 per CU) wins; residual-producing GEMMs (N = E) are split along K up to 8 ways to reach
+    // that many workgroups, keeping >= 6 K-tiles per split.
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-    *bm = M <= 64 ? 64 : 128;
-    *bn = 128;
-    int tiles = cdiv(M, *bm) * cdiv(N, 128);
-    if (tiles < 160 || N % 128 != 0) {
-        *bn = 64;
-        tiles = cdiv(M, *bm) * cdiv(N, 64);
+    static const int cand[3][2] = {{64, 64}, {128, 64}, {128, 128}};
+    int pick = 2;
+    for (int c = 0; c < 3; ++c) {
+        if (M <= 64 && cand[c][0] > 64) continue;
+        if (cdiv(M, cand[c][0]) * cdiv(N, cand[c][1]) <= 768) { pick = c; break; }
     }
+    if (M <= 64) pick = 0;
+    *bm = cand[pick][0];
+    *bn = cand[pick][1];
+    const int tiles = cdiv(M, *bm) * cdiv(N, *bn);
     *splitk = 1;
-    if (allow_splitk && tiles < 192) {
-        int s = 256 / tiles;
-        int max_by_k = (K / 64) / 4;
+    if (allow_splitk) {
+        int s = 768 / tiles;
+        const int max_by_k = (K / 64) / 6;
         if (s > max_by_k) s = max_by_k;
         if (s > 8) s = 8;
         if (s < 1) s = 1;
         *splitk = s;
     }
+}
+
+// diagnostics entry (include/rqamd.h): one raw launch of the decode-step GEMM, for microbenchmarks
+// and kernel-level parity tests.  epi: 0 bf16, 1 bf16+GELU, 3 fp32, 4 fp32 split-K slabs.
+extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
+                                   void* out, int bm, int bn, int splitk, void* stream) {
+    if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
+    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk;
+    if (bm <= 0 || bn <= 0) {
+        int sk;
+        rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk);
+        if (splitk <= 0) a.splitk = sk;
+    }
+    if (a.splitk <= 0) a.splitk = 1;
+    return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
 }

@@ -4,26 +4,43 @@
 
 // =================================================================================================
 // residual add (+ split-K slab reduce + bias) fused with LayerNorm
+// NS = number of split-K slabs (compile time: all slab loads are issued back to back, the kernel is
+// latency-bound otherwise); each thread owns float4 columns tid, tid+256, ... of its row.
+template <int NS>
 __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
     __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int E = p.E;
+    const int E = p.E, E4 = E >> 2;
     const long base = (long)row * E;
-    float v[16];
+    const long slab_stride = (long)p.rows * E;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < E4) v[i] = *(const f32x4*)(p.x_in + base + q * 4);
+    }
+    f32x4 t[NS > 0 ? NS : 1][4];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            t[sl][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (q < E4) t[sl][i] = *(const f32x4*)(p.slabs + sl * slab_stride + base + q * 4);
+        }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = tid + 256 * i;
-        float val = 0.f;
-        if (idx < E) {
-            val = p.x_in[base + idx];
-            for (int sl = 0; sl < p.n_slabs; ++sl) val += p.slabs[((long)sl * p.rows + row) * E + idx];
-            if (p.bias) val += p.bias[idx];
-            if (p.addvec) val += p.addvec[idx];
-            if (p.x_out) p.x_out[base + idx] = val;
-            s += val;
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) v[i] += t[sl][i];
+        if (q < E4) {
+            if (p.bias) v[i] += *(const f32x4*)(p.bias + q * 4);
+            if (p.addvec) v[i] += *(const f32x4*)(p.addvec + q * 4);
+            if (p.x_out) *(f32x4*)(p.x_out + base + q * 4) = v[i];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
-        v[i] = val;
     }
     if (!p.gamma) return;   // uniform
     s = wave_sum(s);
@@ -32,9 +49,12 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
     const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)E;
     float s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < E) { float d = v[i] - mean; s2 = fmaf(d, d, s2); }
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        if (q < E4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; s2 = fmaf(d, d, s2); }
+        }
     }
     s2 = wave_sum(s2);
     if (lane == 0) red[4 + wave] = s2;
@@ -42,15 +62,33 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
     const float var = ((red[4] + red[5]) + (red[6] + red[7])) / (float)E;
     const float rstd = 1.0f / sqrtf(var + p.eps);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int idx = tid + 256 * i;
-        if (idx < E) p.y[base + idx] = f32_to_bf16((v[i] - mean) * rstd * p.gamma[idx] + p.beta[idx]);
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i;
+        if (q < E4) {
+            const f32x4 g = *(const f32x4*)(p.gamma + q * 4), b = *(const f32x4*)(p.beta + q * 4);
+            const uint32_t lo = pack_bf16x2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
+            const uint32_t hi = pack_bf16x2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
+            *(uint32_t*)(p.y + base + q * 4) = lo;
+            *(uint32_t*)(p.y + base + q * 4 + 2) = hi;
+        }
     }
 }
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s) {
-    if (a.E > 4096) return rq_fail(RQAMD_ERR_UNSUPPORTED, "resid_ln: embed_dim %d > 4096", a.E);
-    RQ_LAUNCH(resid_ln_kernel, dim3(a.rows), dim3(256), 0, s, a);
+    if (a.E > 4096 || a.E % 4) return rq_fail(RQAMD_ERR_UNSUPPORTED, "resid_ln: embed_dim %d > 4096 or not a multiple of 4", a.E);
+    const dim3 g(a.rows), b(256);
+    switch (a.slabs ? a.n_slabs : 0) {
+        case 0: RQ_LAUNCH(resid_ln_kernel<0>, g, b, 0, s, a); break;
+        case 1: RQ_LAUNCH(resid_ln_kernel<1>, g, b, 0, s, a); break;
+        case 2: RQ_LAUNCH(resid_ln_kernel<2>, g, b, 0, s, a); break;
+        case 3: RQ_LAUNCH(resid_ln_kernel<3>, g, b, 0, s, a); break;
+        case 4: RQ_LAUNCH(resid_ln_kernel<4>, g, b, 0, s, a); break;
+        case 5: RQ_LAUNCH(resid_ln_kernel<5>, g, b, 0, s, a); break;
+        case 6: RQ_LAUNCH(resid_ln_kernel<6>, g, b, 0, s, a); break;
+        case 7: RQ_LAUNCH(resid_ln_kernel<7>, g, b, 0, s, a); break;
+        case 8: RQ_LAUNCH(resid_ln_kernel<8>, g, b, 0, s, a); break;
+        default: return rq_fail(RQAMD_ERR_INVALID, "resid_ln: %d slabs > 8", a.n_slabs);
+    }
     return rq_check_launch("resid_ln_kernel");
 }
 
@@ -352,8 +390,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
             remaining = (int)bcast[1];
             rq_syncthreads();
         }
-        for (int i = tid; i < V; i += SMP_T)
-            if (order_key(sx[i]) < prefix) sx[i] = NEG_INF;
+        // k-th largest is NaN (torch.topk ranks NaN first): `out < NaN` is false everywhere -> nothing dropped
+        if (prefix != 0xffffffffu)
+            for (int i = tid; i < V; i += SMP_T)
+                if (order_key(sx[i]) < prefix) sx[i] = NEG_INF;
         rq_syncthreads();
     }
 

@@ -90,15 +90,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, const fl
     rq_syncthreads();
     const int CC = C / 8, gs = C / 32;
     const long nvec = (long)HW * CC;
+    // the grid stride (gridDim.x*256) is a multiple of CC, so a thread always sees the same 8 channels:
+    // fold mean / rstd / gamma / beta into one scale and shift per channel, once
+    const int cc = tid % CC;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ch = cc * 8 + e, g = ch / gs;
+        sc[e] = srstd[g] * gamma[ch];
+        sh[e] = beta[ch] - smean[g] * sc[e];
+    }
     for (long i = (long)blockIdx.x * 256 + tid; i < nvec; i += (long)gridDim.x * 256) {
-        const int cc = (int)(i % CC);
         const long off = ((long)b * HW) * C + i * 8;
         float f[8];
         unpack8v(ld128(x + off), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int ch = cc * 8 + e, g = ch / gs;
-            float v = (f[e] - smean[g]) * srstd[g] * gamma[ch] + beta[ch];
+            float v = fmaf(f[e], sc[e], sh[e]);
             if (silu) v = v / (1.0f + __expf(-v));
             f[e] = v;
         }

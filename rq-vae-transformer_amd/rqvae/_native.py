@@ -55,6 +55,8 @@ _SIGS = {
     'rqamd_rqt_set_profile': (C.c_int, [C.c_void_p, C.c_int]),
     'rqamd_rqt_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double)]),
+    'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -161,6 +163,20 @@ def sample_logits(logits, temperature=1.0, top_k=None, top_p=None, seed=0, offse
                                     int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(samples), ptr(probs),
                                     stream_of(logits)))
     return samples, probs
+
+
+def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
+    """diagnostics: out[M,N] = a[M,K] @ w[N,K]^T (+bias); a, w are torch.bfloat16."""
+    M, K = a_bf16.shape
+    N = w_bf16.shape[0]
+    if out is None:
+        if epi == 4:
+            out = torch.empty((splitk if splitk > 0 else 8, M, N), dtype=torch.float32, device=a_bf16.device)
+        else:
+            out = torch.empty((M, N), dtype=torch.float32 if epi == 3 else torch.bfloat16, device=a_bf16.device)
+    check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
+                                    ptr(out), bm, bn, splitk, stream_of(a_bf16)))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------- engines

@@ -1,0 +1,110 @@
+"""CPU-only: host-side mirror logic that needs no device -- config handling, constructor errors,
+state_dict tables, sampler argument normalisation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import configs as C
+
+
+def test_state_dict_tables_match_reference_shapes():
+    from rqvae.models.rqvae import RQVAE
+    from rqvae.models.rqtransformer import RQTransformer
+    for hps, dd in (C.VAE_TINY, C.VAE_FFHQ):
+        m = RQVAE(**hps, ddconfig=dd, checkpointing=False)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
+            {k: tuple(s) for k, s in oracle.rqvae_param_shapes(hps, dd).items()}
+        # shared codebook: one tensor under 4 names (quantizations.py:199-205)
+        assert m.quantizer.codebooks[0] is m.quantizer.codebooks[3]
+        assert not m.quantizer.codebooks[0].weight.requires_grad
+    for cfg in (C.RQT_TINY, C.RQT_CC3M_654M):
+        with torch.device('meta'):
+            t = RQTransformer(cfg)
+        assert {k: tuple(v.shape) for k, v in t.state_dict().items()} == \
+            {k: tuple(s) for k, s in oracle.rqt_param_shapes(cfg).items()}
+
+
+def test_constructor_errors_follow_the_reference():
+    from rqvae.models.rqvae.quantizations import RQBottleneck
+    from rqvae.models.rqtransformer import RQTransformer
+    with pytest.raises(ValueError):
+        RQBottleneck([8, 8, 256], [8, 8], 16)                       # quantizations.py:175-176
+    with pytest.raises(ValueError):
+        RQBottleneck([8, 8, 256], [3, 8, 4], 16)                    # :177-178
+    with pytest.raises(ValueError):
+        RQBottleneck([8, 8, 256], [8, 8, 4], [16] * 4, shared_codebook=True)   # :189-191
+    bad = dict(C.RQT_TINY, block_size=[4, 4])
+    with pytest.raises(ValueError):
+        RQTransformer(bad)                                          # transformers.py:41-42
+    rq = RQBottleneck([16, 16, 64], [8, 8, 4], 32)
+    x = torch.arange(2 * 16 * 16 * 64, dtype=torch.float32).reshape(2, 16, 16, 64)
+    assert rq.to_code_shape(x).shape == (2, 8, 8, 256)
+    assert torch.equal(rq.to_latent_shape(rq.to_code_shape(x)), x)  # quantizations.py:216-235 round trip
+
+
+def test_config_loading(tmp_path):
+    from rqvae.utils.config import Config, augment_arch_defaults, load_config
+    p = tmp_path / 'cfg.yaml'
+    p.write_text('''
+arch:
+  type: rq-transformer
+  block_size: [8, 8, 4]
+  embed_dim: 1536
+  input_embed_dim: 256
+  shared_tok_emb: true
+  shared_cls_emb: true
+  input_emb_vqvae: true
+  head_emb_vqvae: true
+  cumsum_depth_ctx: true
+  vocab_size_cond: 1000
+  block_size_cond: 1
+  vocab_size: 16384
+  body: {n_layer: 42, block: {n_head: 24}}
+  head: {n_layer: 6, block: {n_head: 24}}
+''')
+    cfg = load_config(str(p))
+    arch = augment_arch_defaults(cfg.arch)
+    assert arch.body.block.embed_dim == 1536 and arch.head.block.resid_pdrop == 0.1 and arch.body.block.gelu == 'v1'
+    assert arch.block_size == [8, 8, 4] and arch.embd_pdrop == 0.0
+    c2 = arch.copy()
+    c2.body.n_layer = 1
+    assert arch.body.n_layer == 42
+    v = augment_arch_defaults(Config({'type': 'rq-vae', 'hparams': {'a': 1}}))
+    assert v.ema is None and dict(**v.hparams) == {'a': 1}
+    with pytest.raises(NotImplementedError):
+        augment_arch_defaults(Config({'type': 'other'}))
+
+
+def test_sample_argument_normalisation(monkeypatch):
+    """transformers.py:314-330: top_k / top_p scalars, singletons and lists -> per-depth lists."""
+    from rqvae.models.rqtransformer import RQTransformer
+    ar = RQTransformer(C.RQT_TINY)
+    seen = {}
+
+    class FakeEngine:
+        def sample(self, xs, c, cbs, start_loc, temperature, top_k, top_p, seed, offset, use_graph):
+            seen.update(top_k=top_k, top_p=top_p, start=start_loc, t=temperature, cond=c)
+            return xs.clone()
+
+    class Aux:
+        class quantizer:
+            @staticmethod
+            def codebook_list():
+                return [None] * 4
+    monkeypatch.setattr(ar, '_eng', lambda: FakeEngine())
+    z = torch.zeros((2, 4, 4, 4), dtype=torch.long)
+    ar.sample(z, Aux)
+    assert seen['top_k'] == [500] * 4 and seen['top_p'] == [1.0] * 4 and seen['cond'] is None
+    ar.sample(z, Aux, top_k=1000, top_p=0.95, temperature=0.7, start_loc=(1, 2))
+    assert seen['top_k'] == [500] * 4 and seen['top_p'] == [0.95] * 4 and seen['t'] == 0.7 and seen['start'] == (1, 2)
+    ar.sample(z, Aux, top_k=[7], top_p=[1.5])
+    assert seen['top_k'] == [7] * 4 and seen['top_p'] == [1.0] * 4
+    ar.sample(z, Aux, top_k=[1, 2, 3, 4], top_p=[0.1, 0.2, 0.3, 0.4], cond=torch.tensor([3, 4]))
+    assert seen['top_k'] == [1, 2, 3, 4] and seen['top_p'] == [0.1, 0.2, 0.3, 0.4] and seen['cond'].shape == (2, 1)
+    with pytest.raises(AssertionError):
+        ar.sample(torch.zeros((2, 8, 8, 4), dtype=torch.long), Aux)   # transformers.py:310
+    with pytest.raises(ValueError):
+        ar.sample(z, None)
