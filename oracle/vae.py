@@ -37,10 +37,11 @@ def conv2d(x, w, b, stride=1, pad=(1, 1, 1, 1)):
     Ho = (H + pad[0] + pad[1] - kh) // stride + 1
     Wo = (W + pad[2] + pad[3] - kw) // stride + 1
     out = np.zeros((B * Ho * Wo, co), np.float32)
+    wt = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))      # (kh,kw,ci,co): contiguous BLAS operands
     for ky in range(kh):
         for kx in range(kw):
             patch = xp[:, ky:ky + stride * (Ho - 1) + 1:stride, kx:kx + stride * (Wo - 1) + 1:stride, :]
-            out += patch.reshape(-1, ci) @ w[:, :, ky, kx].T
+            out += np.ascontiguousarray(patch).reshape(-1, ci) @ wt[ky, kx]
     return (out + b).reshape(B, Ho, Wo, co)
 
 

@@ -66,7 +66,6 @@ def test_vae_tiny(golden):
     np.testing.assert_allclose(loss, g['loss'], rtol=1e-5)
 
 
-@pytest.mark.slow
 def test_vae_imagenet_decode(golden):
     g = golden('vae_imagenet.npz')
     hps, dd = C.VAE_IMAGENET
