@@ -141,6 +141,12 @@ int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_lau
  * kernel-level parity test and scripts/gemm_bench.py; not part of the reference-facing surface. */
 int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                         void* out, int bm, int bn, int splitk, void* stream);
+/* One raw implicit-GEMM convolution launch (the conv form of the same kernel): x NHWC bf16
+ * [B][H>>ups][W>>ups][Cin] (H, W = virtual input size after the folded nearest-2x upsample), w bf16
+ * [Cout][k][k][Cin], out NHWC bf16 (+bias, +resid if not NULL); stride 2 = Downsample (layers.py:50-54). */
+int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const void* resid, int B, int H, int W,
+                        int Cin, int Cout, int ksize, int stride, int ups, void* out, int bm, int bn, int flags,
+                        void* stream);
 
 #ifdef __cplusplus
 }

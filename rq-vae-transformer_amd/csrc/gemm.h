@@ -37,6 +37,7 @@ struct GemmArgs {
     int lda;
     // conv gather (conv != 0): A is NHWC [n_img][Hs][Ws][Cin], Hs = Hin >> ups
     int conv, Hin, Win, Cin, Hout, Wout, ksize, stride, pad, ups;
+    int cin_shift;           // log2(Cin) when Cin is a power of two, else -1 (filled by rq_gemm_launch)
     // epilogue
     int epi, gelu_v2;
     const float* bias;       // [N] (or [steps][N] when bias_step != nullptr)
@@ -47,6 +48,7 @@ struct GemmArgs {
     const bf16_t* resid;
     int ldr;
     int splitk;
+    int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
 };
 
 static __device__ __forceinline__ float rq_gelu(float x, int v2) {
@@ -58,8 +60,9 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int MODE>   // MODE 0: dense A; 1: conv gather; 2: conv gather through a folded nearest-2x upsample
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr bool CONV = MODE != 0;
     constexpr int BK = 64;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int MI = WM / 32, NI = WN / 32;
@@ -93,26 +96,52 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int chunk = tid & 7, lrow = tid >> 3;
 
-    // Per-row gather bases.  Loads are UNCONDITIONAL (addresses clamped into the tensor): a predicated
-    // load becomes an exec-masked branch and hipcc then drains vmcnt(0) at every join, which serialises
-    // the whole pipeline on memory latency.  Rows >= M / >= N only feed outputs that are never stored;
-    // conv padding taps must contribute zeros, so their validity mask is applied when the registers are
-    // written to LDS, after the (counted) wait.
-    long a_base[A_IT];     // element offset of (row, k=0) for dense; image base for conv
-    int a_oy[A_IT], a_ox[A_IT];
+    // Per-row gather state.  Loads are UNCONDITIONAL (addresses always inside the tensor): a predicated
+    // load becomes an exec-masked branch and hipcc then drains vmcnt(0) at every join, which serialises the
+    // pipeline on memory latency.  Rows >= M / >= N only feed outputs that are never stored.  Conv padding
+    // taps must contribute zeros: each row carries a 9-bit validity mask computed once, the load of an
+    // invalid tap is redirected to the row's own (always valid) centre pixel and zeroed when the registers
+    // are written to LDS.  Per K-tile the address is  pixel base + one wave-uniform tap offset, so the
+    // gather costs a handful of VALU per row instead of re-deriving (iy, ix) every tile (PMC: the first
+    // version issued 13 VALU + 8 SALU per MFMA).
+    long a_base[A_IT];      // dense: &A[m][chunk*8]; conv: element offset of tap (0,0) for this output pixel
+    long a_safe[A_IT];      // conv: offset of an in-bounds pixel of the same image
+    int a_par[A_IT];        // MODE 2: (oy&1) | (ox&1)<<1
+    unsigned a_valid[A_IT]; // conv: bit t = tap t lies inside the image
+    const int Hs = p.Hin >> p.ups, Ws = p.Win >> p.ups;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + lrow + 32 * i;
         if (m > p.M - 1) m = p.M - 1;
+        a_par[i] = 0;
+        a_valid[i] = 0xffffffffu;
         if (CONV) {
-            int hw = p.Hout * p.Wout;
-            int img = m / hw, rem = m - img * hw;
-            a_oy[i] = rem / p.Wout;
-            a_ox[i] = rem - a_oy[i] * p.Wout;
-            a_base[i] = (long)img * (p.Hin >> p.ups) * (p.Win >> p.ups) * p.Cin + chunk * 8;
+            const int hw = p.Hout * p.Wout;
+            const int img = m / hw, rem = m - img * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            const long img_base = (long)img * Hs * Ws * p.Cin + chunk * 8;
+            unsigned valid = 0;
+            for (int ky = 0; ky < p.ksize; ++ky)
+                for (int kx = 0; kx < p.ksize; ++kx) {
+                    const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
+                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) valid |= 1u << (ky * p.ksize + kx);
+                }
+            a_valid[i] = valid;
+            if (MODE == 2) {
+                // source pixel of tap (ky,kx): ((oy+ky-1)>>1, (ox+kx-1)>>1) = (oy>>1, ox>>1) + ((par+k-1)>>1)
+                a_par[i] = (oy & 1) | ((ox & 1) << 1);
+                a_base[i] = img_base + ((long)(oy >> 1) * Ws + (ox >> 1)) * p.Cin;
+                a_safe[i] = a_base[i];
+            } else {
+                a_base[i] = img_base + ((long)(oy * p.stride - p.pad) * Ws + (ox * p.stride - p.pad)) * p.Cin;
+                int cy = oy * p.stride, cx = ox * p.stride;
+                cy = cy < p.Hin ? cy : p.Hin - 1;
+                cx = cx < p.Win ? cx : p.Win - 1;
+                a_safe[i] = img_base + ((long)cy * Ws + cx) * p.Cin;
+            }
         } else {
-            a_oy[i] = a_ox[i] = 0;
             a_base[i] = (long)m * p.lda + chunk * 8;
+            a_safe[i] = a_base[i];
         }
     }
     const bf16_t* w_ptr[B_IT];
@@ -123,23 +152,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         w_ptr[i] = p.W + (long)n * p.K + chunk * 8;
     }
 
-    // returns the validity mask of the A rows (bit i = tap inside the image); dense GEMM: all ones
+    // returns the validity mask of the A rows (bit i = this K-tile's tap is inside the image for row i)
     auto load_tile = [&](int kt, rq_u128* ra, rq_u128* rb) -> unsigned {
         const int k0 = kt * BK;
         unsigned mask = 0xffffffffu;
         if (CONV) {
-            const int tap = k0 / p.Cin;
+            // wave-uniform tap decode (scalar unit)
+            const int tap = p.cin_shift >= 0 ? (k0 >> p.cin_shift) : (k0 / p.Cin);
             const int ci0 = k0 - tap * p.Cin;
-            const int dy = tap / p.ksize - p.pad, dx = tap % p.ksize - p.pad;
+            const int ky = p.ksize == 3 ? (tap * 11) >> 5 : 0;      // tap / 3 for tap < 9
+            const int kx = tap - ky * p.ksize;
             mask = 0;
+            if (MODE == 2) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                int iy = a_oy[i] * p.stride + dy, ix = a_ox[i] * p.stride + dx;
-                const bool ok = iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                mask |= (ok ? 1u : 0u) << i;
-                iy = iy < 0 ? 0 : (iy >= p.Hin ? p.Hin - 1 : iy);
-                ix = ix < 0 ? 0 : (ix >= p.Win ? p.Win - 1 : ix);
-                ra[i] = ld128(p.A + a_base[i] + ((long)(iy >> p.ups) * (p.Win >> p.ups) + (ix >> p.ups)) * p.Cin + ci0);
+                for (int i = 0; i < A_IT; ++i) {
+                    const bool ok = (a_valid[i] >> tap) & 1u;
+                    const int dsy = ((a_par[i] & 1) + ky - 1) >> 1, dsx = ((a_par[i] >> 1) + kx - 1) >> 1;
+                    const long off = a_base[i] + (long)((dsy * Ws + dsx) * p.Cin + ci0);
+                    mask |= (ok ? 1u : 0u) << i;
+                    ra[i] = ld128(p.A + (ok ? off : a_safe[i] + ci0));
+                }
+            } else {
+                const long toff = (long)(ky * Ws + kx) * p.Cin + ci0;       // same for every row
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const bool ok = (a_valid[i] >> tap) & 1u;
+                    mask |= (ok ? 1u : 0u) << i;
+                    ra[i] = ld128(p.A + (ok ? a_base[i] + toff : a_safe[i] + ci0));
+                }
             }
         } else {
 #pragma unroll
@@ -222,9 +262,74 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogue
+    if (p.dbg & 1) {          // ablation: keep the accumulators live, store one value per wave
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+        if (keep == 12345.678f) ((float*)p.out)[0] = keep;
+        return;
+    }
     const float* bias = p.bias;
     if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
     const int epi = p.epi;
+    if (epi <= EPI_BF16_RESID) {
+        // bf16 outputs: stage the fp32 tile through LDS (reusing the operand buffers) so that global
+        // stores -- and the residual reads -- are row-contiguous 8-byte accesses instead of one scattered
+        // 2-byte access per accumulator register (ablation: the scattered epilogue cost 33-80 % on top of
+        // the main loop on the decoder convs).
+        float* sC = (float*)smem;                  // [BM][BN] fp32 <= (BM+BN)*256 bytes
+        rq_syncthreads();                          // every wave is done reading the operand buffers
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nl = wn * WN + j * 32 + (lane & 31);
+                const int n = n0 + nl;
+                const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bv;
+                    if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
+                    sC[ml * BN + nl] = v;
+                }
+            }
+        rq_syncthreads();
+        constexpr int QPR = BN / 4;                // float4 groups per row
+        const bool n_vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+#pragma unroll 4
+        for (int q = tid; q < BM * QPR; q += 256) {
+            const int ml = q / QPR, nl = (q - ml * QPR) * 4;
+            const int m = m0 + ml, n = n0 + nl;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *(const f32x4*)(sC + ml * BN + nl);
+            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+            if (n_vec_ok) {
+                if (epi == EPI_BF16_RESID) {
+                    const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                    const uint32_t r0 = rp[0], r1 = rp[1];
+                    v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                    v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                }
+                uint32_t* op = (uint32_t*)o;
+                const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
+                op[0] = w0;
+                op[1] = w1;
+            } else {
+                for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                    float x = v[e];
+                    if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                    o[e] = f32_to_bf16(x);
+                }
+            }
+        }
+        return;
+    }
+    // fp32 outputs: a wavefront store already covers 2 x 128 contiguous bytes
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -235,20 +340,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m >= p.M || n >= p.N) continue;
-                float v = acc[i][j][r] + bv;
+                const float v = acc[i][j][r] + bv;
                 const long o = (long)m * p.ldo + n;
-                if (epi == EPI_BF16) {
-                    ((bf16_t*)p.out)[o] = f32_to_bf16(v);
-                } else if (epi == EPI_BF16_GELU) {
-                    ((bf16_t*)p.out)[o] = f32_to_bf16(rq_gelu(v, p.gelu_v2));
-                } else if (epi == EPI_BF16_RESID) {
-                    v += bf16_to_f32(p.resid[(long)m * p.ldr + n]);
-                    ((bf16_t*)p.out)[o] = f32_to_bf16(v);
-                } else if (epi == EPI_F32) {
-                    ((float*)p.out)[o] = v;
-                } else {
-                    ((float*)p.out)[(long)blockIdx.z * p.M * p.ldo + o] = v;
-                }
+                if (epi == EPI_F32) ((float*)p.out)[o] = v;
+                else ((float*)p.out)[(long)blockIdx.z * p.M * p.ldo + o] = v;
             }
         }
 }

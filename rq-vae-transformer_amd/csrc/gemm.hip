@@ -2,21 +2,22 @@
 #include "gemm.h"
 #include "rq_common.h"
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int MODE>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, CONV>), grid, dim3(256), smem, stream, a);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE>), grid, dim3(256), smem, stream, a);
     return rq_check_launch("gemm_bf16_kernel");
 }
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
-    return a.conv ? launch_c<BM, BN, true>(a, stream) : launch_c<BM, BN, false>(a, stream);
+    if (!a.conv) return launch_c<BM, BN, 0>(a, stream);
+    return a.ups ? launch_c<BM, BN, 2>(a, stream) : launch_c<BM, BN, 1>(a, stream);
 }
 
 int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
@@ -26,6 +27,13 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm: K=%d must be a positive multiple of 64 (M=%d N=%d)", a.K, a.M, a.N);
     if (a.conv && (a.Cin % 64 != 0 || a.K != a.ksize * a.ksize * a.Cin))
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv gemm: Cin=%d must be a multiple of 64", a.Cin);
+    a.cin_shift = -1;
+    if (a.conv)
+        for (int sh = 0; sh < 16; ++sh)
+            if ((1 << sh) == a.Cin) a.cin_shift = sh;
+    if (a.conv && a.ups && (a.stride != 1 || a.ksize != 3 || a.pad != 1 || (a.Hin & 1) || (a.Win & 1)))
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv gemm: the folded upsample needs a 3x3 stride-1 conv on even sizes");
+    if (a.conv && a.ksize != 1 && a.ksize != 3) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv gemm: kernel size %d", a.ksize);
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
     if (bm == 64 && bn == 64) return launch_t<64, 64>(a, stream);
@@ -67,14 +75,34 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
 extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
+    int flags = 0;
+    if (epi >= 16) { flags = 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
-    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk;
+    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags;
     if (bm <= 0 || bn <= 0) {
         int sk;
         rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk);
         if (splitk <= 0) a.splitk = sk;
     }
     if (a.splitk <= 0) a.splitk = 1;
+    return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
+}
+
+// diagnostics: one implicit-GEMM convolution launch.  x NHWC bf16 [B][H>>ups][W>>ups][Cin], w [Cout][k][k][Cin] bf16,
+// out NHWC bf16 [B][Ho][Wo][Cout] (+bias, +resid when given).  flags bit0: skip the epilogue (ablation).
+extern "C" int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const void* resid, int B, int H, int W,
+                                   int Cin, int Cout, int ksize, int stride, int ups, void* out, int bm, int bn, int flags,
+                                   void* stream) {
+    if (!x || !w || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv: null argument");
+    GemmArgs a{};
+    int Ho = H, Wo = W, pad = ksize / 2;
+    if (stride == 2) { Ho = H / 2; Wo = W / 2; pad = 0; }
+    a.A = (const bf16_t*)x; a.W = (const bf16_t*)w; a.M = B * Ho * Wo; a.N = Cout; a.K = ksize * ksize * Cin; a.lda = Cin;
+    a.conv = 1; a.Hin = H; a.Win = W; a.Cin = Cin; a.Hout = Ho; a.Wout = Wo; a.ksize = ksize; a.stride = stride; a.pad = pad; a.ups = ups;
+    a.epi = resid ? EPI_BF16_RESID : EPI_BF16; a.bias = bias; a.out = out; a.ldo = Cout; a.resid = (const bf16_t*)resid; a.ldr = Cout;
+    a.splitk = 1; a.dbg = flags;
+    if (bm <= 0) bm = a.M >= 128 ? 128 : 64;
+    if (bn <= 0) bn = (Cout % 128 == 0) ? 128 : 64;
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
 }

@@ -57,6 +57,8 @@ _SIGS = {
                                         C.POINTER(C.c_double)]),
     'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'rqamd_dbg_conv_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -176,6 +178,19 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
             out = torch.empty((M, N), dtype=torch.float32 if epi == 3 else torch.bfloat16, device=a_bf16.device)
     check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
                                     ptr(out), bm, bn, splitk, stream_of(a_bf16)))
+    return out
+
+
+def dbg_conv(x, w, bias=None, resid=None, ksize=3, stride=1, ups=0, bm=0, bn=0, flags=0, out=None):
+    """diagnostics: x (B,Hs,Ws,Cin) bf16 NHWC, w (Cout,k,k,Cin) bf16 -> (B,Ho,Wo,Cout) bf16."""
+    B, Hs, Ws, Cin = x.shape
+    H, W = Hs << ups, Ws << ups
+    Cout = w.shape[0]
+    Ho, Wo = (H // 2, W // 2) if stride == 2 else (H, W)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    check(lib().rqamd_dbg_conv_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias), ptr(resid), B, H, W, Cin, Cout,
+                                    ksize, stride, ups, ptr(out), bm, bn, flags, stream_of(x)))
     return out
 
 
