@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 1024)), help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 2048)), help='images per GPU per step')
     ap.add_argument('--model', default='huge')
     ap.add_argument('--top-k', type=int, default=None)
     ap.add_argument('--top-p', type=float, default=None)

@@ -22,6 +22,10 @@
 #pragma once
 #include "rq_hip.h"
 
+#ifndef RQ_GEMM_VARIANT
+#define RQ_GEMM_VARIANT 0
+#endif
+
 enum GemmEpi {
     EPI_BF16 = 0,         // out bf16 = acc + bias
     EPI_BF16_GELU = 1,    // out bf16 = gelu(acc + bias)
@@ -214,6 +218,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     auto compute = [&](int buf) {
         const bf16_t* a = sA + buf * BM * BK;
         const bf16_t* b = sB + buf * BN * BK;
+#if RQ_GEMM_VARIANT == 1
+        // all fragments of the K-tile first (one LDS latency per tile), then 4*MI*NI back-to-back MFMAs
+        bf16x8 af[4][MI], bfr[4][NI];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[ks][i] = as_bf16x8(ld128(a + swz_off(wm * WM + i * 32 + frow, ks * 2 + fk)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[ks][j] = as_bf16x8(ld128(b + swz_off(wn * WN + j * 32 + frow, ks * 2 + fk)));
+        }
+        rq_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j]);
+        rq_setprio(0);
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[MI], bfr[NI];
@@ -221,11 +244,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(a + swz_off(wm * WM + i * 32 + frow, ks * 2 + fk)));
 #pragma unroll
             for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(b + swz_off(wn * WN + j * 32 + frow, ks * 2 + fk)));
+#if RQ_GEMM_VARIANT == 2
+            rq_setprio(1);
+#endif
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
+#if RQ_GEMM_VARIANT == 2
+            rq_setprio(0);
+#endif
         }
+#endif
     };
 
     // Two register sets keep two K-tiles of global loads in flight (tile t+1 landing, tile t+2 issued)

@@ -61,6 +61,7 @@ static __device__ __forceinline__ int rq_shfl_i(int v, int lane) { return __shfl
 static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
 // pins instruction order at this point (hipcc otherwise sinks independent global loads below LDS writes)
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)
+#define rq_setprio(x) __builtin_amdgcn_s_setprio(x)
 #define RQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define RQ_LAUNCH(kern, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, smem, (hipStream_t)(stream), __VA_ARGS__)

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 from rqvae import _native  # noqa: E402
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (diagnostics only)
+    _native.LIB_PATH = os.environ['RQ_LIB']
 
 
 def run(B, H, Cin, Cout, ks=3, stride=1, ups=0, resid=False, flags=0, bm=0, bn=0, reps=10, check=False):

@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch  # noqa: E402
 from rqvae import _native  # noqa: E402
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (diagnostics only)
+    _native.LIB_PATH = os.environ['RQ_LIB']
 
 
 def bench(M, N, K, epi, bm, bn, sk, reps=40):
@@ -37,7 +39,7 @@ def bench(M, N, K, epi, bm, bn, sk, reps=40):
 
 if __name__ == '__main__':
     shapes = [('qkv', 4608, 1536, 0), ('proj', 1536, 1536, 4), ('fc1', 6144, 1536, 1), ('fc2', 1536, 6144, 4), ('cls', 16384, 1536, 3)]
-    for M in (64, 256, 512, 1024):
+    for M in ([int(x) for x in os.environ['RQ_MS'].split(',')] if os.environ.get('RQ_MS') else (64, 256, 512, 1024)):
         for name, N, K, epi in shapes:
             best = None
             rows = []
