@@ -100,110 +100,126 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int chunk = tid & 7, lrow = tid >> 3;
 
-    // Per-row gather state.  Loads are UNCONDITIONAL (addresses always inside the tensor): a predicated
-    // load becomes an exec-masked branch and hipcc then drains vmcnt(0) at every join, which serialises the
-    // pipeline on memory latency.  Rows >= M / >= N only feed outputs that are never stored.  Conv padding
-    // taps must contribute zeros: each row carries a 9-bit validity mask computed once, the load of an
-    // invalid tap is redirected to the row's own (always valid) centre pixel and zeroed when the registers
-    // are written to LDS.  Per K-tile the address is  pixel base + one wave-uniform tap offset, so the
-    // gather costs a handful of VALU per row instead of re-deriving (iy, ix) every tile (PMC: the first
-    // version issued 13 VALU + 8 SALU per MFMA).
-    long a_base[A_IT];      // dense: &A[m][chunk*8]; conv: element offset of tap (0,0) for this output pixel
-    long a_safe[A_IT];      // conv: offset of an in-bounds pixel of the same image
-    int a_par[A_IT];        // MODE 2: (oy&1) | (ox&1)<<1
-    unsigned a_valid[A_IT]; // conv: bit t = tap t lies inside the image
+    // ---------------------------------------------------------------------------------------------
+    // Addressing.  Everything the main loop touches is either loop-invariant or one 32-bit add:
+    //  * LDS: the XOR swizzle of a fragment read depends only on (lane&31)>>1 and of a staging write only
+    //    on (tid>>3)>>1, so each thread keeps a few byte offsets; tile rows / buffers are immediates.
+    //  * global: 32-bit BYTE offsets from the (wave-uniform) tensor bases (launcher checks < 4 GiB).
+    //  * Loads are UNCONDITIONAL: a predicated load becomes an exec-masked branch and hipcc then drains
+    //    vmcnt(0) at every join, serialising the pipeline.  Rows >= M / >= N only feed outputs that are
+    //    never stored.  Conv padding taps must contribute zeros: each row has a 9-bit validity mask
+    //    (computed once); an invalid tap loads the row's centre pixel instead and is zeroed when the
+    //    registers go to LDS (a branch taken only on border tiles).
+    // (PMC on the first version: 13 VALU + 8 SALU per MFMA -- the issue port, not the matrix pipe, was busy.)
+    const char* gA = (const char*)p.A;
+    const char* gW = (const char*)p.W;
+    unsigned a_off[A_IT];    // dense: byte offset of A[m][chunk*8]; conv: byte offset of tap (0,0) (may wrap below 0)
+    unsigned a_safe[A_IT];   // conv: byte offset of an in-bounds pixel of the same image
+    int a_par[A_IT];         // MODE 2: (oy&1) | (ox&1)<<1
+    unsigned a_valid[A_IT];  // conv: bit t = tap t lies inside the image
     const int Hs = p.Hin >> p.ups, Ws = p.Win >> p.ups;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         int m = m0 + lrow + 32 * i;
         if (m > p.M - 1) m = p.M - 1;
         a_par[i] = 0;
-        a_valid[i] = 0xffffffffu;
+        a_valid[i] = 0x1ffu;
+        a_safe[i] = 0;
         if (CONV) {
             const int hw = p.Hout * p.Wout;
             const int img = m / hw, rem = m - img * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            const long img_base = (long)img * Hs * Ws * p.Cin + chunk * 8;
+            const unsigned img_base = ((unsigned)img * Hs * Ws * p.Cin + chunk * 8) * 2u;
+            // validity of the 3 (or 1) rows and columns of the stencil, combined into 9 bits
+            unsigned vy = 0, vx = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int iy = oy * p.stride + k - p.pad, ix = ox * p.stride + k - p.pad;
+                if (k < p.ksize && iy >= 0 && iy < p.Hin) vy |= 1u << k;
+                if (k < p.ksize && ix >= 0 && ix < p.Win) vx |= 1u << k;
+            }
             unsigned valid = 0;
-            for (int ky = 0; ky < p.ksize; ++ky)
-                for (int kx = 0; kx < p.ksize; ++kx) {
-                    const int iy = oy * p.stride + ky - p.pad, ix = ox * p.stride + kx - p.pad;
-                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) valid |= 1u << (ky * p.ksize + kx);
-                }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                if ((vy >> ky) & 1u) valid |= vx << (ky * p.ksize);
             a_valid[i] = valid;
             if (MODE == 2) {
                 // source pixel of tap (ky,kx): ((oy+ky-1)>>1, (ox+kx-1)>>1) = (oy>>1, ox>>1) + ((par+k-1)>>1)
                 a_par[i] = (oy & 1) | ((ox & 1) << 1);
-                a_base[i] = img_base + ((long)(oy >> 1) * Ws + (ox >> 1)) * p.Cin;
-                a_safe[i] = a_base[i];
+                a_off[i] = img_base + (unsigned)(((oy >> 1) * Ws + (ox >> 1)) * p.Cin) * 2u;
+                a_safe[i] = a_off[i];
             } else {
-                a_base[i] = img_base + ((long)(oy * p.stride - p.pad) * Ws + (ox * p.stride - p.pad)) * p.Cin;
+                a_off[i] = img_base + (unsigned)(((oy * p.stride - p.pad) * Ws + (ox * p.stride - p.pad)) * p.Cin) * 2u;
                 int cy = oy * p.stride, cx = ox * p.stride;
                 cy = cy < p.Hin ? cy : p.Hin - 1;
                 cx = cx < p.Win ? cx : p.Win - 1;
-                a_safe[i] = img_base + ((long)cy * Ws + cx) * p.Cin;
+                a_safe[i] = img_base + (unsigned)((cy * Ws + cx) * p.Cin) * 2u;
             }
         } else {
-            a_base[i] = (long)m * p.lda + chunk * 8;
-            a_safe[i] = a_base[i];
+            a_off[i] = ((unsigned)m * p.lda + chunk * 8) * 2u;
         }
     }
-    const bf16_t* w_ptr[B_IT];
+    unsigned w_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         int n = n0 + lrow + 32 * i;
         if (n > p.N - 1) n = p.N - 1;
-        w_ptr[i] = p.W + (long)n * p.K + chunk * 8;
+        w_off[i] = ((unsigned)n * p.K + chunk * 8) * 2u;
     }
+    constexpr unsigned FULL = (1u << A_IT) - 1u;
 
     // returns the validity mask of the A rows (bit i = this K-tile's tap is inside the image for row i)
     auto load_tile = [&](int kt, rq_u128* ra, rq_u128* rb) -> unsigned {
-        const int k0 = kt * BK;
-        unsigned mask = 0xffffffffu;
+        const unsigned kb = (unsigned)kt * (BK * 2);          // byte offset of the K-tile (dense operands)
+        unsigned mask = FULL;
         if (CONV) {
             // wave-uniform tap decode (scalar unit)
+            const int k0 = kt * BK;
             const int tap = p.cin_shift >= 0 ? (k0 >> p.cin_shift) : (k0 / p.Cin);
             const int ci0 = k0 - tap * p.Cin;
             const int ky = p.ksize == 3 ? (tap * 11) >> 5 : 0;      // tap / 3 for tap < 9
             const int kx = tap - ky * p.ksize;
+            const unsigned cb = (unsigned)ci0 * 2u;
             mask = 0;
             if (MODE == 2) {
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
                     const bool ok = (a_valid[i] >> tap) & 1u;
                     const int dsy = ((a_par[i] & 1) + ky - 1) >> 1, dsx = ((a_par[i] >> 1) + kx - 1) >> 1;
-                    const long off = a_base[i] + (long)((dsy * Ws + dsx) * p.Cin + ci0);
+                    const unsigned off = a_off[i] + (unsigned)((dsy * Ws + dsx) * p.Cin) * 2u;
                     mask |= (ok ? 1u : 0u) << i;
-                    ra[i] = ld128(p.A + (ok ? off : a_safe[i] + ci0));
+                    ra[i] = ld128(gA + ((ok ? off : a_safe[i]) + cb));
                 }
             } else {
-                const long toff = (long)(ky * Ws + kx) * p.Cin + ci0;       // same for every row
+                const unsigned toff = (unsigned)((ky * Ws + kx) * p.Cin) * 2u;       // same for every row
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
                     const bool ok = (a_valid[i] >> tap) & 1u;
                     mask |= (ok ? 1u : 0u) << i;
-                    ra[i] = ld128(p.A + (ok ? a_base[i] + toff : a_safe[i] + ci0));
+                    ra[i] = ld128(gA + ((ok ? a_off[i] + toff : a_safe[i]) + cb));
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) ra[i] = ld128(p.A + a_base[i] + k0);
+            for (int i = 0; i < A_IT; ++i) ra[i] = ld128(gA + (a_off[i] + kb));
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = ld128(w_ptr[i] + k0);
+        for (int i = 0; i < B_IT; ++i) rb[i] = ld128(gW + (w_off[i] + kb));
         return mask;
     };
-    auto store_tile = [&](int buf, const rq_u128* ra, const rq_u128* rb, unsigned mask) {
-        bf16_t* a = sA + buf * BM * BK;
-        bf16_t* b = sB + buf * BN * BK;
+    // staging writes: row lrow + 32 i, chunk swizzled by (lrow>>1)&7 (32 i does not change it)
+    char* wr_a = (char*)sA + (lrow * 64 + ((chunk ^ ((lrow >> 1) & 7)) << 3)) * 2;
+    char* wr_b = (char*)sB + (lrow * 64 + ((chunk ^ ((lrow >> 1) & 7)) << 3)) * 2;
+    auto store_tile = [&](int buf, rq_u128* ra, const rq_u128* rb, unsigned mask) {
+        if (CONV && mask != FULL) {             // border tiles only
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            rq_u128 v = ra[i];
-            if (CONV && !((mask >> i) & 1u)) v = zero128();
-            st128(a + swz_off(lrow + 32 * i, chunk), v);
+            for (int i = 0; i < A_IT; ++i)
+                if (!((mask >> i) & 1u)) ra[i] = zero128();
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) st128(b + swz_off(lrow + 32 * i, chunk), rb[i]);
+        for (int i = 0; i < A_IT; ++i) st128(wr_a + buf * (BM * BK * 2) + i * (32 * 64 * 2), ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) st128(wr_b + buf * (BN * BK * 2) + i * (32 * 64 * 2), rb[i]);
     };
 
     f32x16 acc[MI][NI];
@@ -214,48 +230,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // fragment reads: row = wave tile base + 32 i + (lane&31); the swizzle term is per-thread constant
     const int frow = lane & 31, fk = lane >> 5;
+    const char* rd_a[4];
+    const char* rd_b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int c = (((ks * 2 + fk) ^ ((frow >> 1) & 7)) << 3);
+        rd_a[ks] = (const char*)sA + ((wm * WM + frow) * 64 + c) * 2;
+        rd_b[ks] = (const char*)sB + ((wn * WN + frow) * 64 + c) * 2;
+    }
     auto compute = [&](int buf) {
-        const bf16_t* a = sA + buf * BM * BK;
-        const bf16_t* b = sB + buf * BN * BK;
-#if RQ_GEMM_VARIANT == 1
-        // all fragments of the K-tile first (one LDS latency per tile), then 4*MI*NI back-to-back MFMAs
-        bf16x8 af[4][MI], bfr[4][NI];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[ks][i] = as_bf16x8(ld128(a + swz_off(wm * WM + i * 32 + frow, ks * 2 + fk)));
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[ks][j] = as_bf16x8(ld128(b + swz_off(wn * WN + j * 32 + frow, ks * 2 + fk)));
-        }
-        rq_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j]);
-        rq_setprio(0);
-#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[MI], bfr[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(a + swz_off(wm * WM + i * 32 + frow, ks * 2 + fk)));
+            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(rd_a[ks] + buf * (BM * BK * 2) + i * (32 * 64 * 2)));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(b + swz_off(wn * WN + j * 32 + frow, ks * 2 + fk)));
-#if RQ_GEMM_VARIANT == 2
-            rq_setprio(1);
-#endif
+            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(rd_b[ks] + buf * (BN * BK * 2) + j * (32 * 64 * 2)));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
-#if RQ_GEMM_VARIANT == 2
-            rq_setprio(0);
-#endif
         }
-#endif
     };
 
     // Two register sets keep two K-tiles of global loads in flight (tile t+1 landing, tile t+2 issued)

@@ -34,6 +34,11 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     if (a.conv && a.ups && (a.stride != 1 || a.ksize != 3 || a.pad != 1 || (a.Hin & 1) || (a.Win & 1)))
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv gemm: the folded upsample needs a 3x3 stride-1 conv on even sizes");
     if (a.conv && a.ksize != 1 && a.ksize != 3) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv gemm: kernel size %d", a.ksize);
+    {   // the kernel addresses both operands with 32-bit byte offsets
+        const double a_bytes = a.conv ? 2.0 * ((double)a.M / (a.Hout * a.Wout)) * (a.Hin >> a.ups) * (a.Win >> a.ups) * a.Cin : 2.0 * a.M * a.lda;
+        if (a_bytes >= 4294967296.0 || 2.0 * a.N * a.K >= 4294967296.0)
+            return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm: operand larger than 4 GiB (split the batch)");
+    }
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
     if (bm == 64 && bn == 64) return launch_t<64, 64>(a, stream);
@@ -44,30 +49,30 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
 }
 
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk) {
-    // Measured on MI355X (scripts/gemm_bench.py, profiles/r01_gemm_bench.md): for the decode-step shapes
-    // (M = batch rows 64..1024, N,K in 1536..16384) the smallest tile that keeps the grid at <= 768
-    // workgroups (3 per CU) wins; residual-producing GEMMs (N = E) are split along K up to 8 ways to reach
-    // that many workgroups, keeping >= 6 K-tiles per split.
+    // Rule distilled from scripts/gemm_bench.py on MI355X (profiles/r01_gemm_bench.md), M = 64..2048 batch
+    // rows against the 1.4B layer shapes: take the LARGEST tile (most MFMAs per barrier) that still yields
+    // >= 768 workgroups (3 per CU) once split-K is allowed to multiply the count; residual-producing GEMMs
+    // (fp32 partial slabs, reduced by resid_ln) may split K up to 8 ways with >= 8 K-tiles per split.
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-    static const int cand[3][2] = {{64, 64}, {128, 64}, {128, 128}};
-    int pick = 2;
-    for (int c = 0; c < 3; ++c) {
-        if (M <= 64 && cand[c][0] > 64) continue;
-        if (cdiv(M, cand[c][0]) * cdiv(N, cand[c][1]) <= 768) { pick = c; break; }
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    int maxsplit = 1;
+    if (allow_splitk) {
+        maxsplit = (K / 64) / 8;
+        if (maxsplit > 8) maxsplit = 8;
+        if (maxsplit < 1) maxsplit = 1;
     }
-    if (M <= 64) pick = 0;
+    int pick = 3;
+    for (int c = 0; c < 4; ++c) {
+        if (M <= 64 && cand[c][0] > 64) continue;
+        if (cdiv(M, cand[c][0]) * cdiv(N, cand[c][1]) * maxsplit >= 768) { pick = c; break; }
+    }
     *bm = cand[pick][0];
     *bn = cand[pick][1];
     const int tiles = cdiv(M, *bm) * cdiv(N, *bn);
-    *splitk = 1;
-    if (allow_splitk) {
-        int s = 768 / tiles;
-        const int max_by_k = (K / 64) / 6;
-        if (s > max_by_k) s = max_by_k;
-        if (s > 8) s = 8;
-        if (s < 1) s = 1;
-        *splitk = s;
-    }
+    int s = cdiv(768, tiles);
+    if (s > maxsplit) s = maxsplit;
+    if (s < 1) s = 1;
+    *splitk = s;
 }
 
 // diagnostics entry (include/rqamd.h): one raw launch of the decode-step GEMM, for microbenchmarks

@@ -298,6 +298,19 @@ static __device__ __forceinline__ float blk_sum(float v, float* red) {
     rq_syncthreads();
     return t;
 }
+// one barrier per call: partials alternate between two 16-float halves of `red2` (a wave can only reach
+// the next write of a half after every wave has passed the barrier that follows the previous read of it)
+static __device__ __forceinline__ float blk_sum_pp(float v, float* red2, int parity) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* red = red2 + (parity & 1) * 16;
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    rq_syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SMP_T / 64; ++w) t += red[w];
+    return t;
+}
 static __device__ __forceinline__ float blk_max(float v, float* red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v = wave_max(v);
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     float* sx = (float*)smem;                  // [V] logits -> probabilities
     float* red = sx + p.V;                     // [16]
     int* redi = (int*)(red + 16);              // [16]
+    float* red2 = (float*)(redi + 16) + 256 + 4; // [32] ping-pong partials (after hist[256] and bcast[4])
     unsigned* hist = (unsigned*)(redi + 16);   // [256]
     unsigned* bcast = hist + 256;              // [4]
     const int tid = threadIdx.x, V = p.V, row = blockIdx.x;
@@ -423,11 +437,11 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
         for (int bit = 30; bit >= 0; --bit) {
             const unsigned cand = cur | (1u << bit);
             const float cv = __uint_as_float(cand);
+            if (cand > 0x3f800000u) continue;           // probabilities never exceed 1.0 (uniform skip)
             float g = 0.f;
-            if (cand <= 0x3f800000u)
-                for (int i = tid; i < V; i += SMP_T) { const float q = sx[i]; if (q >= cv) g += q; }
-            g = blk_sum(g, red);
-            if (cand <= 0x3f800000u && g >= p.top_p) cur = cand;
+            for (int i = tid; i < V; i += SMP_T) { const float q = sx[i]; if (q >= cv) g += q; }
+            g = blk_sum_pp(g, red2, bit);
+            if (g >= p.top_p) cur = cand;
         }
         const float tau = __uint_as_float(cur);
         // boundary value, strict mass above it, number of ties at it
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
 int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V < 1 || a.V > 36000) return rq_fail(RQAMD_ERR_UNSUPPORTED, "sampler: vocab %d not in 1..36000", a.V);
     if (!(a.temperature > 0.f)) return rq_fail(RQAMD_ERR_INVALID, "sampler: temperature must be > 0");
-    const size_t smem = (size_t)a.V * 4 + 16 * 4 + 16 * 4 + 256 * 4 + 4 * 4;
+    const size_t smem = (size_t)a.V * 4 + 16 * 4 + 16 * 4 + 256 * 4 + 4 * 4 + 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
