@@ -64,7 +64,11 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
     return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3);
 }
 
-template <int BM, int BN, int MODE>   // MODE 0: dense A; 1: conv gather; 2: conv gather through a folded nearest-2x upsample
+// MODE 0: dense A; 1: conv gather; 2: conv gather through a folded nearest-2x upsample.
+// TR 1: accumulate the transposed tile (4 consecutive output columns per lane -> 16-byte fp32 stores); used
+// for the split-K partial slabs, whose rows are short (N = E).  TR 0: bf16 outputs go through an LDS transpose,
+// wide fp32 outputs (logits) are stored as 2 x 128 contiguous bytes per wavefront store.
+template <int BM, int BN, int MODE, int TR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     constexpr bool CONV = MODE != 0;
     constexpr int BK = 64;
@@ -251,7 +255,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = TR ? rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]) : rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
         }
     };
 
@@ -270,6 +275,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         // header along which hipcc's waitcnt pass sees the first half's loads pending, and it then drains
         // them at the top of every iteration (vmcnt(1) in the ISA) -- that serialised the pipeline.
         const int npair = nk >> 1;
+        if (p.dbg & 6) {
+            // ablations (scripts only): bit1 = MFMA + LDS reads + barriers, no staging at all;
+            // bit2 = global loads issued but never written to LDS
+            for (int pi = 0; pi < npair; ++pi) {
+                if (p.dbg & 4) { mk0 = load_tile(kt0 + 2 * pi + 2 < kt1 ? kt0 + 2 * pi + 2 : last, ra0, rb0); rq_sched_barrier(); }
+                compute(0);
+                rq_syncthreads();
+                if (p.dbg & 4) { mk1 = load_tile(kt0 + 2 * pi + 3 < kt1 ? kt0 + 2 * pi + 3 : last, ra1, rb1); rq_sched_barrier(); }
+                compute(1);
+                rq_syncthreads();
+            }
+            if (p.dbg & 4) { store_tile(0, ra0, rb0, mk0); store_tile(1, ra1, rb1, mk1); }
+        } else
         for (int pi = 0; pi < npair; ++pi) {
             const int i = 2 * pi;
             // even tile in LDS buffer 0; set 0 is free, set 1 holds tile i+1
@@ -300,6 +318,77 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         if (keep == 12345.678f) ((float*)p.out)[0] = keep;
         return;
     }
+    if (TR) {
+    // TR: the MFMAs above computed the TRANSPOSED tile (weight fragment as the "A" operand), so in the C/D
+    // register map (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31) the row index is the output
+    // column n and the col index is the output row m: every lane owns, for its row m, four groups of
+    // FOUR CONSECUTIVE n -- one 8-byte (bf16) or 16-byte (fp32) vector store each, and the residual is
+    // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
+    // time on the decoder convs; an LDS-staged transpose was 19 %.)
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const int epi = p.epi;
+    const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WM + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (m >= p.M || n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                const bool full4 = vec_ok && n + 3 < p.N;
+                if (bias && epi != EPI_F32_PARTIAL) {
+                    if (full4) {
+                        const f32x4 bv = *(const f32x4*)(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
+                    }
+                }
+                if (epi == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                }
+                if (epi <= EPI_BF16_RESID) {
+                    bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+                    if (full4) {
+                        if (epi == EPI_BF16_RESID) {
+                            const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                            const uint32_t r0 = rp[0], r1 = rp[1];
+                            v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                            v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                        }
+                        struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
+                        w.a = pack_bf16x2(v[0], v[1]);
+                        w.b = pack_bf16x2(v[2], v[3]);
+                        *(u64*)o = w;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                            float x = v[e];
+                            if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                            o[e] = f32_to_bf16(x);
+                        }
+                    }
+                } else {
+                    float* o = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
+                    if (full4) {
+                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+        return;
+    }
+    // TR == 0: untransposed accumulators (row = output row m, col = output column n)
     const float* bias = p.bias;
     if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
     const int epi = p.epi;

@@ -2,22 +2,22 @@
 #include "gemm.h"
 #include "rq_common.h"
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int TR>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE>), grid, dim3(256), smem, stream, a);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR>), grid, dim3(256), smem, stream, a);
     return rq_check_launch("gemm_bf16_kernel");
 }
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
-    if (!a.conv) return launch_c<BM, BN, 0>(a, stream);
-    return a.ups ? launch_c<BM, BN, 2>(a, stream) : launch_c<BM, BN, 1>(a, stream);
+    if (!a.conv) return a.epi == EPI_F32_PARTIAL ? launch_c<BM, BN, 0, 1>(a, stream) : launch_c<BM, BN, 0, 0>(a, stream);
+    return a.ups ? launch_c<BM, BN, 2, 0>(a, stream) : launch_c<BM, BN, 1, 0>(a, stream);
 }
 
 int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
