@@ -48,6 +48,8 @@ RQT_IN_3800M = rqt(2560, 40, 42, 6, 16384)
 RQT_CC3M_654M = rqt(1280, 20, 26, 4, 16384, vocab_cond=16384, block_cond=32)
 # tiny: 4x4x4 codes, E=128 (2 heads x 64), pairs with a 500x64 codebook
 RQT_TINY = rqt(128, 2, 2, 2, 500, vocab_cond=10, block_size=(4, 4, 4), input_embed_dim=64)
+# text-conditioned variant: 4 conditioning tokens from a 20-word vocabulary (exercises the cond-prefix prefill)
+RQT_TINY_TXT = rqt(128, 2, 2, 2, 500, vocab_cond=20, block_cond=4, block_size=(4, 4, 4), input_embed_dim=64)
 # one real-width layer of each stack (E=1536, 24 heads, V=16384) -- layer-count-independent parity
 RQT_WIDE = rqt(1536, 24, 2, 1, 16384)
 

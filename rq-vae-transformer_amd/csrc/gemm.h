@@ -52,6 +52,7 @@ struct GemmArgs {
     const bf16_t* resid;
     int ldr;
     int splitk;
+    int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
     int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
 };
 
@@ -81,16 +82,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // tile id -> (m-tile, n-tile).  Blocks are dispatched round-robin over the 8 XCDs (private L2s), so
-    // the m-tiles that share one weight tile are given ids 8 apart: same XCD, back to back.
+    // tile id -> (m-tile, n-tile).  Workgroups are dispatched round-robin over the 8 XCDs, each with a private
+    // 4 MiB L2 (block b runs on XCD b % 8 -- a speed assumption only, never a correctness one).  PMC showed
+    // fabric-side fetch traffic at 3-5x the algorithmic bytes with a naive order, so the schedule gives every
+    // XCD a contiguous slice of the tile space and walks it so that what is re-read stays in that XCD's L2:
+    //  * sched 1 (NT >= 8, decode GEMMs): XCD x owns a contiguous range of n-tiles; inside it the m-tiles are
+    //    visited in groups of `sched_gm` whose A panel fits L2, all n-tiles of the range per group.
+    //  * sched 2 (NT < 8, convs): XCD x owns a contiguous band of m-tiles (adjacent output rows share their
+    //    3x3 halo rows), n fastest so an A tile is reused by all its n-tiles at once.
+    // The grid is padded to 8 x (largest slice); surplus workgroups exit here, before any barrier.
     const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
     int mt, nt;
     {
-        const int id = blockIdx.x;
-        if ((NT & 7) == 0) {
-            const int xcd = id & 7, slot = id >> 3;
-            nt = (slot / MT) * 8 + xcd;
-            mt = slot - (slot / MT) * MT;
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        if (p.sched == 1) {
+            const int nb = NT >> 3, rem = NT & 7;
+            const int nn = nb + (xcd < rem ? 1 : 0);
+            const int n_lo = xcd * nb + (xcd < rem ? xcd : rem);
+            if (slot >= nn * MT) return;
+            const int per_group = p.sched_gm * nn;
+            const int mg = slot / per_group, r = slot - mg * per_group;
+            int gm = MT - mg * p.sched_gm;
+            gm = gm < p.sched_gm ? gm : p.sched_gm;
+            nt = n_lo + r / gm;
+            mt = mg * p.sched_gm + (r - (r / gm) * gm);
+        } else if (p.sched == 2) {
+            const int mm = (MT + 7) >> 3;
+            mt = xcd * mm + slot / NT;
+            nt = slot - (slot / NT) * NT;
+            if (slot >= mm * NT || mt >= MT) return;
         } else {
             mt = id / NT;
             nt = id - mt * NT;

@@ -1,5 +1,6 @@
 // gemm.hip -- launcher / tile selection for the bf16 MFMA GEMM (see gemm.h)
 #include "gemm.h"
+#include <stdlib.h>
 #include "rq_common.h"
 
 template <int BM, int BN, int MODE, int TR>
@@ -10,8 +11,26 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
-    dim3 grid(((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM), 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR>), grid, dim3(256), smem, stream, a);
+    // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
+    GemmArgs g = a;
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    int nblocks;
+    if (getenv("RQAMD_GEMM_SCHED0")) {
+        g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
+    } else if (NT >= 8) {
+        const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
+        long panel = (long)BM * ktiles * 64 * 2;                   // bytes of one m-tile's A panel for this K split
+        int gm = (int)((3 << 19) / (panel > 0 ? panel : 1));       // keep ~1.5 MiB of A hot in the 4 MiB L2
+        if (gm < 1) gm = 1;
+        if (gm > MT) gm = MT;
+        g.sched = 1; g.sched_gm = gm;
+        nblocks = 8 * ((NT + 7) / 8) * MT;
+    } else {
+        g.sched = 2; g.sched_gm = 1;
+        nblocks = 8 * ((MT + 7) / 8) * NT;
+    }
+    dim3 grid(nblocks, 1, a.splitk);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR>), grid, dim3(256), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
 template <int BM, int BN>
@@ -64,7 +83,9 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
     int pick = 3;
     for (int c = 0; c < 4; ++c) {
         if (M <= 64 && cand[c][0] > 64) continue;
-        if (cdiv(M, cand[c][0]) * cdiv(N, cand[c][1]) * maxsplit >= 768) { pick = c; break; }
+        const int nt = cdiv(N, cand[c][1]);
+        if (nt >= 8 && (nt & 7) != 0 && cdiv(N, 64) % 8 == 0) continue;   // XCD schedule pads NT to a multiple of 8: avoid idle slices
+        if (cdiv(M, cand[c][0]) * nt * maxsplit >= 768) { pick = c; break; }
     }
     *bm = cand[pick][0];
     *bn = cand[pick][1];

@@ -145,7 +145,15 @@ class RQTransformer(Stage2Model):
         engine's cached path over the given codes (identical to the uncached pass up to rounding --
         the reference's own cached==uncached invariant, transformers.py:352-356)."""
         if self.block_size_cond > 1:
-            raise NotImplementedError('cond_logits of text-conditioned forward() (training-side, transformers.py:150-153)')
+            # the reference returns (seq_logits, cond_logits); cond_logits come from cond_classifier over the
+            # conditioning positions and only feed the training loss (transformers.py:150-153,384-392)
+            raise NotImplementedError('text-conditioned forward() also returns cond_logits (training-side); '
+                                      'use teacher_forced_logits() for the image-code logits')
+        return self.teacher_forced_logits(xs, model_aux, cond)
+
+    @torch.no_grad()
+    def teacher_forced_logits(self, xs, model_aux=None, cond=None):
+        """seq_logits of forward() (transformers.py:113-188) for any block_size_cond, via the engine's cached path."""
         (B, H, W, D) = xs.shape
         assert torch.Size([H, W, D]) == self.block_size
         eng = self._eng()

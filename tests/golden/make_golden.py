@@ -178,14 +178,15 @@ def gen_rqt():
     hps, dd = C.VAE_TINY
     vae, vparams = ref_rqvae(hps, dd, seed=31)
     cb = vparams['quantizer.codebooks.0.weight'][:-1]
-    for tag, cfg, B in (('tiny', C.RQT_TINY, 3),):
+    for tag, cfg, B in (('tiny', C.RQT_TINY, 3), ('tiny_txt', C.RQT_TINY_TXT, 2)):
         m, params = ref_rqt(cfg, seed=41)
         H, W, D = cfg['block_size']
         rng = np.random.default_rng(42)
         codes = rng.integers(0, cfg['vocab_size'], (B, H, W, D))
-        cond = rng.integers(0, cfg['vocab_size_cond'], (B, 1))
+        cond = rng.integers(0, cfg['vocab_size_cond'], (B, max(cfg['block_size_cond'], 1)))
         tc, tcond = torch.from_numpy(codes), torch.from_numpy(cond)
-        logits = m(tc, vae, cond=tcond).numpy()
+        logits = m(tc, vae, cond=tcond)
+        logits = (logits[0] if isinstance(logits, tuple) else logits).numpy()   # (seq_logits, cond_logits) when cond_len > 1
         # cached path == uncached path (the reference's built-in self check, transformers.py:352-356)
         m.init_cache()
         cl = np.zeros_like(logits)

@@ -119,6 +119,17 @@ def test_emu_rqt_tiny_logits(nat, golden):
     assert err.max() < 0.06 and err.mean() < 0.01          # bf16 weights/activations vs fp32 reference, |logits| <= 2.4
 
 
+def test_emu_rqt_text_conditioned_logits(nat, golden):
+    g = golden('rqt_tiny_txt.npz')
+    cfg = C.RQT_TINY_TXT
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    eng = _rqt_engine(nat, cfg, oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed'])))
+    logits = eng.logits(T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64)), [T(cb)] * 4).numpy()
+    err = np.abs(logits - g['logits'])
+    assert err.max() < 0.06 and err.mean() < 0.01
+
+
 def test_emu_rqt_tiny_sample(nat, golden):
     """sample(): teacher-forcing the sampled codes back through the logits path must reproduce, at every
     step, a distribution under which the sampled code has non-zero filtered probability."""

@@ -233,6 +233,25 @@ def test_rqt_sample_semantics(nat, golden):
     assert torch.equal(o1, o2)
 
 
+def test_rqt_text_conditioned(nat, golden):
+    """block_size_cond = 4: the cond prefix is prefilled through the body KV cache."""
+    g = golden('rqt_tiny_txt.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY_TXT, int(g['vae_seed']), int(g['seed']))
+    cond = G(g['cond'], torch.long)
+    logits = N(ar.teacher_forced_logits(G(g['codes'], torch.long), vae, cond=cond))
+    err = np.abs(logits - g['logits'])
+    print('rqt tiny text-cond logits: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01
+    with pytest.raises(NotImplementedError):
+        ar(G(g['codes'], torch.long), vae, cond=cond)
+    torch.cuda.manual_seed_all(1)
+    a = ar.sample(torch.zeros((2, 4, 4, 4), dtype=torch.long, device=DEV), vae, cond=cond, top_k=20, top_p=0.9)
+    torch.cuda.manual_seed_all(1)
+    ar.use_graph = False
+    b = ar.sample(torch.zeros((2, 4, 4, 4), dtype=torch.long, device=DEV), vae, cond=cond, top_k=20, top_p=0.9)
+    assert torch.equal(a, b) and int(a.max()) < 500
+
+
 def test_rqt_batch_invariance(nat, golden):
     """rows are independent: logits of a row do not depend on which batch it sits in (tile placement)."""
     g = golden('rqt_tiny.npz')

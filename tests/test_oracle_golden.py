@@ -96,6 +96,23 @@ def test_rqt_tiny(golden):
     np.testing.assert_allclose(lg, g['logits'][:, 1, 2, 0], rtol=0, atol=1e-5)
 
 
+def test_rqt_tiny_text_conditioned(golden):
+    """block_size_cond = 4: conditioning prefix + prefill of the first cached step (transformers.py:235-239)."""
+    g = golden('rqt_tiny_txt.npz')
+    cfg = C.RQT_TINY_TXT
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    orc = oracle.RQTransformerOracle(cfg, oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed'])))
+    codes, cond = g['codes'].astype(np.int64), g['cond'].astype(np.int64)
+    assert cond.shape == (2, 4)
+    np.testing.assert_allclose(orc.forward(codes, [cb] * 4, cond), g['logits'], rtol=0, atol=1e-5)
+    orc.init_cache()
+    for h in range(4):
+        for w in range(4):
+            lg = orc.cached_forward(codes[:, :h + 1], [cb] * 4, cond, (h, w, 0))
+            np.testing.assert_allclose(lg, g['logits'][:, h, w, 0], rtol=0, atol=1e-5)
+
+
 def test_param_counts():
     """README.md:38-47 of the reference: structural known answers."""
     with open(os.path.join(GOLDEN, 'param_counts.json')) as f:
