@@ -70,7 +70,7 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk) {
     // Rule distilled from scripts/gemm_bench.py on MI355X (profiles/r01_gemm_bench.md), M = 64..2048 batch
     // rows against the 1.4B layer shapes: take the LARGEST tile (most MFMAs per barrier) that still yields
-    // >= 768 workgroups (3 per CU) once split-K is allowed to multiply the count; residual-producing GEMMs
+    // >= 512 workgroups (2 per CU) once split-K is allowed to multiply the count (split target: 768); residual-producing GEMMs
     // (fp32 partial slabs, reduced by resid_ln) may split K up to 8 ways with >= 8 K-tiles per split.
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
@@ -85,7 +85,7 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
         if (M <= 64 && cand[c][0] > 64) continue;
         const int nt = cdiv(N, cand[c][1]);
         if (nt >= 8 && (nt & 7) != 0 && cdiv(N, 64) % 8 == 0) continue;   // XCD schedule pads NT to a multiple of 8: avoid idle slices
-        if (cdiv(M, cand[c][0]) * nt * maxsplit >= 768) { pick = c; break; }
+        if (cdiv(M, cand[c][0]) * nt * maxsplit >= 512) { pick = c; break; }
     }
     *bm = cand[pick][0];
     *bn = cand[pick][1];
