@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 2048)), help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 4096)), help='images per GPU per step')
     ap.add_argument('--model', default='huge')
     ap.add_argument('--top-k', type=int, default=None)
     ap.add_argument('--top-p', type=float, default=None)
@@ -176,7 +176,7 @@ def main():
                             'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
             traffic, traffic_src = None, None
             tp = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic_m2048.json')
-            if args.model == 'huge' and B == 2048 and os.path.exists(tp):
+            if args.model == 'huge' and B >= 2048 and os.path.exists(tp):
                 # PMC counters cannot be collected from inside the timed run; this is the committed result of
                 # scripts/gpu_pmc2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM
                 # shapes at the same batch rows, launch-weighted like `achieved`

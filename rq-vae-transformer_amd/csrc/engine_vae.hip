@@ -27,7 +27,7 @@ struct rqamd_vae {
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
-    int chunk_max = 64;
+    int chunk_max = 128;
     std::string missing;
 };
 
