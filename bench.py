@@ -175,14 +175,14 @@ def main():
                 roofline = {'bound': 'mfma', 'achieved': tfl, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
             traffic, traffic_src = None, None
-            tp = os.path.join(ROOT, 'profiles', 'r01_gemm_traffic_m2048.json')
-            if args.model == 'huge' and B >= 2048 and os.path.exists(tp):
+            tp = os.path.join(ROOT, 'profiles', f'r01_gemm_traffic_m{B}.json')
+            if args.model == 'huge' and os.path.exists(tp):
                 # PMC counters cannot be collected from inside the timed run; this is the committed result of
                 # scripts/gpu_pmc2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM
                 # shapes at the same batch rows, launch-weighted like `achieved`
                 with open(tp) as f:
                     tj = json.load(f)
-                traffic, traffic_src = tj['hbm_bytes_per_launch_weighted'], 'profiles/r01_gemm_traffic_m2048.json'
+                traffic, traffic_src = tj['hbm_bytes_per_launch_weighted'], os.path.relpath(tp, ROOT)
             roofline.update({'traffic': traffic, 'traffic_source': traffic_src,
                              'algorithmic_bytes_per_launch': pf['gemm_bytes'] / pf['gemm_launches'], 'kernel': 'gemm_bf16_kernel', 'launches_per_batch': pf['gemm_launches'],
                              'avg_launch_us': pf['gemm_ms_total'] * 1e3 / pf['gemm_launches'],
