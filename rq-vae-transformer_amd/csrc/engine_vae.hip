@@ -145,8 +145,9 @@ struct VaeRun {
         a.conv = (ks == 3 || stride != 1 || ups) ? 1 : 0;
         a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.ksize = ks; a.stride = stride; a.pad = pad; a.ups = ups;
         a.epi = epi; a.bias = b; a.out = dst; a.ldo = Cout; a.resid = resid; a.ldr = Cout; a.splitk = 1;
-        const int bm = a.M >= 128 ? 128 : 64;
+        int bm = a.M >= 128 ? 128 : 64;
         const int bn = (Cout % 128 == 0) ? 128 : 64;
+        if (bn == 128 && (long)(a.M / 256) * (Cout / 128) >= 512) bm = 256;     // 8-wave tile for the big layers
         err = rq_gemm_launch(a, bm, bn, st);
     }
     void norm(const std::string& name, const bf16_t* src, bf16_t* dst, int HW, int C, int silu) {

@@ -15,7 +15,8 @@
 // (rqvae/models/rqvae/layers.py:20-182, modules.py:23,67,123,165), F.interpolate(nearest, x2)
 // (layers.py:32) and F.pad(0,1,0,1) (layers.py:52-53).
 //
-// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 64, wave tile (BM/2) x (BN/2) built from
+// Tiling: WGM x WGN wavefronts (2x2 = 256 threads, or 4x2 = 512 threads for the 256x128 tile), block tile
+// BM x BN x 64, wave tile (BM/WGM) x (BN/WGN) built from
 // v_mfma_f32_32x32x16_bf16; LDS double-buffered, register-staged (global_load_dwordx4 -> ds_write_b128)
 // with the loads of the next TWO K-tiles in flight behind the current tile's MFMAs; XCD-aware tile order; 16-byte-chunk XOR swizzle
 // (chunk ^ ((row>>1)&7)) makes both the b128 writes and the fragment reads bank-conflict free.
@@ -69,19 +70,21 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
 // TR 1: accumulate the transposed tile (4 consecutive output columns per lane -> 16-byte fp32 stores); used
 // for the split-K partial slabs, whose rows are short (N = E).  TR 0: bf16 outputs go through an LDS transpose,
 // wide fp32 outputs (logits) are stored as 2 x 128 contiguous bytes per wavefront store.
-template <int BM, int BN, int MODE, int TR>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2>   // WGM x WGN wavefronts per workgroup
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr int NTH = 64 * WGM * WGN;      // threads per workgroup
+    constexpr int RP = NTH / 8;              // tile rows staged per pass (8 threads x 16 B per 64-wide row)
     constexpr bool CONV = MODE != 0;
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_IT = BM / RP, B_IT = BN / RP;
     RQ_DYN_SMEM(smem);
     bf16_t* sA = (bf16_t*)smem;              // [2][BM*64]
     bf16_t* sB = sA + 2 * BM * BK;           // [2][BN*64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     // tile id -> (m-tile, n-tile).  Workgroups are dispatched round-robin over the 8 XCDs, each with a private
     // 4 MiB L2 (block b runs on XCD b % 8 -- a speed assumption only, never a correctness one).  PMC showed
     // fabric-side fetch traffic at 3-5x the algorithmic bytes with a naive order, so the schedule gives every
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int Hs = p.Hin >> p.ups, Ws = p.Win >> p.ups;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        int m = m0 + lrow + 32 * i;
+        int m = m0 + lrow + RP * i;
         if (m > p.M - 1) m = p.M - 1;
         a_par[i] = 0;
         a_valid[i] = 0x1ffu;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     unsigned w_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        int n = n0 + lrow + 32 * i;
+        int n = n0 + lrow + RP * i;
         if (n > p.N - 1) n = p.N - 1;
         w_off[i] = ((unsigned)n * p.K + chunk * 8) * 2u;
     }
@@ -241,9 +244,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                 if (!((mask >> i) & 1u)) ra[i] = zero128();
         }
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) st128(wr_a + buf * (BM * BK * 2) + i * (32 * 64 * 2), ra[i]);
+        for (int i = 0; i < A_IT; ++i) st128(wr_a + buf * (BM * BK * 2) + i * (RP * 64 * 2), ra[i]);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) st128(wr_b + buf * (BN * BK * 2) + i * (32 * 64 * 2), rb[i]);
+        for (int i = 0; i < B_IT; ++i) st128(wr_b + buf * (BN * BK * 2) + i * (RP * 64 * 2), rb[i]);
     };
 
     f32x16 acc[MI][NI];
@@ -338,6 +341,83 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         if (keep == 12345.678f) ((float*)p.out)[0] = keep;
         return;
     }
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const int epi = p.epi;
+    if (TR && epi <= EPI_BF16_RESID) {
+        // bf16 outputs: each lane packs its 4 consecutive columns to 8 bytes and writes them into a padded
+        // [BM][BN] bf16 tile in LDS (over the operand buffers); the tile is then streamed out as 16-byte,
+        // row-contiguous global stores, the residual being read the same way.  (Ablation on the decoder convs:
+        // the first, scattered 2-byte epilogue cost +33..80 %; an fp32 LDS transpose +24 %.)
+        constexpr int LDR = BN * 2 + 16;           // padded row stride in bytes (16-byte aligned rows)
+        static_assert(BM * LDR <= (BM + BN) * 64 * 2 * 2, "bf16 epilogue tile must fit the operand buffers");
+        char* sT = (char*)smem;
+        rq_syncthreads();                          // every wave is done reading the operand buffers
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * WM + i * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                    const int n = n0 + nl;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                    if (bias) {
+                        if (n + 3 < p.N) {
+                            const f32x4 bv = *(const f32x4*)(bias + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                        } else {
+                            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
+                        }
+                    }
+                    if (epi == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                    }
+                    if (epi == EPI_BF16_RESID) {
+                        // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
+                        const int m = m0 + ml;
+                        if (m < p.M && n < p.N) {
+                            const bf16_t* rp = p.resid + (long)m * p.ldr + n;
+                            if ((p.ldr & 3) == 0 && n + 3 < p.N) {
+                                const uint32_t r0 = ((const uint32_t*)rp)[0], r1 = ((const uint32_t*)rp)[1];
+                                v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                                v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                            } else {
+                                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bf16_to_f32(rp[e]);
+                            }
+                        }
+                    }
+                    struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
+                    w.a = pack_bf16x2(v[0], v[1]);
+                    w.b = pack_bf16x2(v[2], v[3]);
+                    *(u64*)(sT + ml * LDR + nl * 2) = w;
+                }
+            }
+        }
+        rq_syncthreads();
+        constexpr int CPR = BN / 8;                // 16-byte chunks per row
+        const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
+#pragma unroll 4
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int ml = c / CPR, nl = (c - ml * CPR) * 8;
+            const int m = m0 + ml, n = n0 + nl;
+            if (m >= p.M || n >= p.N) continue;
+            rq_u128 u = ld128(sT + ml * LDR + nl * 2);
+            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+            if (v16) {
+                st128(o, u);
+            } else {
+                const bf16_t* t = (const bf16_t*)(sT + ml * LDR + nl * 2);
+                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = t[e];
+            }
+        }
+        return;
+    }
     if (TR) {
     // TR: the MFMAs above computed the TRANSPOSED tile (weight fragment as the "A" operand), so in the C/D
     // register map (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31) the row index is the output
@@ -345,9 +425,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     // FOUR CONSECUTIVE n -- one 8-byte (bf16) or 16-byte (fp32) vector store each, and the residual is
     // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
     // time on the decoder convs; an LDS-staged transpose was 19 %.)
-    const float* bias = p.bias;
-    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
-    const int epi = p.epi;
     const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -409,57 +486,63 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         return;
     }
     // TR == 0: untransposed accumulators (row = output row m, col = output column n)
-    const float* bias = p.bias;
-    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
-    const int epi = p.epi;
     if (epi <= EPI_BF16_RESID) {
         // bf16 outputs: stage the fp32 tile through LDS (reusing the operand buffers) so that global
         // stores -- and the residual reads -- are row-contiguous 8-byte accesses instead of one scattered
         // 2-byte access per accumulator register (ablation: the scattered epilogue cost 33-80 % on top of
         // the main loop on the decoder convs).
-        float* sC = (float*)smem;                  // [BM][BN] fp32 <= (BM+BN)*256 bytes
-        rq_syncthreads();                          // every wave is done reading the operand buffers
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int nl = wn * WN + j * 32 + (lane & 31);
-                const int n = n0 + nl;
-                const float bv = (bias && n < p.N) ? bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = acc[i][j][r] + bv;
-                    if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
-                    sC[ml * BN + nl] = v;
-                }
-            }
-        rq_syncthreads();
+        float* sC = (float*)smem;                  // [HB][BN] fp32 slab of the tile, reusing the operand buffers
+        constexpr int SM_BYTES = (BM + BN) * 64 * 2 * 2;
+        constexpr int NH = (BM * BN * 4 + SM_BYTES - 1) / SM_BYTES;     // passes (1, or 2 for the 256-row tile)
+        constexpr int HB = BM / NH;                                     // rows per pass (multiple of WM)
+        static_assert(HB % WM == 0 && HB * BN * 4 <= SM_BYTES, "epilogue slab must fit the operand buffers");
         constexpr int QPR = BN / 4;                // float4 groups per row
         const bool n_vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            rq_syncthreads();                      // operand buffers / previous slab are free
+            if (wm * WM >= hh * HB && wm * WM < (hh + 1) * HB) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int nl = wn * WN + j * 32 + (lane & 31);
+                        const int n = n0 + nl;
+                        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = wm * WM - hh * HB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            float v = acc[i][j][r] + bv;
+                            if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
+                            sC[ml * BN + nl] = v;
+                        }
+                    }
+            }
+            rq_syncthreads();
 #pragma unroll 4
-        for (int q = tid; q < BM * QPR; q += 256) {
-            const int ml = q / QPR, nl = (q - ml * QPR) * 4;
-            const int m = m0 + ml, n = n0 + nl;
-            if (m >= p.M || n >= p.N) continue;
-            f32x4 v = *(const f32x4*)(sC + ml * BN + nl);
-            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
-            if (n_vec_ok) {
-                if (epi == EPI_BF16_RESID) {
-                    const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
-                    const uint32_t r0 = rp[0], r1 = rp[1];
-                    v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                    v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
-                }
-                uint32_t* op = (uint32_t*)o;
-                const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
-                op[0] = w0;
-                op[1] = w1;
-            } else {
-                for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                    float x = v[e];
-                    if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
-                    o[e] = f32_to_bf16(x);
+            for (int q = tid; q < HB * QPR; q += NTH) {
+                const int ml = q / QPR, nl = (q - ml * QPR) * 4;
+                const int m = m0 + hh * HB + ml, n = n0 + nl;
+                if (m >= p.M || n >= p.N) continue;
+                f32x4 v = *(const f32x4*)(sC + ml * BN + nl);
+                bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+                if (n_vec_ok) {
+                    if (epi == EPI_BF16_RESID) {
+                        const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                        const uint32_t r0 = rp[0], r1 = rp[1];
+                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                    }
+                    uint32_t* op = (uint32_t*)o;
+                    const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
+                    op[0] = w0;
+                    op[1] = w1;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                        float x = v[e];
+                        if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                        o[e] = f32_to_bf16(x);
+                    }
                 }
             }
         }

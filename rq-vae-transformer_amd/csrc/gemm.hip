@@ -3,12 +3,12 @@
 #include <stdlib.h>
 #include "rq_common.h"
 
-template <int BM, int BN, int MODE, int TR>
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * 2;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
@@ -30,13 +30,16 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         nblocks = 8 * ((MT + 7) / 8) * NT;
     }
     dim3 grid(nblocks, 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR>), grid, dim3(256), smem, stream, g);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
-    if (!a.conv) return a.epi == EPI_F32_PARTIAL ? launch_c<BM, BN, 0, 1>(a, stream) : launch_c<BM, BN, 0, 0>(a, stream);
-    return a.ups ? launch_c<BM, BN, 2, 0>(a, stream) : launch_c<BM, BN, 1, 0>(a, stream);
+    // transposed accumulators (TR = 1) for everything except wide fp32 rows (logits / fp32 activations)
+    const bool tr = a.epi != EPI_F32;
+    if (!a.conv) return tr ? launch_c<BM, BN, 0, 1>(a, stream) : launch_c<BM, BN, 0, 0>(a, stream);
+    if (a.ups) return tr ? launch_c<BM, BN, 2, 1>(a, stream) : launch_c<BM, BN, 2, 0>(a, stream);
+    return tr ? launch_c<BM, BN, 1, 1>(a, stream) : launch_c<BM, BN, 1, 0>(a, stream);
 }
 
 int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
@@ -64,6 +67,12 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     if (bm == 64 && bn == 128) return launch_t<64, 128>(a, stream);
     if (bm == 128 && bn == 64) return launch_t<128, 64>(a, stream);
     if (bm == 128 && bn == 128) return launch_t<128, 128>(a, stream);
+    if (bm == 256 && bn == 128) {     // 8 wavefronts (4x2), 96 KiB LDS: half the weight staging per FLOP
+        const bool tr = a.epi != EPI_F32;
+        if (!a.conv) return tr ? launch_c<256, 128, 0, 1, 4, 2>(a, stream) : launch_c<256, 128, 0, 0, 4, 2>(a, stream);
+        if (a.ups) return tr ? launch_c<256, 128, 2, 1, 4, 2>(a, stream) : launch_c<256, 128, 2, 0, 4, 2>(a, stream);
+        return tr ? launch_c<256, 128, 1, 1, 4, 2>(a, stream) : launch_c<256, 128, 1, 0, 4, 2>(a, stream);
+    }
     return rq_fail(RQAMD_ERR_INVALID, "gemm: no tile %dx%d", bm, bn);
 }
 
@@ -79,6 +88,11 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
         maxsplit = (K / 64) / 8;
         if (maxsplit > 8) maxsplit = 8;
         if (maxsplit < 1) maxsplit = 1;
+    }
+    // the 8-wave 256x128 tile (half the weight staging per FLOP) pays off only with plenty of tiles and no split
+    if (M >= 2048 && cdiv(N, 128) % 8 == 0 && cdiv(M, 256) * cdiv(N, 128) >= 192) {
+        *bm = 256; *bn = 128; *splitk = 1;
+        return;
     }
     int pick = 3;
     for (int c = 0; c < 4; ++c) {
