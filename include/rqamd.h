@@ -148,6 +148,14 @@ int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const v
                         int Cin, int Cout, int ksize, int stride, int ups, void* out, int bm, int bn, int flags,
                         void* stream);
 
+/* One launch of the halo-reuse 3x3 / stride-1 conv used for the high-resolution decoder/encoder layers
+ * (csrc/conv_halo.hip): x NHWC bf16 [B][H][W][Cin], w bf16 [Cout][3][3][Cin], out NHWC bf16; gn = NULL or fp32
+ * [B][Cin][2] (scale, shift): the input is then read as silu(x*scale + shift), i.e. GroupNorm+SiLU fused into the
+ * staging (ResnetBlock norm -> swish -> conv, layers.py:100-120).  Needs H % 8 == 0, W % 32 == 0, H >= 64,
+ * Cin % 64 == 0, Cout % 128 == 0. */
+int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
+                             int B, int H, int W, int Cin, int Cout, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

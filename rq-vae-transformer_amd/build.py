@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'librqamd.so')
-SOURCES = ['api.hip', 'gemm.hip', 'quantize.hip', 'rqt_kernels.hip', 'engine_rqt.hip', 'vae_kernels.hip', 'engine_vae.hip']
+SOURCES = ['api.hip', 'gemm.hip', 'quantize.hip', 'rqt_kernels.hip', 'engine_rqt.hip', 'vae_kernels.hip', 'conv_halo.hip', 'engine_vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-I', CSRC]
 
 

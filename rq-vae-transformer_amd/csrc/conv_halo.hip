@@ -1,0 +1,303 @@
+// conv_halo.hip -- 3x3 / stride 1 / pad 1 convolution for the high-resolution RQ-VAE layers (gfx950).
+//
+// Same arithmetic as the implicit-GEMM conv of gemm.h (bf16 MFMA, fp32 accumulate, bias / residual
+// epilogue), different data movement.  The implicit GEMM re-gathers the activation tile once per tap
+// (9x) and needs a separate GroupNorm-apply pass in front of it.  Here a workgroup owns an 8 x 32 pixel
+// output tile (256 GEMM rows) x 128 output channels and, per 64-channel chunk of the input:
+//   * stages the (8+2) x (32+2) HALO patch once (43.5 KB) and reuses it for all 9 taps -- 3.0x less
+//     activation staging than 9 separate gathers (ablation in DESIGN.md: staging, not MFMA, bounds the conv);
+//   * applies GroupNorm (per image/channel scale+shift prepared from the statistics) and SiLU while the
+//     patch goes from registers to LDS, i.e. once per element, so ResnetBlock's norm -> swish -> conv
+//     (rqvae/models/rqvae/layers.py:100-120 of the reference) needs no normalised copy of the activation in HBM;
+//   * streams the 9 weight tiles W[cout][tap][chunk] (16 KB each) through a double buffer.
+// Zero padding is applied AFTER normalisation (F.conv2d pads the normalised tensor), so out-of-image halo
+// pixels are stored as zeros.  Fragment reads address the patch at (ty+ky, tx+kx): a per-tap constant
+// shift of the pixel index, XOR-swizzled like gemm.h's tiles (conflict-free ds_read_b128).
+// 8 wavefronts (4 x 2), wave tile 64 pixels x 64 channels, transposed accumulators and the packed-bf16
+// LDS epilogue of gemm.h.  Used when H % 8 == 0, W % 32 == 0, Cin % 64 == 0, Cout % 128 == 0.
+#include "gemm.h"
+#include "rq_common.h"
+#include "vae_kernels.h"
+
+struct ConvHaloArgs {
+    const bf16_t* x;        // NHWC [B][H][W][Cin] raw (pre-norm) activation, or already-activated when gn == null
+    const bf16_t* w;        // [Cout][3][3][Cin]
+    const float* bias;      // [Cout]
+    const float* gn;        // [B][Cin][2] (scale, shift) or null: y = silu(x*scale + shift) applied on staging
+    const bf16_t* resid;    // NHWC [B][H][W][Cout] or null
+    bf16_t* out;            // NHWC [B][H][W][Cout]
+    int B, H, W, Cin, Cout;
+};
+
+constexpr int HT_H = 8, HT_W = 32;                 // output tile
+constexpr int HP_W = HT_W + 2, HP_N = (HT_H + 2) * HP_W;   // halo patch: 34 x 10 = 340 pixels
+constexpr int H_BN = 128;
+constexpr int H_NTH = 512;
+constexpr int HALO_BYTES = HP_N * 128;             // one 64-channel chunk of the patch (bf16)
+constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
+constexpr int H_IT = (HP_N * 8 + H_NTH - 1) / H_NTH;        // 16-byte chunks of the patch per thread (6)
+
+static __device__ __forceinline__ unsigned halo_lds_off(int hp, int c8) {
+    return (unsigned)(hp * 128 + ((c8 ^ ((hp >> 1) & 7)) << 4));
+}
+
+template <int FUSE_GN>
+__global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    RQ_DYN_SMEM(smem);
+    char* sH = (char*)smem;                        // [2][HALO_BYTES]
+    char* sW = sH + 2 * HALO_BYTES;                // [2][HW_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 wavefronts: rows (tile y pairs) x cout halves
+
+    // ---- tile decode: contiguous band of tiles per XCD (neighbouring tiles share halo rows in that L2)
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / HT_H, NT = p.Cout / H_BN;
+    const int n_mt = p.B * tiles_y * tiles_x;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int per = (n_mt + 7) >> 3;
+    const int mtile = xcd * per + slot / NT;
+    const int nt = slot - (slot / NT) * NT;
+    if (slot >= per * NT || mtile >= n_mt) return;
+    const int img = mtile / (tiles_y * tiles_x);
+    const int trem = mtile - img * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * HT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+    const int n0 = nt * H_BN;
+
+    // ---- halo staging bookkeeping (loop-invariant): byte offsets from x, validity, LDS offsets
+    unsigned h_goff[H_IT], h_loff[H_IT];
+    bool h_in[H_IT], h_ok[H_IT];
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) {
+        const int q = tid + H_NTH * it;
+        const int hp = q >> 3, c8 = q & 7;
+        h_in[it] = hp < HP_N;
+        const int hy = hp / HP_W, hx = hp - hy * HP_W;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        h_ok[it] = h_in[it] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+        h_goff[it] = (unsigned)((((long)img * p.H + cy) * p.W + cx) * p.Cin + c8 * 8) * 2u;   // clamped: always readable
+        h_loff[it] = halo_lds_off(h_in[it] ? hp : 0, c8);
+    }
+    // weight staging: 128 rows x 8 chunks = 1024 chunks, 2 per thread
+    const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row and w_row + 64
+    unsigned w_goff[2], w_loff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = w_row + 64 * i;
+        w_goff[i] = (unsigned)(((long)(n0 + r) * 9 * p.Cin + w_c8 * 8) * 2);
+        w_loff[i] = (unsigned)(r * 128 + ((w_c8 ^ ((r >> 1) & 7)) << 4));
+    }
+    const char* gX = (const char*)p.x;
+    const char* gWt = (const char*)p.w;
+    const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
+
+    auto load_halo = [&](int c, rq_u128* rh) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff[it] + (unsigned)c * 128u));
+    };
+    auto store_halo = [&](int c, int buf, rq_u128* rh) {
+        char* dst = sH + buf * HALO_BYTES;
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            if (!h_in[it]) continue;
+            rq_u128 v = rh[it];
+            if (FUSE_GN) {
+                // 8 channels c*64 + c8*8 .. +7 of this image: y = silu(x * scale + shift)
+                const int ch = c * 64 + ((tid + H_NTH * it) & 7) * 8;
+                float f[8];
+                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x4 ss = *(const f32x4*)(gn + (ch + e) * 2);      // (scale, shift) x 2 channels
+                    float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
+                    f[e] = a / (1.0f + __expf(-a));
+                    f[e + 1] = b / (1.0f + __expf(-b));
+                }
+                v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+                v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+            }
+            if (!h_ok[it]) v = zero128();          // zero padding of the (normalised) input
+            st128(dst + h_loff[it], v);
+        }
+    };
+    auto load_w = [&](int c, int tap, rq_u128* rw) {
+        const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
+        rw[0] = ld128(gWt + (w_goff[0] + kb));
+        rw[1] = ld128(gWt + (w_goff[1] + kb));
+    };
+    auto store_w = [&](int buf, const rq_u128* rw) {
+        st128(sW + buf * HW_BYTES + w_loff[0], rw[0]);
+        st128(sW + buf * HW_BYTES + w_loff[1], rw[1]);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ftx = lane & 31, fk = lane >> 5;
+    // weight fragment addresses (as gemm.h): row = wn*64 + j*32 + ftx
+    unsigned rd_w[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd_w[ks] = (unsigned)((wn * 64 + ftx) * 128 + (((ks * 2 + fk) ^ ((ftx >> 1) & 7)) << 4));
+
+    auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
+        const char* hb = sH + hbuf * HALO_BYTES;
+        const char* wb = sW + wbuf * HW_BYTES;
+        // this lane's patch pixel for fragment i: tile row wm*2+i shifted by the tap
+        int hp[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) hp[i] = (wm * 2 + i + ky) * HP_W + ftx + kx;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + halo_lds_off(hp[i], ks * 2 + fk)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + rd_w[ks] + j * (32 * 128)));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);   // transposed tile
+        }
+    };
+
+    // ---- main loop over (64-channel chunk, tap); weights double-buffered per tap, halo per chunk
+    const int NC = p.Cin / 64;
+    rq_u128 rh[H_IT], rw[2];
+    load_halo(0, rh);
+    load_w(0, 0, rw);
+    store_halo(0, 0, rh);
+    store_w(0, rw);
+    rq_syncthreads();
+    int wbuf = 0;
+    for (int c = 0; c < NC; ++c) {
+        const int hbuf = c & 1;
+        const bool more_c = c + 1 < NC;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            // prefetch: next weight tile every tap; next chunk's halo patch once, a few taps ahead
+            if (tap < 8) load_w(c, tap + 1, rw);
+            else load_w(more_c ? c + 1 : c, 0, rw);          // last tap of the last chunk: harmless reload
+            if (tap == 4) load_halo(more_c ? c + 1 : c, rh);
+            rq_sched_barrier();
+            compute(hbuf, wbuf, ky, kx);
+            store_w(wbuf ^ 1, rw);
+            if (tap == 8) store_halo(more_c ? c + 1 : c, hbuf ^ 1, rh);
+            rq_syncthreads();
+            wbuf ^= 1;
+        }
+    }
+
+    // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
+    constexpr int LDR = H_BN * 2 + 16;
+    static_assert(256 * LDR <= 2 * HALO_BYTES + 2 * HW_BYTES, "epilogue tile must fit");
+    char* sT = (char*)smem;
+    // (the loop ended with a barrier: all waves are done with the operand buffers)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ty = wm * 2 + i, tx = lane & 31;
+        const int ml = ty * HT_W + tx;
+        const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+                const int n = n0 + nl;
+                const f32x4 bv = *(const f32x4*)(p.bias + n);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
+                if (p.resid) {
+                    const uint32_t* rp = (const uint32_t*)(p.resid + pix * p.Cout + n);
+                    const uint32_t r0 = rp[0], r1 = rp[1];
+                    v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                    v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                }
+                struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
+                w2.a = pack_bf16x2(v[0], v[1]);
+                w2.b = pack_bf16x2(v[2], v[3]);
+                *(u64*)(sT + ml * LDR + nl * 2) = w2;
+            }
+        }
+    }
+    rq_syncthreads();
+    constexpr int CPR = H_BN / 8;
+#pragma unroll 4
+    for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
+        const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+        const int ty = ml / HT_W, tx = ml - ty * HT_W;
+        const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+        st128(p.out + pix * p.Cout + n0 + nl, ld128(sT + ml * LDR + nl * 2));
+    }
+}
+
+// (scale, shift) per (image, channel) from the GroupNorm partial statistics of gn_stats_kernel
+__global__ void gn_params_kernel(const float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
+                                 int nchunk, float eps) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * C) return;
+    const int b = gid / C, ch = gid - b * C, g = ch / (C / 32);
+    float a = 0.f, q = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* o = part + (((long)b * nchunk + c) * 32 + g) * 2;
+        a += o[0];
+        q += o[1];
+    }
+    const float n = (float)HW * (float)(C / 32);
+    const float mean = a / n;
+    float var = q / n - mean * mean;
+    if (var < 0.f) var = 0.f;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = rstd * gamma[ch];
+    gn[(long)gid * 2] = sc;
+    gn[(long)gid * 2 + 1] = beta[ch] - mean * sc;
+}
+
+bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
+    return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64;
+}
+
+int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
+                        int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+    if (!rq_conv_halo_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: shape %dx%d %d->%d", H, W, Cin, Cout);
+    if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
+    ConvHaloArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    const size_t smem = 2 * HALO_BYTES + 2 * HW_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    const int n_mt = B * (H / HT_H) * (W / HT_W), NT = Cout / H_BN;
+    const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
+    if (gn) RQ_LAUNCH(conv3x3_halo_kernel<1>, dim3(nblocks), dim3(H_NTH), smem, s, a);
+    else RQ_LAUNCH(conv3x3_halo_kernel<0>, dim3(nblocks), dim3(H_NTH), smem, s, a);
+    return rq_check_launch("conv3x3_halo_kernel");
+}
+
+int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
+                        hipStream_t s) {
+    int nchunk = 0;
+    RQ_TRY(rq_launch_gn_stats(x, part, B, HW, C, &nchunk, s));
+    const int n = B * C;
+    RQ_LAUNCH(gn_params_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, gamma, beta, gn, B, HW, C, nchunk, 1e-6f);
+    return rq_check_launch("gn_params_kernel");
+}
+
+// diagnostics entry (include/rqamd.h)
+extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
+                                        int B, int H, int W, int Cin, int Cout, void* out, void* stream) {
+    if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
+    return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, B, H, W, Cin, Cout,
+                               (hipStream_t)stream);
+}

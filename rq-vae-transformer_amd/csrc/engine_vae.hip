@@ -28,6 +28,7 @@ struct rqamd_vae {
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
+    bool no_halo = false;
     std::string missing;
 };
 
@@ -48,6 +49,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     rqamd_vae* h = new rqamd_vae();
     h->cfg = *c;
     if (const char* e = getenv("RQAMD_VAE_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 1024) h->chunk_max = v; }
+    h->no_halo = getenv("RQAMD_NO_HALO") != nullptr;      // A/B switch (diagnostics)
     *out = h;
     return RQAMD_OK;
 }
@@ -140,6 +142,12 @@ struct VaeRun {
         if (err) return;
         int Hout = Hin, Wout = Win, pad = ks / 2;
         if (stride == 2) { Hout = Hin / 2; Wout = Win / 2; pad = 0; }      // F.pad(0,1,0,1) + conv(s2, p0), layers.py:50-54
+        // high-resolution 3x3 / stride-1 layers: halo-reuse kernel (one patch staged per 64-channel chunk, 9 taps)
+        if (ks == 3 && stride == 1 && !ups && (epi == EPI_BF16 || epi == EPI_BF16_RESID) && !h->no_halo &&
+            rq_conv_halo_supported(Hin, Win, Cin, Cout)) {
+            err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst, B, Hin, Win, Cin, Cout, st);
+            return;
+        }
         GemmArgs a{};
         a.A = src; a.W = w; a.M = B * Hout * Wout; a.N = Cout; a.K = ks * ks * Cin; a.lda = Cin;
         a.conv = (ks == 3 || stride != 1 || ups) ? 1 : 0;

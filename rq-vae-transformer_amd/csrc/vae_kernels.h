@@ -10,3 +10,10 @@ int rq_launch_vae_attn(const bf16_t* qkv, bf16_t* out, int B, int T, int C, hipS
 int rq_launch_conv_in3(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);
 int rq_launch_conv_out3(const bf16_t* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);
 int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int kw, int mode, hipStream_t s);
+int rq_launch_gn_stats(const bf16_t* x, float* part, int B, int HW, int C, int* nchunk_out, hipStream_t s);
+// conv_halo.hip: halo-reuse 3x3 conv with optional fused GroupNorm+SiLU on the input
+bool rq_conv_halo_supported(int H, int W, int Cin, int Cout);
+int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
+                        int B, int H, int W, int Cin, int Cout, hipStream_t s);
+int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
+                        hipStream_t s);

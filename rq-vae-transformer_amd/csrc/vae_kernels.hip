@@ -116,15 +116,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, const fl
     }
 }
 
-int rq_launch_groupnorm(const bf16_t* x, bf16_t* y, float* part, const float* gamma, const float* beta, int B, int HW, int C,
-                        int silu, hipStream_t s) {
+int rq_launch_gn_stats(const bf16_t* x, float* part, int B, int HW, int C, int* nchunk_out, hipStream_t s) {
     if (C % 32 != 0 || C % 8 != 0 || 256 % (C / 8) != 0 || C > 2048)
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "groupnorm: channels %d unsupported (need 64,128,256,512,1024,2048)", C);
     int nchunk = HW / 64;
     if (nchunk < 1) nchunk = 1;
     if (nchunk > RQ_GN_MAX_CHUNK) nchunk = RQ_GN_MAX_CHUNK;
     RQ_LAUNCH(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, x, part, HW, C, nchunk);
-    RQ_TRY(rq_check_launch("gn_stats_kernel"));
+    *nchunk_out = nchunk;
+    return rq_check_launch("gn_stats_kernel");
+}
+
+int rq_launch_groupnorm(const bf16_t* x, bf16_t* y, float* part, const float* gamma, const float* beta, int B, int HW, int C,
+                        int silu, hipStream_t s) {
+    int nchunk = 0;
+    RQ_TRY(rq_launch_gn_stats(x, part, B, HW, C, &nchunk, s));
     long nvec = (long)HW * C / 8;
     int nblk = (int)((nvec + 1023) / 1024);
     if (nblk < 1) nblk = 1;

@@ -178,3 +178,28 @@ def test_emu_vae_tiny(nat, golden):
     err = np.abs(z_e - g['z_e'])
     print('emu vae tiny encode: max err %.4f mean %.5f (|ref| max %.3f)' % (err.max(), err.mean(), np.abs(g['z_e']).max()))
     assert err.max() < 0.05 and err.mean() < 0.008
+
+
+def test_emu_conv_halo(nat):
+    """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual;
+    against the oracle's conv2d / silu on the bf16-rounded operands."""
+    from oracle.vae import conv2d, silu
+    rng = np.random.default_rng(4)
+    B, H, W, Cin, Cout = 1, 64, 64, 64, 128
+
+    def bf(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+    x = bf(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    w = bf((0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    bias = T(rng.standard_normal(Cout).astype(np.float32))
+    resid = bf(rng.standard_normal((B, H, W, Cout)).astype(np.float32))
+    gn = T(np.stack([1.0 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], -1).astype(np.float32))
+    xf, wf = x.float().numpy(), np.transpose(w.float().numpy(), (0, 3, 1, 2))
+    ref_plain = conv2d(xf, wf, bias.numpy())
+    out = nat.dbg_conv_halo(x, w, bias).float().numpy()
+    assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max()
+    xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
+    xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
+    ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
+    out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid).float().numpy()
+    assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max()
