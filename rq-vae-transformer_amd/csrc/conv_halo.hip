@@ -37,8 +37,13 @@ constexpr int HALO_BYTES = HP_N * 128;             // one 64-channel chunk of th
 constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
 constexpr int H_IT = (HP_N * 8 + H_NTH - 1) / H_NTH;        // 16-byte chunks of the patch per thread (6)
 
-static __device__ __forceinline__ unsigned halo_lds_off(int hp, int c8) {
-    return (unsigned)(hp * 128 + ((c8 ^ ((hp >> 1) & 7)) << 4));
+// LDS byte offset of 16-byte chunk c8 of patch pixel (hy, hx).  The XOR swizzle depends on the patch COLUMN
+// only, so a tap's row shift (and the fragment row i, and the double-buffer index) are plain multiples of 128
+// added to one per-kx base address -- they fold into the ds_read immediate, and the k-step is an XOR of bits
+// 5..6.  (With the swizzle on the linear pixel index every (tap, i, k-step) needed its own address register:
+// 72 of them, which pushed the kernel past 256 VGPRs and into scratch.)
+static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) {
+    return (unsigned)((hy * HP_W + hx) * 128 + ((c8 ^ ((hx >> 1) & 7)) << 4));
 }
 
 template <int FUSE_GN>
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         h_ok[it] = h_in[it] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
         h_goff[it] = (unsigned)((((long)img * p.H + cy) * p.W + cx) * p.Cin + c8 * 8) * 2u;   // clamped: always readable
-        h_loff[it] = halo_lds_off(h_in[it] ? hp : 0, c8);
+        h_loff[it] = h_in[it] ? halo_lds_off(hy, hx, c8) : 0u;
     }
     // weight staging: 128 rows x 8 chunks = 1024 chunks, 2 per thread
     const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row and w_row + 64
@@ -90,37 +95,47 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     const char* gWt = (const char*)p.w;
     const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
 
+    // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7), loaded
+    // with the patch so that no global-load latency sits between the taps
+    f32x4 gs[4];
     auto load_halo = [&](int c, rq_u128* rh) {
 #pragma unroll
         for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff[it] + (unsigned)c * 128u));
-    };
-    auto store_halo = [&](int c, int buf, rq_u128* rh) {
-        char* dst = sH + buf * HALO_BYTES;
+        if (FUSE_GN) {
 #pragma unroll
-        for (int it = 0; it < H_IT; ++it) {
-            if (!h_in[it]) continue;
-            rq_u128 v = rh[it];
-            if (FUSE_GN) {
-                // 8 channels c*64 + c8*8 .. +7 of this image: y = silu(x * scale + shift)
-                const int ch = c * 64 + ((tid + H_NTH * it) & 7) * 8;
-                float f[8];
-                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const f32x4 ss = *(const f32x4*)(gn + (ch + e) * 2);      // (scale, shift) x 2 channels
-                    float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
-                    f[e] = a / (1.0f + __expf(-a));
-                    f[e + 1] = b / (1.0f + __expf(-b));
-                }
-                v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
-                v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
-            }
-            if (!h_ok[it]) v = zero128();          // zero padding of the (normalised) input
-            st128(dst + h_loff[it], v);
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
         }
+    };
+    // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS.  The fused form is spread over
+    // the taps of a chunk (one piece per tap) so that its VALU / transcendental work issues under the MFMAs;
+    // done in one lump before the barrier it cost +73 % on the 128->128 @256^2 layer.
+    auto store_halo_piece = [&](int c, int buf, const rq_u128* rh, int it) {
+        if (!h_in[it]) return;
+        char* dst = sH + buf * HALO_BYTES;
+        rq_u128 v = rh[it];
+        if (FUSE_GN) {
+            // 8 channels c*64 + c8*8 .. +7 of this image: y = silu(x * scale + shift) = a / (1 + 2^(-a log2 e))
+            float f[8];
+            f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+            f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+            f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+            f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x4 ss = gs[e >> 1];                              // (scale, shift) x 2 channels
+                const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
+                f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
+                f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+            }
+            v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+            v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+        }
+        if (!h_ok[it]) v = zero128();              // zero padding of the (normalised) input
+        st128(dst + h_loff[it], v);
+    };
+    auto store_halo = [&](int c, int buf, const rq_u128* rh) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) store_halo_piece(c, buf, rh, it);
     };
     auto load_w = [&](int c, int tap, rq_u128* rw) {
         const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
@@ -141,25 +156,24 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int ftx = lane & 31, fk = lane >> 5;
-    // weight fragment addresses (as gemm.h): row = wn*64 + j*32 + ftx
-    unsigned rd_w[4];
+    // fragment base addresses for k-step 0: weights row = wn*64 + ftx (+32 j); patch pixel (wm*2, ftx + kx)
+    const unsigned rd_w0 = (unsigned)((wn * 64 + ftx) * 128 + ((fk ^ ((ftx >> 1) & 7)) << 4));
+    unsigned rd_h0[3];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) rd_w[ks] = (unsigned)((wn * 64 + ftx) * 128 + (((ks * 2 + fk) ^ ((ftx >> 1) & 7)) << 4));
+    for (int kx = 0; kx < 3; ++kx) rd_h0[kx] = halo_lds_off(wm * 2, ftx + kx, fk);
 
     auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
-        const char* hb = sH + hbuf * HALO_BYTES;
-        const char* wb = sW + wbuf * HW_BYTES;
-        // this lane's patch pixel for fragment i: tile row wm*2+i shifted by the tap
-        int hp[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) hp[i] = (wm * 2 + i + ky) * HP_W + ftx + kx;
+        const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES);
+        const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[2], bfr[2];
+            const char* hb = sH + (ha ^ (unsigned)(ks << 5));
+            const char* wb = sW + (wa ^ (unsigned)(ks << 5));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + halo_lds_off(hp[i], ks * 2 + fk)));
+            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + (i + ky) * (HP_W * 128)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + rd_w[ks] + j * (32 * 128)));
+            for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -185,11 +199,16 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             // prefetch: next weight tile every tap; next chunk's halo patch once, a few taps ahead
             if (tap < 8) load_w(c, tap + 1, rw);
             else load_w(more_c ? c + 1 : c, 0, rw);          // last tap of the last chunk: harmless reload
-            if (tap == 4) load_halo(more_c ? c + 1 : c, rh);
+            if (tap == 0) load_halo(more_c ? c + 1 : c, rh);
             rq_sched_barrier();
+            // next chunk's patch: pieces 0..5 in taps 3..8 (the loads were issued three taps earlier).  With the
+            // fused GroupNorm the two wavefronts that share a SIMD (w and w+4) do their piece on opposite sides
+            // of the MFMA block, so one's VALU/transcendental work runs under the other's MFMAs.
+            const bool piece = tap >= 9 - H_IT;
+            if (FUSE_GN && piece && wave < 4) { store_halo_piece(more_c ? c + 1 : c, hbuf ^ 1, rh, tap - (9 - H_IT)); rq_sched_barrier(); }
             compute(hbuf, wbuf, ky, kx);
             store_w(wbuf ^ 1, rw);
-            if (tap == 8) store_halo(more_c ? c + 1 : c, hbuf ^ 1, rh);
+            if (piece && !(FUSE_GN && wave < 4)) { rq_sched_barrier(); store_halo_piece(more_c ? c + 1 : c, hbuf ^ 1, rh, tap - (9 - H_IT)); }
             rq_syncthreads();
             wbuf ^= 1;
         }

@@ -23,12 +23,12 @@
 struct rqamd_vae {
     rqamd_vae_config cfg;
     std::map<std::string, std::unique_ptr<DevBuf>> params;
-    DevBuf ws, part;
+    DevBuf ws, part, gnp;      // gnp: [chunk][C][2] GroupNorm (scale, shift) for the fused norm->swish->conv
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
-    bool no_halo = false;
+    bool no_halo = false, no_fuse_gn = false;
     std::string missing;
 };
 
@@ -49,7 +49,8 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     rqamd_vae* h = new rqamd_vae();
     h->cfg = *c;
     if (const char* e = getenv("RQAMD_VAE_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 1024) h->chunk_max = v; }
-    h->no_halo = getenv("RQAMD_NO_HALO") != nullptr;      // A/B switch (diagnostics)
+    h->no_halo = getenv("RQAMD_NO_HALO") != nullptr;      // A/B switches (diagnostics)
+    h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
     *out = h;
     return RQAMD_OK;
 }
@@ -165,17 +166,35 @@ struct VaeRun {
         if (err) return;
         err = rq_launch_groupnorm(src, dst, h->part.as<float>(), g, b, B, HW, C, silu, st);
     }
+    // GroupNorm -> swish -> 3x3 conv (layers.py:104-106,112-115).  On the high-resolution layers the normalisation is
+    // applied inside the halo conv while it stages the patch (no normalised copy of the activation in HBM: only
+    // the statistics pass reads the tensor); elsewhere norm() writes tmp and the implicit-GEMM conv reads it.
+    void norm_conv(const std::string& nname, const std::string& cname, const bf16_t* src, bf16_t* tmp, bf16_t* dst, int H, int W,
+                   int Cin, int Cout, int epi, const bf16_t* resid) {
+        if (err) return;
+        if (!h->no_halo && !h->no_fuse_gn && rq_conv_halo_supported(H, W, Cin, Cout)) {
+            const float* g = (const float*)P(nname + ".weight");
+            const float* be = (const float*)P(nname + ".bias");
+            const bf16_t* w = (const bf16_t*)P(cname + ".weight");
+            const float* b = (const float*)P(cname + ".bias");
+            if (err) return;
+            err = rq_launch_gn_params(src, h->part.as<float>(), g, be, h->gnp.as<float>(), B, H * W, Cin, st);
+            if (err) return;
+            err = rq_launch_conv_halo(src, w, b, h->gnp.as<float>(), epi == EPI_BF16_RESID ? resid : nullptr, dst, B, H, W, Cin, Cout, st);
+            return;
+        }
+        norm(nname, src, tmp, H * W, Cin, 1);
+        conv(cname, tmp, dst, H, W, Cin, Cout, 3, 1, 0, epi, resid);
+    }
     // ResnetBlock._forward (layers.py:100-120): X -> Y, then swap
     void res(const std::string& name, int H, int W, int Cin, int Cout) {
-        norm(name + ".norm1", X, T1, H * W, Cin, 1);
-        conv(name + ".conv1", T1, T2, H, W, Cin, Cout, 3, 1, 0, EPI_BF16, nullptr);
-        norm(name + ".norm2", T2, T1, H * W, Cout, 1);
+        norm_conv(name + ".norm1", name + ".conv1", X, T1, T2, H, W, Cin, Cout, EPI_BF16, nullptr);
         const bf16_t* sc = X;
         if (Cin != Cout) {
             conv(name + ".nin_shortcut", X, T3, H, W, Cin, Cout, 1, 1, 0, EPI_BF16, nullptr);
             sc = T3;
         }
-        conv(name + ".conv2", T1, Y, H, W, Cout, Cout, 3, 1, 0, EPI_BF16_RESID, sc);
+        norm_conv(name + ".norm2", name + ".conv2", T2, T1, Y, H, W, Cout, Cout, EPI_BF16_RESID, sc);
         swap();
     }
     // AttnBlock.forward (layers.py:158-182): X -> Y, then swap
@@ -210,6 +229,7 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
     RQ_TRY(h->ws.reserve(bytes * 5));
     for (int i = 0; i < 5; ++i) h->buf[i] = (bf16_t*)((char*)h->ws.p + bytes * i);
     RQ_TRY(h->part.reserve((size_t)chunk * RQ_GN_MAX_CHUNK * 32 * 2 * 4));
+    RQ_TRY(h->gnp.reserve((size_t)chunk * 2048 * 2 * 4));
     h->cap_elems = elems;
     h->chunk = chunk;
     return RQAMD_OK;

@@ -38,6 +38,8 @@ for B, H, Cin, Cout in ((2, 64, 128, 128), (8, 256, 128, 128), (8, 128, 128, 128
     t_g = bench(lambda: _native.dbg_conv(x, w, bias, None, 3, 1, 0, 0, 0, 0, out=out))
     t_h = bench(lambda: _native.dbg_conv_halo(x, w, bias, out=out))
     t_hg = bench(lambda: _native.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, out=out))
+    t_hr = bench(lambda: _native.dbg_conv_halo(x, w, bias, resid=resid, out=out))
+    t_hn = bench(lambda: _native.dbg_conv_halo(x, w, bias, gn=gn, out=out))
     t_gr = bench(lambda: _native.dbg_conv(x, w, bias, resid, 3, 1, 0, 0, 0, 0, out=out))
     print(f'B{B} {Cin}->{Cout}@{H}: err plain {e1:.1e} fused {e2:.1e} | implicit-GEMM {t_g:7.1f} us {fl / t_g:6.1f} TF (+resid {t_gr:7.1f}) | '
-          f'halo {t_h:7.1f} us {fl / t_h:6.1f} TF | halo+GN+SiLU+resid {t_hg:7.1f} us {fl / t_hg:6.1f} TF', flush=True)
+          f'halo {t_h:7.1f} us {fl / t_h:6.1f} TF | halo+GN+SiLU+resid {t_hg:7.1f} us {fl / t_hg:6.1f} TF | halo+resid {t_hr:7.1f} | halo+GN {t_hn:7.1f}', flush=True)

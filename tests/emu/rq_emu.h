@@ -119,6 +119,8 @@ typedef short bf16x8_emu __attribute__((ext_vector_type(8)));
 static inline void rq_syncthreads() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)
+static inline float rq_fast_rcp(float x) { return 1.0f / x; }
+static inline float rq_fast_exp2(float x) { return exp2f(x); }
 
 static inline float rq_emu_bf16(short v) {
     union { uint32_t u; float f; } c;
