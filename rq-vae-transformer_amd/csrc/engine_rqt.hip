@@ -61,7 +61,9 @@ struct rqamd_rqt {
     int max_slabs = 8;
 
     // graph cache
-    hipGraphExec_t gexec = nullptr;
+    // one captured position per 8-key bucket of the body context (the attention kernel variant is baked in)
+    static constexpr int NGRAPH = 33;
+    hipGraphExec_t gexec[NGRAPH] = {};
     struct Key { int B; float T; int tk[8]; float tp[8]; const float* cb[8]; void* stream; } gkey;
     bool gvalid = false;
 
@@ -131,7 +133,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
 
 extern "C" int rqamd_rqt_destroy(rqamd_rqt* h) {
     if (!h) return RQAMD_OK;
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    for (auto& g : h->gexec) if (g) (void)hipGraphExecDestroy(g);
     for (auto e : h->prof.ev) (void)hipEventDestroy(e);
     delete h;
     return RQAMD_OK;
@@ -295,7 +297,7 @@ struct Pending { const float* slabs; int n; const float* bias; };   // un-reduce
 // one transformer block on `rows` single-token rows; x is the fp32 residual stream (updated lazily:
 // `pend` carries the previous block's fc2 partials + bias into this block's first resid_ln)
 static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& pend, const float* addvec, int rows,
-                     const int* step, int step_off, int Tcap, hipStream_t st) {
+                     const int* step, int step_off, int t_max, int Tcap, hipStream_t st) {
     const int E = h->E;
     ResidLnArgs r{};
     r.x_in = x_in; r.x_out = x; r.slabs = pend.slabs; r.n_slabs = pend.n; r.bias = pend.bias; r.addvec = addvec;
@@ -304,7 +306,7 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
     AttnDecodeArgs at{};
     at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
-    at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
+    at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
     RQ_TRY(rq_launch_attn_decode(at, st));
     int ns = 1;
     RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st));
@@ -329,9 +331,10 @@ struct StepCtx {
 };
 
 // body stack for the token whose input is already in h->x; leaves the last fc2 un-reduced in `pend`
-static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, Pending& pend, hipStream_t st) {
+// t_max: host-side bound on the number of cached keys (selects the attention kernel's register-block count)
+static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, int t_max, Pending& pend, hipStream_t st) {
     pend = Pending{nullptr, 0, nullptr};
-    for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, step, step_off, h->Tbody, st));
+    for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, step, step_off, t_max, h->Tbody, st));
     return RQAMD_OK;
 }
 
@@ -357,7 +360,8 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         // token = sum_d input_mlp(e_d) + pos_emb_hw[pos-1]  (transformers.py:218-225)
         RQ_TRY(embed_gemm(h, c, -1, h->D, h->w_in, h->body_in_bias, -1, true, h->x, st));
     }
-    RQ_TRY(body_stack(h, B, h->st, h->cond_len - 1, pend, st));
+    // a captured graph serves every position of the same 8-key bucket: bound t by the bucket's last position
+    RQ_TRY(body_stack(h, B, h->st, h->cond_len - 1, ((host_pos + h->cond_len - 1) | 7), pend, st));
     if (!do_head) {
         // keep the residual stream consistent is unnecessary: the next position overwrites h->x
         return RQAMD_OK;
@@ -375,7 +379,7 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
             hp = Pending{nullptr, 0, nullptr};
         }
         for (size_t li = 0; li < h->head.size(); ++li) {
-            RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, h->D, st));
+            RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
         }
         ResidLnArgs r{};
         r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
@@ -410,14 +414,19 @@ static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const
         RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, i, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
                                     h->pos_cond, h->x, B, h->E, st));
         Pending pend;
-        RQ_TRY(body_stack(h, B, nullptr, i, pend, st));
+        RQ_TRY(body_stack(h, B, nullptr, i, i, pend, st));
     }
     for (int pos = 0; pos < h->HW; ++pos) {
         const bool do_head = pos >= start_idx;
         const bool graphable = use_graph && c.sample && do_head && pos >= 1 && !h->prof.on;
         if (graphable) {
             if (!h->gvalid) {
-                if (h->gexec) { (void)hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+                for (auto& g : h->gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+                h->gvalid = true;
+            }
+            int bucket = (pos + h->cond_len - 1) >> 3;
+            if (bucket >= rqamd_rqt::NGRAPH) bucket = rqamd_rqt::NGRAPH - 1;
+            if (!h->gexec[bucket]) {
                 hipGraph_t g = nullptr;
                 hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
                 if (e == hipSuccess) {
@@ -426,16 +435,15 @@ static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const
                     hipError_t e2 = hipStreamEndCapture(st, &g);
                     if (rc != RQAMD_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
                     if (e2 != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e2));
-                    e2 = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+                    e2 = hipGraphInstantiate(&h->gexec[bucket], g, nullptr, nullptr, 0);
                     (void)hipGraphDestroy(g);
                     if (e2 != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
-                    h->gvalid = true;
                 } else {
                     use_graph = false;    // capture unavailable: fall through to eager launches
                 }
             }
-            if (h->gvalid) {
-                RQ_HIP(hipGraphLaunch(h->gexec, st));
+            if (h->gexec[bucket]) {
+                RQ_HIP(hipGraphLaunch(h->gexec[bucket], st));
                 continue;
             }
         }

@@ -73,6 +73,14 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         if (a.ups) return tr ? launch_c<256, 128, 2, 1, 4, 2>(a, stream) : launch_c<256, 128, 2, 0, 4, 2>(a, stream);
         return tr ? launch_c<256, 128, 1, 1, 4, 2>(a, stream) : launch_c<256, 128, 1, 0, 4, 2>(a, stream);
     }
+    // register-blocked variants (dense operands only): wave tile 128x64 -> 0.75 KB of LDS fragment reads per
+    // MFMA instead of 1 KB (the 64x64 wave tile saturates the LDS read port at ~50 % MFMA rate)
+    if (bm == 257 && bn == 128 && !a.conv) {   // 256x128, 4 wavefronts (2x2)
+        return a.epi != EPI_F32 ? launch_c<256, 128, 0, 1, 2, 2>(a, stream) : launch_c<256, 128, 0, 0, 2, 2>(a, stream);
+    }
+    if (bm == 129 && bn == 128 && !a.conv) {   // 128x128, 2 wavefronts (1x2)
+        return a.epi != EPI_F32 ? launch_c<128, 128, 0, 1, 1, 2>(a, stream) : launch_c<128, 128, 0, 0, 1, 2>(a, stream);
+    }
     return rq_fail(RQAMD_ERR_INVALID, "gemm: no tile %dx%d", bm, bn);
 }
 

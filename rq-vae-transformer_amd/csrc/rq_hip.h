@@ -63,6 +63,9 @@ static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)
 #define rq_setprio(x) __builtin_amdgcn_s_setprio(x)
 // single-instruction reciprocal / exp2 (v_rcp_f32 / v_exp_f32, ~1 ulp): used where the result is rounded to bf16
+// wave-uniform value -> SGPR (lets address arithmetic derived from it run on the scalar unit)
+static __device__ __forceinline__ int rq_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define RQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]

@@ -30,11 +30,12 @@ struct ResidLnArgs {
 
 struct AttnDecodeArgs {
     const bf16_t* qkv;      // [rows][3E]: q | k | v, head h at columns h*64..h*64+63 of each third
-    bf16_t* kc;             // K cache [rows][nh][8][Tcap][8]   (chunk-major: coalesced per-key reads)
+    bf16_t* kc;             // K cache [rows][nh][Tcap][64]
     bf16_t* vc;             // V cache [rows][nh][Tcap][64]
     bf16_t* y;              // [rows][E]
     const int* step;        // device-side step counter (or null)
     int step_off;           // t = *step + step_off = number of cached keys before this token
+    int t_max;              // host-side upper bound of t for this launch (selects the register-block count), -1 = Tcap-1
     int rows, nh, E, Tcap;
 };
 

@@ -93,7 +93,8 @@ int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s) {
 }
 
 // =================================================================================================
-// KV-cache decode attention: one wavefront per (row, head), head_dim 64, up to NB*64 keys
+// KV-cache decode attention (attentions.py:60-105 of the reference, cached branch): one wavefront per (row, head),
+// head_dim 64, up to NB*64 keys
 static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
     f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
     f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
@@ -101,79 +102,94 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
     f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
-template <int NB>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long pair = (long)blockIdx.x * 4 + wave;
-    if (pair >= (long)p.rows * p.nh) return;                       // whole wave exits together
+// Lane (g = lane >> 3, cc = lane & 7) owns 16-byte chunk cc of key / value row jj*8 + g of every 8-row block jj,
+// for K and V alike (both caches are [row][head][Tcap][64]): a block is one 1 KB contiguous wavefront load, the
+// number of load instructions follows the context length (2 * ceil((t+1)/8) + 2, not a fixed 25), the partial
+// dot products are reduced over the 8 lanes of a group, and the softmax weight of a key already sits in the
+// lanes that hold its value row.  Every launch at B=4096 issues 98 304 wavefronts; a 16-byte-per-lane load
+// occupies the CU's address path for 16 cycles whatever the lanes address, which made the previous
+// one-key-per-lane mapping cost ~100 us per launch even at t = 0 (profiles/r01_attn_trace.txt).
+// NJ = number of 8-key blocks held in registers; DYN = skip blocks >= nblk at run time (long contexts).
+template <int NJ, bool DYN>
+static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, long pair, int t) {
     const int b = (int)(pair / p.nh), h = (int)(pair - (long)b * p.nh);
-    const int t = (p.step ? *p.step : 0) + p.step_off;
     const int E = p.E, Tcap = p.Tcap;
     const bf16_t* qrow = p.qkv + (long)b * 3 * E + h * 64;
     const bf16_t* krow = qrow + E;
     const bf16_t* vrow = qrow + 2 * E;
-    bf16_t* kc = p.kc + pair * 8 * Tcap * 8;
+    bf16_t* kc = p.kc + pair * Tcap * 64;
     bf16_t* vc = p.vc + pair * Tcap * 64;
+    const int cc = lane & 7, g = lane >> 3;
+    const int nblk = (t >> 3) + 1;
+    const int tprev = t > 0 ? t - 1 : 0;
+    const float NEG_INF = -__int_as_float(0x7f800000);
 
-    // append this token's k / v (the current key is always read back from qkv, never from the cache)
-    if (lane < 8) st128(kc + ((long)lane * Tcap + t) * 8, ld128(krow + lane * 8));
-    else if (lane < 16) st128(vc + (long)t * 64 + (lane - 8) * 8, ld128(vrow + (lane - 8) * 8));
-
-    float q[64];
+    // every global load is issued before the first use (q, this token's k|v, all K and V blocks); rows j >= t
+    // read this token's k / v straight from qkv (the cache row is written by this launch), clamped, unmasked
+    const rq_u128 qv = ld128(qrow + cc * 8);
+    const rq_u128 kv_new = ld128((lane < 8 ? krow : vrow) + cc * 8);
+    rq_u128 kr[NJ], vr[NJ];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) unpack8(ld128(qrow + c * 8), q + c * 8);
-
-    float sc[NB];
-    float mx = -__int_as_float(0x7f800000);
+    for (int jj = 0; jj < NJ; ++jj) {
+        if (DYN && jj >= nblk) continue;
+        const int j = jj * 8 + g;
+        const long off = (long)(j < t ? j : tprev) * 64 + cc * 8;
+        kr[jj] = ld128((j >= t) ? (krow + cc * 8) : (kc + off));
+    }
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int j = nb * 64 + lane;
-        float s = -__int_as_float(0x7f800000);
-        if (j <= t) {
+    for (int jj = 0; jj < NJ; ++jj) {
+        if (DYN && jj >= nblk) continue;
+        const int j = jj * 8 + g;
+        const long off = (long)(j < t ? j : tprev) * 64 + cc * 8;
+        vr[jj] = ld128((j >= t) ? (vrow + cc * 8) : (vc + off));
+    }
+    if (lane < 8) st128(kc + (long)t * 64 + cc * 8, kv_new);
+    else if (lane < 16) st128(vc + (long)t * 64 + cc * 8, kv_new);
+
+    float qf[8];
+    unpack8(qv, qf);
+    float sc[NJ];
+    float mx = NEG_INF;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        float s = NEG_INF;
+        if (!DYN || jj < nblk) {
+            float kf[8];
+            unpack8(kr[jj], kf);
             float dot = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const bf16_t* src = (j == t) ? (krow + c * 8) : (kc + ((long)c * Tcap + j) * 8);
-                float kf[8];
-                unpack8(ld128(src), kf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dot = fmaf(q[c * 8 + e], kf[e], dot);
-            }
-            s = dot * 0.125f;                                       // 1/sqrt(64), attentions.py:87
+            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+            dot += rq_shfl_xor(dot, 1);
+            dot += rq_shfl_xor(dot, 2);
+            dot += rq_shfl_xor(dot, 4);
+            if (jj * 8 + g <= t) s = dot * 0.125f;                  // 1/sqrt(64), attentions.py:87
         }
-        sc[nb] = s;
+        sc[jj] = s;
         mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int j = nb * 64 + lane;
-        sc[nb] = (j <= t) ? expf(sc[nb] - mx) : 0.f;
-        sum += sc[nb];
+    for (int jj = 0; jj < NJ; ++jj) {
+        sc[jj] = (sc[jj] == NEG_INF) ? 0.f : rq_fast_exp2((sc[jj] - mx) * 1.4426950408889634f);
+        sum += sc[jj];
     }
-    sum = wave_sum(sum);
+    sum += rq_shfl_xor(sum, 8);                                     // over the key groups only: the 8 lanes of a
+    sum += rq_shfl_xor(sum, 16);                                    // group hold the same weights
+    sum += rq_shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
-    const int cc = lane & 7, g = lane >> 3;
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
+    for (int jj = 0; jj < NJ; ++jj) {
+        if (DYN && jj >= nblk) continue;
+        const float pj = sc[jj] * inv;                              // 0 for j > t
+        float vf[8];
+        unpack8(vr[jj], vf);
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int jl = jj * 8 + g;
-            const int j = nb * 64 + jl;
-            const float pj = rq_shfl(sc[nb], jl) * inv;
-            if (j <= t) {
-                const bf16_t* src = (j == t) ? (vrow + cc * 8) : (vc + (long)j * 64 + cc * 8);
-                float vf[8];
-                unpack8(ld128(src), vf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
-            }
-        }
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -189,13 +205,41 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     }
 }
 
+// One kernel per register-block count: the launch picks the smallest NJ that covers the host-known bound on t
+// (engine_rqt.hip keeps one captured graph per NJ), so short contexts and the depth transformer (t < 8) run
+// with ~40 VGPRs and 8 wavefronts per SIMD instead of inheriting the 64-key variant's register budget.
+template <int NJ, bool DYN>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = rq_uniform((int)(threadIdx.x >> 6));
+    const int h = blockIdx.x * 4 + wave;
+    if (h >= p.nh) return;                                         // whole wave exits together
+    const long pair = (long)blockIdx.y * p.nh + h;
+    const int t = (p.step ? *p.step : 0) + p.step_off;
+    if ((t >> 3) >= NJ) rq_trap();                                 // host bound violated: never drop keys silently
+    attn_run<NJ, DYN>(p, lane, pair, t);
+}
+
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
-    const long pairs = (long)a.rows * a.nh;
-    dim3 grid((unsigned)((pairs + 3) / 4));
-    if (a.Tcap <= 64) RQ_LAUNCH(attn_decode_kernel<1>, grid, dim3(256), 0, s, a);
-    else if (a.Tcap <= 128) RQ_LAUNCH(attn_decode_kernel<2>, grid, dim3(256), 0, s, a);
-    else if (a.Tcap <= 256) RQ_LAUNCH(attn_decode_kernel<4>, grid, dim3(256), 0, s, a);
+    if (a.rows > 65535) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: %d rows > 65535", a.rows);
+    const dim3 grid((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk(256);
+    const int nj_cap = (a.Tcap + 7) / 8;
+    int nj = a.t_max >= 0 ? (a.t_max >> 3) + 1 : nj_cap;
+    if (nj > nj_cap) nj = nj_cap;
+    if (a.Tcap <= 64) {
+        switch (nj) {
+            case 1: RQ_LAUNCH((attn_decode_kernel<1, false>), grid, blk, 0, s, a); break;
+            case 2: RQ_LAUNCH((attn_decode_kernel<2, false>), grid, blk, 0, s, a); break;
+            case 3: RQ_LAUNCH((attn_decode_kernel<3, false>), grid, blk, 0, s, a); break;
+            case 4: RQ_LAUNCH((attn_decode_kernel<4, false>), grid, blk, 0, s, a); break;
+            case 5: RQ_LAUNCH((attn_decode_kernel<5, false>), grid, blk, 0, s, a); break;
+            case 6: RQ_LAUNCH((attn_decode_kernel<6, false>), grid, blk, 0, s, a); break;
+            case 7: RQ_LAUNCH((attn_decode_kernel<7, false>), grid, blk, 0, s, a); break;
+            default: RQ_LAUNCH((attn_decode_kernel<8, false>), grid, blk, 0, s, a); break;
+        }
+    } else if (a.Tcap <= 128) RQ_LAUNCH((attn_decode_kernel<16, true>), grid, blk, 0, s, a);
+    else if (a.Tcap <= 256) RQ_LAUNCH((attn_decode_kernel<32, true>), grid, blk, 0, s, a);
     else return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: context %d > 256", a.Tcap);
     return rq_check_launch("attn_decode_kernel");
 }
@@ -434,7 +478,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs p) {
     // ---- top-p (utils.py:67-79): keep the sorted prefix up to and including the first token whose
     // inclusive cumulative mass reaches p.  tau = largest value v with mass{prob >= v} >= p, found by a
     // bitwise search on the (monotone) float bit pattern -- no sort, deterministic reductions.
-    if (p.top_p >= 0.f) {
+    // p >= 1 keeps every token: the reference's `cum_probs >= 1.0` can only fire through fp32 cumsum rounding
+    // (mass of a few ulp), which no reordering of the sum reproduces -- the filter is skipped.
+    if (p.top_p >= 0.f && p.top_p < 1.0f) {
         unsigned cur = 0;
         const bool in_regs = V <= SMP_T * SMP_VPT;
         float pv[SMP_VPT];
@@ -536,9 +582,69 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs p) {
     }
 }
 
+// Unfiltered draw (top_k covers the vocabulary, top_p >= 1: the reference's defaults, transformers.py:309-323):
+// softmax + multinomial collapse to one streaming pass, argmax_i (logit_i / T + Gumbel_i), with
+// Gumbel_i = -log(-log u_i) from the same Philox counters as sample_kernel -- no max / sum reductions, no
+// LDS copy of the row, so occupancy is set by registers only (the general kernel holds V floats in LDS:
+// 2 workgroups per CU, 830 us per call at 4096 x 16384; this one is bound by reading the logits once).
+__global__ __launch_bounds__(256) void sample_gumbel_kernel(SampleArgs p) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x, V = p.V, row = blockIdx.x;
+    const float* lg = p.logits + (long)row * V;
+    const float inv_t = 1.0f / p.temperature;
+    const int slot = p.pos ? (*p.pos) * p.D + p.d : 0;
+    const uint64_t seed = p.rng ? p.rng[0] : p.seed;
+    const uint64_t off = (p.rng ? p.rng[1] : p.offset) + (uint64_t)slot;
+    const float NEG_INF = -__int_as_float(0x7f800000);
+    float best = NEG_INF;
+    int besti = 0x7fffffff;
+    const bool vec = (V & 3) == 0;
+    for (int i4 = tid; i4 * 4 < V; i4 += 256) {
+        float v[4];
+        if (vec) {
+            const f32x4 q = *(const f32x4*)(lg + i4 * 4);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (i4 * 4 + e < V) ? lg[i4 * 4 + e] : NEG_INF;
+        }
+        unsigned r[4];
+        philox4x32_10((unsigned)i4, (unsigned)row, (unsigned)off, (unsigned)(off >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = i4 * 4 + e;
+            const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+            float x = v[e] * inv_t;
+            if (x != x) x = NEG_INF;                                            // NaN scrub (utils.py:103-105)
+            const float sc = x - __logf(-__logf(u));
+            if (i < V && sc > best) { best = sc; besti = i; }
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = rq_shfl_xor(best, m);
+        const int oi = rq_shfl_xor_i(besti, m);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { red[wave] = best; redi[wave] = besti; }
+    rq_syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > best || (red[w] == best && redi[w] < besti)) { best = red[w]; besti = redi[w]; }
+        if (besti >= V) besti = 0;
+        p.out[(long)row * p.out_stride + slot] = (int64_t)besti;
+    }
+}
+
 int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
     if (a.V < 1 || a.V > 36000) return rq_fail(RQAMD_ERR_UNSUPPORTED, "sampler: vocab %d not in 1..36000", a.V);
     if (!(a.temperature > 0.f)) return rq_fail(RQAMD_ERR_INVALID, "sampler: temperature must be > 0");
+    if ((a.top_k <= 0 || a.top_k >= a.V) && (a.top_p < 0.f || a.top_p >= 1.0f) && !a.probs_out && a.out) {
+        RQ_LAUNCH(sample_gumbel_kernel, dim3(a.rows), dim3(256), 0, s, a);
+        return rq_check_launch("sample_gumbel_kernel");
+    }
     const size_t smem = (size_t)a.V * 4 + 16 * 4 + 16 * 4 + 256 * 4 + 4 * 4 + 32 * 4;
     static bool attr_done = false;
     if (!attr_done) {

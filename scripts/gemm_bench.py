@@ -43,7 +43,7 @@ if __name__ == '__main__':
         for name, N, K, epi in shapes:
             best = None
             rows = []
-            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128)):
+            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128), (257, 128), (129, 128)):
                 if bm == 64 and M > 128 and bn == 64:
                     pass
                 for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):

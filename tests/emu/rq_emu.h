@@ -119,6 +119,8 @@ typedef short bf16x8_emu __attribute__((ext_vector_type(8)));
 static inline void rq_syncthreads() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)
+static inline int rq_uniform(int x) { return x; }
+static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
 static inline float rq_fast_exp2(float x) { return exp2f(x); }
 
@@ -200,6 +202,7 @@ static inline f32x16_emu rq_mfma_32x32x2_f32(float a, float b, f32x16_emu c) {
 // ---------------------------------------------------------------------------------------------
 // device math / atomics
 #define __expf expf
+#define __logf logf
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }

@@ -93,6 +93,16 @@ def test_emu_sampler_draws(nat):
     s1, _ = nat.sample_logits(T(logits), 1.0, 10, 0.9, seed=7, offset=0)
     s2, _ = nat.sample_logits(T(logits), 1.0, 10, 0.9, seed=7, offset=0)
     assert torch.equal(s1, s2)
+    # unfiltered draw (the reference's default top_k=None, top_p=None -> 1.0): single-pass Gumbel-max kernel
+    probs = oracle.filtered_probs(logits[:1], 0.8, None, None)[0]
+    counts = np.zeros(40)
+    for rep in range(6):
+        s, _ = nat.sample_logits(T(logits), 0.8, None, 1.0, seed=11, offset=rep)
+        counts += np.bincount(s.numpy(), minlength=40)
+    n = counts.sum()
+    big = probs * n >= 5
+    chi2 = (((counts - n * probs) ** 2) / (n * probs))[big].sum()
+    assert chi2 < 3.0 * big.sum() + 20.0, chi2
 
 
 def _rqt_engine(nat, cfg, params):

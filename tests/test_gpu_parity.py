@@ -137,6 +137,21 @@ def test_sampler_draws(nat):
     s2, _ = nat.sample_logits(logits, 1.0, 10, 0.9, seed=7, offset=0)
     s3, _ = nat.sample_logits(logits, 1.0, 10, 0.9, seed=7, offset=4)
     assert torch.equal(s, s2) and not torch.equal(s, s3)
+    # unfiltered draw (reference defaults top_k=None / top_p=1.0): the single-pass Gumbel-max kernel, on a real
+    # 16384-way row (V % 4 == 0, vector loads) and a ragged 1001-way row
+    for V, T_ in ((16384, 1.0), (1001, 0.7)):
+        row = (3.0 * rng.standard_normal((1, V))).astype(np.float32)
+        probs = oracle.filtered_probs(row, T_, None, None)[0].astype(np.float64)
+        n = 32768
+        lg = G(row).repeat(n, 1)
+        s, _ = nat.sample_logits(lg, T_, None, 1.0, seed=5, offset=12)
+        counts = np.bincount(N(s), minlength=V).astype(np.float64)
+        big = probs * n >= 8
+        dof = int(big.sum())
+        chi2 = (((counts - n * probs) ** 2) / (n * probs))[big].sum() + (counts[~big].sum() - n * probs[~big].sum()) ** 2 / max(n * probs[~big].sum(), 1e-9)
+        assert chi2 < dof + 6.0 * np.sqrt(2.0 * dof) + 10.0, (V, chi2, dof)
+        s2, _ = nat.sample_logits(lg, T_, V, None, seed=5, offset=12)     # top_k = V, top_p None: same path
+        assert torch.equal(s, s2)
 
 
 # ------------------------------------------------------------------------------------------------ transformer
