@@ -156,6 +156,12 @@ int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const v
 int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
                              int B, int H, int W, int Cin, int Cout, void* out, void* stream);
 
+/* One launch of the MFMA Decoder.conv_out kernel (modules.py:165-169): x NHWC bf16 [B][H][W][Cin], w fp32
+ * [Cout][3][3][Cin] (Cout <= 4), y NCHW fp32 [B][Cout][H][W]; gn as above (norm_out + swish fused into the
+ * staging).  Needs H % 4 == 0, W % 32 == 0, Cin in {64, 128, 256}. */
+int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,
+                            int Cin, int Cout, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -258,6 +258,161 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Decoder.conv_out (modules.py:165-169 of the reference): Cin -> Cout <= 4 at full resolution, writes the NCHW
+// fp32 image.  Same halo idea, but the whole problem of a tile lives in LDS at once: a 4 x 32 pixel tile's
+// (4+2) x (32+2) patch of ALL input channels (52 KB at Cin = 128) plus every tap of the (bf16) weights, so there
+// is ONE barrier and then 9 * Cin/16 back-to-back MFMAs per wavefront (one output row each).  The transposed
+// tile D[cout][pixel] = W[cout][k] * X[k][pixel] is used with a 32-row weight operand of which only rows < Cout
+// are real -- the other rows alias them and their outputs are discarded (rows of D are independent): 10x the
+// necessary MFMA work, still ~2 us per image, against 68 us for the VALU + LDS-broadcast kernel it replaces
+// (3456 LDS weight reads per pixel).  norm_out's GroupNorm + SiLU is applied while staging (gn != null).
+struct ConvOutArgs {
+    const bf16_t* x;        // NHWC [B][H][W][Cin]
+    const float* w;         // [Cout][3][3][Cin] fp32 (repacked conv_out weight)
+    const float* bias;      // [Cout]
+    const float* gn;        // [B][Cin][2] or null
+    float* y;               // NCHW fp32 [B][Cout][H][W]
+    int B, H, W, Cin, Cout;
+};
+constexpr int OT_H = 4, OP_N = (OT_H + 2) * HP_W;          // 6 x 34 = 204 patch pixels
+constexpr int O_NTH = 256;
+constexpr int O_PLANE = OP_N * 128;                        // one 64-channel plane of the patch
+
+template <int FUSE_GN>
+__global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
+    RQ_DYN_SMEM(smem);
+    const int NC = p.Cin / 64;
+    char* sH = (char*)smem;                                // [NC][O_PLANE]
+    const int wrow = 9 * p.Cin * 2 + 32;                   // padded weight row (bytes): rows land on different banks
+    char* sW = sH + NC * O_PLANE;                          // [8][wrow]: rows >= Cout are zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
+
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / OT_H;
+    const int n_mt = p.B * tiles_y * tiles_x;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int per = (n_mt + 7) >> 3;
+    const int mtile = xcd * per + slot;
+    if (slot >= per || mtile >= n_mt) return;
+    const int img = mtile / (tiles_y * tiles_x);
+    const int trem = mtile - img * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * OT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+
+    // ---- stage the patch: piece q = (pixel hp, 16-byte chunk cq of the Cin channels); cq is the same for all of a
+    // thread's pieces (256 % (Cin/8) == 0), so its 8 (scale, shift) pairs are loaded once
+    const int CPP = p.Cin / 8;                             // chunks per pixel: 8, 16 or 32
+    const int cq = tid & (CPP - 1);
+    const int n_piece = OP_N * CPP;
+    f32x4 gs[4];
+    if (FUSE_GN) {
+        const float* gn = p.gn + ((long)img * p.Cin + cq * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4);
+    }
+    const char* gX = (const char*)p.x;
+    constexpr int PIT = 4;                                 // pieces in flight per thread
+    for (int q0 = tid; q0 < n_piece; q0 += O_NTH * PIT) {
+        rq_u128 r[PIT];
+        unsigned loff[PIT];
+        bool ok[PIT], in[PIT];
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            const int q = q0 + O_NTH * k;
+            in[k] = q < n_piece;
+            const int hp = in[k] ? q / CPP : 0;
+            const int hy = hp / HP_W, hx = hp - hy * HP_W;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            ok[k] = in[k] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+            r[k] = ld128(gX + ((((long)img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);     // clamped: always readable
+            loff[k] = (unsigned)((cq >> 3) * O_PLANE) + halo_lds_off(hy, hx, cq & 7);
+        }
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            if (!in[k]) continue;
+            rq_u128 v = r[k];
+            if (FUSE_GN) {
+                float f[8];
+                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const f32x4 ss = gs[e >> 1];
+                    const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
+                    f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
+                    f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+                }
+                v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+                v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+            }
+            if (!ok[k]) v = zero128();                     // zero padding of the (normalised) input
+            st128(sH + loff[k], v);
+        }
+    }
+    // ---- weights: fp32 [Cout][9*Cin] -> bf16 rows 0..Cout-1, zero rows up to 8
+    const int KT = 9 * p.Cin;
+    for (int i = tid; i < 8 * (KT / 2); i += O_NTH) {
+        const int row = i / (KT / 2), k2 = (i - row * (KT / 2)) * 2;
+        uint32_t v = 0;
+        if (row < p.Cout) v = pack_bf16x2(p.w[(long)row * KT + k2], p.w[(long)row * KT + k2 + 1]);
+        *(uint32_t*)(sW + row * wrow + k2 * 2) = v;
+    }
+    rq_syncthreads();
+
+    // ---- 9 taps x Cin/16 MFMAs: wave = output row of the tile, lane&31 = pixel (B operand) / weight row (A operand)
+    const int ftx = lane & 31, fk = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* wl = sW + (ftx & 7) * wrow + fk * 16;
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned ha = (unsigned)(c * O_PLANE) + halo_lds_off(wave + ky, ftx + kx, fk);
+            const char* wt = wl + (tap * p.Cin + c * 64) * 2;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 af = as_bf16x8(ld128(sH + (ha ^ (unsigned)(ks << 5))));
+                const bf16x8 wf = as_bf16x8(ld128(wt + ks * 32));
+                acc = rq_mfma_32x32x16_bf16(wf, af, acc);
+            }
+        }
+    }
+    // C/D layout: lanes 0..31 hold rows (= cout) 0..3 of column (= pixel) lane in acc[0..3]
+    if (lane < 32) {
+        const int oy = ty0 + wave, ox = tx0 + lane;
+#pragma unroll
+        for (int co = 0; co < 4; ++co)
+            if (co < p.Cout) p.y[(((long)img * p.Cout + co) * p.H + oy) * p.W + ox] = acc[co] + p.bias[co];
+    }
+}
+
+bool rq_conv_out_halo_supported(int H, int W, int Cin, int Cout) {
+    return H % OT_H == 0 && W % HT_W == 0 && (Cin == 64 || Cin == 128 || Cin == 256) && Cout >= 1 && Cout <= 4;
+}
+
+int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, const float* gn, float* y, int B, int H, int W,
+                            int Cin, int Cout, hipStream_t s) {
+    if (!rq_conv_out_halo_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_out_halo: shape %dx%d %d->%d", H, W, Cin, Cout);
+    ConvOutArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.y = y; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    const size_t smem = (size_t)(Cin / 64) * O_PLANE + 8 * (size_t)(9 * Cin * 2 + 32);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_out_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_out_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    const int n_mt = B * (H / OT_H) * (W / HT_W);
+    const int nblocks = 8 * ((n_mt + 7) / 8);
+    if (gn) RQ_LAUNCH(conv_out_halo_kernel<1>, dim3(nblocks), dim3(O_NTH), smem, s, a);
+    else RQ_LAUNCH(conv_out_halo_kernel<0>, dim3(nblocks), dim3(O_NTH), smem, s, a);
+    return rq_check_launch("conv_out_halo_kernel");
+}
+
 // (scale, shift) per (image, channel) from the GroupNorm partial statistics of gn_stats_kernel
 __global__ void gn_params_kernel(const float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
                                  int nchunk, float eps) {
@@ -319,4 +474,10 @@ extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const floa
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
     return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, B, H, W, Cin, Cout,
                                (hipStream_t)stream);
+}
+
+extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,
+                                       int Cin, int Cout, float* y, void* stream) {
+    if (!x || !w || !bias || !y) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_out: null argument");
+    return rq_launch_conv_out_halo((const bf16_t*)x, w, bias, gn, y, B, H, W, Cin, Cout, (hipStream_t)stream);
 }

@@ -264,10 +264,18 @@ static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipSt
             r.swap();
         }
     }
-    r.norm("decoder.norm_out", r.X, r.T1, res * res, block_in, 1);
-    if (r.err) return r.err;
     const float* w = (const float*)r.P("decoder.conv_out.weight");
     const float* b = (const float*)r.P("decoder.conv_out.bias");
+    if (r.err) return r.err;
+    if (!h->no_halo && rq_conv_out_halo_supported(res, res, block_in, c.out_ch)) {
+        // norm_out -> swish -> conv_out in one pass over the activation (plus the statistics pass)
+        const float* g = (const float*)r.P("decoder.norm_out.weight");
+        const float* be = (const float*)r.P("decoder.norm_out.bias");
+        if (r.err) return r.err;
+        RQ_TRY(rq_launch_gn_params(r.X, h->part.as<float>(), g, be, h->gnp.as<float>(), B, res * res, block_in, st));
+        return rq_launch_conv_out_halo(r.X, w, b, h->gnp.as<float>(), out, B, res, res, block_in, c.out_ch, st);
+    }
+    r.norm("decoder.norm_out", r.X, r.T1, res * res, block_in, 1);
     if (r.err) return r.err;
     return rq_launch_conv_out3(r.T1, w, b, out, B, res, res, block_in, c.out_ch, st);
 }

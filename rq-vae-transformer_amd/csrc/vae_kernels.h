@@ -15,5 +15,9 @@ int rq_launch_gn_stats(const bf16_t* x, float* part, int B, int HW, int C, int* 
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout);
 int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
                         int B, int H, int W, int Cin, int Cout, hipStream_t s);
+// MFMA conv_out (Cin -> Cout <= 4, NCHW fp32 image out) with optional fused GroupNorm+SiLU of norm_out
+bool rq_conv_out_halo_supported(int H, int W, int Cin, int Cout);
+int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, const float* gn, float* y, int B, int H, int W,
+                            int Cin, int Cout, hipStream_t s);
 int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
                         hipStream_t s);

@@ -61,6 +61,8 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_dbg_conv_out_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -205,6 +207,16 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None):
     check(lib().rqamd_dbg_conv_halo_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias, torch.float32), ptr(gn), ptr(resid),
                                          B, H, W, Cin, Cout, ptr(out), stream_of(x)))
     return out
+
+
+def dbg_conv_out(x, w, bias, gn=None):
+    """diagnostics: MFMA conv_out; x (B,H,W,Cin) bf16, w (Cout,3,3,Cin) fp32, returns (B,Cout,H,W) fp32."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    check(lib().rqamd_dbg_conv_out_bf16(ptr(x, torch.bfloat16), ptr(w, torch.float32), ptr(bias, torch.float32), ptr(gn),
+                                        B, H, W, Cin, Cout, ptr(y), stream_of(x)))
+    return y
 
 
 # ---------------------------------------------------------------------------------------------- engines

@@ -213,3 +213,27 @@ def test_emu_conv_halo(nat):
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
     out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid).float().numpy()
     assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max()
+
+
+def test_emu_conv_out_mfma(nat):
+    """Decoder.conv_out as an MFMA halo kernel (csrc/conv_halo.hip): Cin -> 3, NCHW fp32 out, optional fused
+    norm_out GroupNorm+SiLU; image borders, two channel planes, against the oracle's conv2d."""
+    from oracle.vae import conv2d, silu
+    rng = np.random.default_rng(6)
+    B, H, W, Cin, Cout = 2, 8, 64, 128, 3
+    x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).to(torch.bfloat16)
+    w = (0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    gn = np.stack([1.0 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], -1).astype(np.float32)
+    w_bf = torch.from_numpy(w).to(torch.bfloat16).float().numpy()      # the kernel multiplies bf16 weights
+    wf = np.transpose(w_bf, (0, 3, 1, 2))
+    xf = x.float().numpy()
+    ref = np.transpose(conv2d(xf, wf, bias), (0, 3, 1, 2))
+    out = nat.dbg_conv_out(x, T(w), T(bias)).numpy()
+    assert out.shape == (B, Cout, H, W)
+    assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max() + 1e-4
+    xn = silu(xf * gn[:, None, None, :, 0] + gn[:, None, None, :, 1])
+    xn = torch.from_numpy(xn.astype(np.float32)).to(torch.bfloat16).float().numpy()
+    ref = np.transpose(conv2d(xn, wf, bias), (0, 3, 1, 2))
+    out = nat.dbg_conv_out(x, T(w), T(bias), gn=T(gn)).numpy()
+    assert np.abs(out - ref).max() < 0.02 * np.abs(ref).max()

@@ -206,6 +206,19 @@ def test_rqt_real_width_logits_vs_oracle(nat):
     print('rqt wide logits: max err %.4f mean %.5f |ref|max %.3f' % (err.max(), err.mean(), scale))
     assert err.max() < 0.03 * max(scale, 1.0) + 0.02 and err.mean() < 0.004 * max(scale, 1.0) + 0.003
 
+    # Large-batch kernel variants (256x128 GEMM tile, wave-per-row resid_ln, full grids of the attention kernel) are
+    # selected by the row count only: 2049 rows = 683 copies of the three checked rows must reproduce them.
+    reps = 683
+    big = ar(G(np.tile(codes, (reps, 1, 1, 1)), torch.long), Aux, cond=G(np.tile(cond, (reps, 1)), torch.long))
+    small = G(logits)
+    worst = 0.0
+    for r0 in range(0, 3 * reps, 3 * 61):                     # strided copies (first, interior, last partial tile)
+        worst = max(worst, float((big[r0:r0 + 3] - small).abs().max()))
+    worst = max(worst, float((big[-3:] - small).abs().max()))
+    print('rqt wide logits: batch-2049 vs batch-3 max diff %.4f' % worst)
+    assert worst < 0.02 * max(scale, 1.0) + 0.01
+    del big
+
 
 def test_rqt_sample_semantics(nat, golden):
     g = golden('rqt_tiny.npz')
@@ -340,6 +353,42 @@ def test_vae_batch_invariance_and_chunking(nat, golden):
     assert torch.equal(full[[0, 127, 128, 132]], one)
     x = G(np.clip(rng.standard_normal((5, 3, 16, 16), dtype=np.float32), -1, 1))
     assert torch.equal(vae.encode(x)[3:4], vae.encode(x[3:4].contiguous()))
+
+
+def test_conv_kernels_vs_torch(nat):
+    """The high-resolution conv kernels through the diagnostics ABI against torch fp32 convs on the bf16-rounded
+    operands: halo 3x3 (plain / fused GroupNorm+SiLU / residual) and the MFMA conv_out (NCHW fp32 image out)."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device=DEV).manual_seed(12)
+
+    def rn(*shape, scale=1.0):
+        return scale * torch.randn(shape, device=DEV, generator=gen)
+    for (B, H, W, Cin, Cout) in ((2, 64, 64, 128, 128), (1, 128, 96, 64, 256)):
+        x = rn(B, H, W, Cin).to(torch.bfloat16)
+        w = rn(Cout, 3, 3, Cin, scale=0.05).to(torch.bfloat16)
+        bias, resid = rn(Cout), rn(B, H, W, Cout).to(torch.bfloat16)
+        gn = torch.stack([1.0 + 0.2 * rn(B, Cin), 0.3 * rn(B, Cin)], -1).contiguous()
+        wt = w.float().permute(0, 3, 1, 2)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1)
+        out = nat.dbg_conv_halo(x, w, bias).float()
+        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
+        xn = F.silu(x.float() * gn[:, None, None, :, 0] + gn[:, None, None, :, 1]).to(torch.bfloat16).float()
+        ref = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
+        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid).float()
+        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
+    for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (1, 64, 64, 256)):
+        x = rn(B, H, W, Cin).to(torch.bfloat16)
+        w = rn(3, 3, 3, Cin, scale=0.05)
+        bias = rn(3)
+        gn = torch.stack([1.0 + 0.2 * rn(B, Cin), 0.3 * rn(B, Cin)], -1).contiguous()
+        wt = w.to(torch.bfloat16).float().permute(0, 3, 1, 2)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, padding=1)
+        out = nat.dbg_conv_out(x, w, bias)
+        assert float((out - ref).abs().max()) < 2e-3 * float(ref.abs().max()) + 1e-4
+        xn = F.silu(x.float() * gn[:, None, None, :, 0] + gn[:, None, None, :, 1]).to(torch.bfloat16).float()
+        ref = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1)
+        out = nat.dbg_conv_out(x, w, bias, gn=gn)
+        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
 
 
 def test_create_model_and_state_dict_roundtrip(nat):
