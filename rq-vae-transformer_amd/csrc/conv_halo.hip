@@ -109,12 +109,10 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS.  The fused form is spread over
     // the taps of a chunk (one piece per tap) so that its VALU / transcendental work issues under the MFMAs;
     // done in one lump before the barrier it cost +73 % on the 128->128 @256^2 layer.
-    auto store_halo_piece = [&](int c, int buf, const rq_u128* rh, int it) {
-        if (!h_in[it]) return;
-        char* dst = sH + buf * HALO_BYTES;
+    auto halo_piece_value = [&](const rq_u128* rh, int it) -> rq_u128 {
         rq_u128 v = rh[it];
         if (FUSE_GN) {
-            // 8 channels c*64 + c8*8 .. +7 of this image: y = silu(x * scale + shift) = a / (1 + 2^(-a log2 e))
+            // 8 channels of this image: y = silu(x * scale + shift) = a / (1 + 2^(-a log2 e))
             float f[8];
             f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
             f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -131,7 +129,12 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
         }
         if (!h_ok[it]) v = zero128();              // zero padding of the (normalised) input
-        st128(dst + h_loff[it], v);
+        return v;
+    };
+    // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS
+    auto store_halo_piece = [&](int c, int buf, const rq_u128* rh, int it) {
+        if (!h_in[it]) return;
+        st128(sH + buf * HALO_BYTES + h_loff[it], halo_piece_value(rh, it));
     };
     auto store_halo = [&](int c, int buf, const rq_u128* rh) {
 #pragma unroll
@@ -183,11 +186,22 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 
     // ---- main loop over (64-channel chunk, tap); weights double-buffered per tap, halo per chunk
     const int NC = p.Cin / 64;
-    rq_u128 rh[H_IT], rw[2];
+    // Weight tiles are prefetched THREE (chunk, tap) units ahead through a rotating set of registers (unit g lives
+    // in set g % 3; 9 taps per chunk keep the rotation static under the unrolled tap loop): with a one-tap
+    // distance the L2 round trip (~1 us under load) was longer than a tap's 16 MFMAs and every tap stalled.
+    rq_u128 rh[H_IT], rw[3][2];
+    const int last_c = NC - 1;
+    auto load_unit = [&](int c, int tap, rq_u128* r) {      // (c, tap) may run past the end: clamp (harmless reload)
+        if (tap >= 9) { tap -= 9; ++c; }
+        if (c > last_c) { c = last_c; tap = 8; }
+        load_w(c, tap, r);
+    };
     load_halo(0, rh);
-    load_w(0, 0, rw);
+    load_w(0, 0, rw[0]);
+    load_unit(0, 1, rw[1]);
+    load_unit(0, 2, rw[2]);
     store_halo(0, 0, rh);
-    store_w(0, rw);
+    store_w(0, rw[0]);
     rq_syncthreads();
     int wbuf = 0;
     for (int c = 0; c < NC; ++c) {
@@ -196,19 +210,25 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            // prefetch: next weight tile every tap; next chunk's halo patch once, a few taps ahead
-            if (tap < 8) load_w(c, tap + 1, rw);
-            else load_w(more_c ? c + 1 : c, 0, rw);          // last tap of the last chunk: harmless reload
+            // prefetch: unit g+3 into the set unit g just left; next chunk's halo patch once, a few taps ahead
+            load_unit(c, tap + 3, rw[tap % 3]);
             if (tap == 0) load_halo(more_c ? c + 1 : c, rh);
             rq_sched_barrier();
-            // next chunk's patch: pieces 0..5 in taps 3..8 (the loads were issued three taps earlier).  With the
-            // fused GroupNorm the two wavefronts that share a SIMD (w and w+4) do their piece on opposite sides
-            // of the MFMA block, so one's VALU/transcendental work runs under the other's MFMAs.
+            // next chunk's patch: pieces 0..5 in taps 3..8 (the loads were issued three taps earlier).  The fused
+            // GroupNorm+SiLU arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no
+            // fence in between) so that its VALU / transcendental instructions issue in the MFMAs' shadow.
             const bool piece = tap >= 9 - H_IT;
-            if (FUSE_GN && piece && wave < 4) { store_halo_piece(more_c ? c + 1 : c, hbuf ^ 1, rh, tap - (9 - H_IT)); rq_sched_barrier(); }
+            const int it = piece ? tap - (9 - H_IT) : 0;
+            rq_u128 pv = zero128();
+            if (piece) pv = halo_piece_value(rh, it);
             compute(hbuf, wbuf, ky, kx);
-            store_w(wbuf ^ 1, rw);
-            if (piece && !(FUSE_GN && wave < 4)) { rq_sched_barrier(); store_halo_piece(more_c ? c + 1 : c, hbuf ^ 1, rh, tap - (9 - H_IT)); }
+            if (FUSE_GN && piece) {
+                // pipeline: each MFMA (8 passes) carries a slice of the piece's ~100 VALU instructions
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
+            }
+            store_w(wbuf ^ 1, rw[(tap + 1) % 3]);
+            if (piece && h_in[it]) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff[it], pv);
             rq_syncthreads();
             wbuf ^= 1;
         }
@@ -218,7 +238,21 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     constexpr int LDR = H_BN * 2 + 16;
     static_assert(256 * LDR <= 2 * HALO_BYTES + 2 * HW_BYTES, "epilogue tile must fit");
     char* sT = (char*)smem;
+    constexpr int CPR = H_BN / 8;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
+    if (p.resid) {
+        // the residual tile comes in as row-contiguous 16-byte loads and waits in the LDS tile, where the lane that
+        // owns an 8-byte slot adds it in fp32 before the single rounding and overwrites it in place (the per-lane
+        // 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
+#pragma unroll 4
+        for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
+            const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+            const int ty = ml / HT_W, tx = ml - ty * HT_W;
+            const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+            st128(sT + ml * LDR + nl * 2, ld128(p.resid + pix * p.Cout + n0 + nl));
+        }
+        rq_syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int ty = wm * 2 + i, tx = lane & 31;
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
                 if (p.resid) {
-                    const uint32_t* rp = (const uint32_t*)(p.resid + pix * p.Cout + n);
+                    const uint32_t* rp = (const uint32_t*)(sT + ml * LDR + nl * 2);
                     const uint32_t r0 = rp[0], r1 = rp[1];
                     v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
                     v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
@@ -248,7 +282,6 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         }
     }
     rq_syncthreads();
-    constexpr int CPR = H_BN / 8;
 #pragma unroll 4
     for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
         const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;

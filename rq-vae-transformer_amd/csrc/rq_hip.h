@@ -38,9 +38,21 @@ static inline __host__ __device__ bf16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN).  The bit-twiddling form
+// above costs ~9 VALU ops per element and, through its NaN branch, an exec-mask diamond per element that also
+// keeps the scheduler from moving anything across it (seen in the fused GroupNorm staging of conv_halo.hip).
+static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef float rq_f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 rq_bf16x2_t __attribute__((ext_vector_type(2)));
+    const rq_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rq_bf16x2_t));
+}
+#else
 static inline __host__ __device__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave-collective wrappers (one spelling for hipcc and the emulator)
@@ -62,6 +74,8 @@ static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
 // pins instruction order at this point (hipcc otherwise sinks independent global loads below LDS writes)
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)
 #define rq_setprio(x) __builtin_amdgcn_s_setprio(x)
+// scheduling pipeline hint: the next `n` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x100 DS read, ...) form a group
+#define rq_sched_group(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 // single-instruction reciprocal / exp2 (v_rcp_f32 / v_exp_f32, ~1 ulp): used where the result is rounded to bf16
 // wave-uniform value -> SGPR (lets address arithmetic derived from it run on the scalar unit)
 static __device__ __forceinline__ int rq_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }

@@ -119,6 +119,7 @@ typedef short bf16x8_emu __attribute__((ext_vector_type(8)));
 static inline void rq_syncthreads() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)
+#define rq_sched_group(mask, n) ((void)0)
 static inline int rq_uniform(int x) { return x; }
 static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
