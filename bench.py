@@ -91,11 +91,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 4096)), help='images per GPU per step')
     ap.add_argument('--model', default='huge')
-    ap.add_argument('--top-k', type=int, default=None)
-    ap.add_argument('--top-p', type=float, default=None)
+    # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
+    ap.add_argument('--top-k', type=int, default=1024)
+    ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
+    if args.top_k is not None and args.top_k <= 0:
+        args.top_k = None
+    if args.top_p is not None and args.top_p >= 1.0:
+        args.top_p = None
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

@@ -58,6 +58,7 @@ struct rqamd_rqt {
     int64_t *xs, *cond;
     int* st;            // [0] = spatial position
     uint64_t* rng;      // {seed, offset}
+    int* smp_redo;      // [rows] sampler workspace (rows the top-k kernel hands back to the general kernel)
     int max_slabs = 8;
 
     // graph cache
@@ -227,7 +228,7 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     const size_t E = h->E, V = h->V;
     const size_t rows = (size_t)B;
     size_t total = 2 * al(rows * E * 4) + al((size_t)h->max_slabs * rows * E * 4) + al(rows * V * 4) + 2 * al(rows * E * 2) + al(rows * 3 * E * 2)
-                   + al(rows * 4 * E * 2) + al(rows * h->Din * 2) + al(rows * h->HW * h->D * 8) + al(rows * h->cond_len * 8) + al(64) + al(64);
+                   + al(rows * 4 * E * 2) + al(rows * h->Din * 2) + al(rows * h->HW * h->D * 8) + al(rows * h->cond_len * 8) + al(64) + al(64) + al(rows * 4);
     RQ_TRY(h->ws.reserve(total));
     char* p = (char*)h->ws.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
@@ -238,7 +239,7 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     h->qkv = (bf16_t*)take(rows * 3 * E * 2); h->hbuf = (bf16_t*)take(rows * 4 * E * 2);
     h->ain = (bf16_t*)take(rows * h->Din * 2);
     h->xs = (int64_t*)take(rows * h->HW * h->D * 8); h->cond = (int64_t*)take(rows * h->cond_len * 8);
-    h->st = (int*)take(64); h->rng = (uint64_t*)take(64);
+    h->st = (int*)take(64); h->rng = (uint64_t*)take(64); h->smp_redo = (int*)take(rows * 4);
     // KV caches: body [rows][nh][Tbody][64] x2 per layer, head Tcap = D
     const size_t kvb = al(rows * E * h->Tbody * 2), kvh = al(rows * E * h->D * 2);
     RQ_TRY(h->kv.reserve(2 * kvb * h->body.size() + 2 * kvh * h->head.size()));
@@ -389,7 +390,7 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         if (c.sample) {
             SampleArgs s{};
             s.logits = h->logits; s.rows = B; s.V = h->V; s.temperature = c.temperature; s.top_k = c.top_k[d]; s.top_p = c.top_p[d];
-            s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;
+            s.redo = h->smp_redo; s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;
             RQ_TRY(rq_launch_sample(s, st));
         } else if (c.logits_out) {
             float* dst = c.logits_out + ((long)host_pos * h->D + d) * h->V;

@@ -79,6 +79,9 @@ static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
 // single-instruction reciprocal / exp2 (v_rcp_f32 / v_exp_f32, ~1 ulp): used where the result is rounded to bf16
 // wave-uniform value -> SGPR (lets address arithmetic derived from it run on the scalar unit)
 static __device__ __forceinline__ int rq_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+static __device__ __forceinline__ unsigned long long rq_ballot(bool pred) { return __ballot(pred); }
+static __device__ __forceinline__ int rq_popc64(unsigned long long m) { return __popcll(m); }
+static __device__ __forceinline__ void rq_threadfence_block() { __threadfence_block(); }
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

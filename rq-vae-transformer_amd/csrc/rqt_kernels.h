@@ -63,6 +63,7 @@ struct SampleArgs {
     int64_t* out;           // samples: out[row * out_stride + (*pos * D + d)] (pos null -> out[row*out_stride])
     long out_stride;
     float* probs_out;       // [rows][V] filtered distribution, or null
+    int* redo;              // [rows] workspace: rows the top-k kernel hands to the general kernel (null: general kernel only)
 };
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s);

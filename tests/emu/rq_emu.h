@@ -121,6 +121,15 @@ static inline void rq_syncthreads() { rqemu::block_barrier(); }
 #define rq_setprio(x) ((void)0)
 #define rq_sched_group(mask, n) ((void)0)
 static inline int rq_uniform(int x) { return x; }
+static inline unsigned long long rq_ballot(bool pred) {
+    unsigned char mine = pred ? 1 : 0;
+    auto mail = rqemu::wave_exchange(&mine, 1);
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (mail[l][0]) m |= 1ull << l;
+    return m;
+}
+static inline int rq_popc64(unsigned long long m) { return __builtin_popcountll(m); }
+static inline void rq_threadfence_block() {}
 static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
 static inline float rq_fast_exp2(float x) { return exp2f(x); }
