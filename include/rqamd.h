@@ -151,10 +151,11 @@ int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const v
 /* One launch of the halo-reuse 3x3 / stride-1 conv used for the high-resolution decoder/encoder layers
  * (csrc/conv_halo.hip): x NHWC bf16 [B][H][W][Cin], w bf16 [Cout][3][3][Cin], out NHWC bf16; gn = NULL or fp32
  * [B][Cin][2] (scale, shift): the input is then read as silu(x*scale + shift), i.e. GroupNorm+SiLU fused into the
- * staging (ResnetBlock norm -> swish -> conv, layers.py:100-120).  Needs H % 8 == 0, W % 32 == 0, H >= 64,
- * Cin % 64 == 0, Cout % 128 == 0. */
+ * staging (ResnetBlock norm -> swish -> conv, layers.py:100-120).  stats = NULL or fp32 [B][(H/8)*(W/32)][32][2]:
+ * per-tile (sum, sum of squares) of the 32 GroupNorm groups of `out` (Cout 128/256/512), taken in the epilogue for
+ * the next layer's Normalize.  Needs H % 8 == 0, W % 32 == 0, H >= 64, Cin % 64 == 0, Cout % 128 == 0. */
 int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
-                             int B, int H, int W, int Cin, int Cout, void* out, void* stream);
+                             int B, int H, int W, int Cin, int Cout, void* out, float* stats, void* stream);
 
 /* One launch of the MFMA Decoder.conv_out kernel (modules.py:165-169): x NHWC bf16 [B][H][W][Cin], w fp32
  * [Cout][3][3][Cin] (Cout <= 4), y NCHW fp32 [B][Cout][H][W]; gn as above (norm_out + swish fused into the

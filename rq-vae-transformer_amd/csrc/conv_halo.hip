@@ -26,6 +26,7 @@ struct ConvHaloArgs {
     const float* gn;        // [B][Cin][2] (scale, shift) or null: y = silu(x*scale + shift) applied on staging
     const bf16_t* resid;    // NHWC [B][H][W][Cout] or null
     bf16_t* out;            // NHWC [B][H][W][Cout]
+    float* stats;           // GroupNorm partials of `out`: [B][tiles][32][2] (sum, sumsq) as gn_stats_kernel writes them, or null
     int B, H, W, Cin, Cout;
 };
 
@@ -282,12 +283,66 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         }
     }
     rq_syncthreads();
+    // Thread tid streams chunk (tid & 15) of pixels (tid >> 4) + 32 k.  The GroupNorm statistics of the NEXT layer are
+    // taken here from the rounded bf16 values on their way out (what a separate gn_stats pass would read back from
+    // HBM: ~30 us per image over the decoder): per-thread (sum, sumsq) over its 8 pixels, folded to the 1-2 groups
+    // its 8 channels belong to, reduced over the 32 threads of the same chunk, one partial per (tile, group).
+    float gs_[8], gq_[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
 #pragma unroll 4
     for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
         const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
         const int ty = ml / HT_W, tx = ml - ty * HT_W;
         const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-        st128(p.out + pix * p.Cout + n0 + nl, ld128(sT + ml * LDR + nl * 2));
+        const rq_u128 u = ld128(sT + ml * LDR + nl * 2);
+        st128(p.out + pix * p.Cout + n0 + nl, u);
+        if (p.stats) {
+            float f[8];
+            f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+            f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+            f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+            f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs_[e] += f[e]; gq_[e] = fmaf(f[e], f[e], gq_[e]); }
+        }
+    }
+    if (p.stats) {                                  // uniform
+        __shared__ float sred[8][16][4];
+        const int gsz = p.Cout / 32;                // channels per group: 4, 8 or 16 (Cout = 128, 256, 512)
+        float a0, q0, a1, q1;                       // pair 0 = channels 0..3 (gsz 4) or 0..7; pair 1 = channels 4..7 (gsz 4)
+        if (gsz == 4) {
+            a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]); q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
+            a1 = (gs_[4] + gs_[5]) + (gs_[6] + gs_[7]); q1 = (gq_[4] + gq_[5]) + (gq_[6] + gq_[7]);
+        } else {
+            a0 = ((gs_[0] + gs_[1]) + (gs_[2] + gs_[3])) + ((gs_[4] + gs_[5]) + (gs_[6] + gs_[7]));
+            q0 = ((gq_[0] + gq_[1]) + (gq_[2] + gq_[3])) + ((gq_[4] + gq_[5]) + (gq_[6] + gq_[7]));
+            a1 = 0.f; q1 = 0.f;
+        }
+        // lanes l, l^16, l^32, l^48 hold the same chunk
+        a0 += rq_shfl_xor(a0, 16); q0 += rq_shfl_xor(q0, 16); a1 += rq_shfl_xor(a1, 16); q1 += rq_shfl_xor(q1, 16);
+        a0 += rq_shfl_xor(a0, 32); q0 += rq_shfl_xor(q0, 32); a1 += rq_shfl_xor(a1, 32); q1 += rq_shfl_xor(q1, 32);
+        if (lane < 16) { sred[wave][lane][0] = a0; sred[wave][lane][1] = q0; sred[wave][lane][2] = a1; sred[wave][lane][3] = q1; }
+        rq_syncthreads();
+        if (wave == 0) {                            // whole wavefront (the shuffle below needs all lanes); lanes >= 32 duplicate
+            // lane = (chunk, pair); channels n0 + chunk*8 + pair*4 ... belong to group (n0 + chunk*8 + pair*4) / gsz
+            const int chunk = (lane >> 1) & 15, pair = lane & 1;
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { a += sred[w][chunk][pair * 2]; q += sred[w][chunk][pair * 2 + 1]; }
+            if (gsz == 16) {                        // a group spans two chunks: even chunk collects its neighbour
+                a += rq_shfl_xor(a, 2);
+                q += rq_shfl_xor(q, 2);
+            }
+            const bool writer = gsz == 4 ? true : (gsz == 8 ? pair == 0 : (pair == 0 && (chunk & 1) == 0));
+            if (writer && lane < 32) {
+                const int g = (n0 + chunk * 8 + pair * 4) / gsz;
+                const int tiles = tiles_x * tiles_y;
+                float* o = p.stats + (((long)img * tiles + trem) * 32 + g) * 2;
+                o[0] = a;
+                o[1] = q;
+            }
+        }
     }
 }
 
@@ -472,12 +527,15 @@ bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
     return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64;
 }
 
+int rq_conv_halo_stat_tiles(int H, int W) { return (H / HT_H) * (W / HT_W); }
+
 int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
-                        int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+                        float* stats, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+    if (stats && Cout != 128 && Cout != 256 && Cout != 512) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: fused statistics need Cout 128/256/512");
     if (!rq_conv_halo_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: shape %dx%d %d->%d", H, W, Cin, Cout);
     if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
     ConvHaloArgs a{};
-    a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const size_t smem = 2 * HALO_BYTES + 2 * HW_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
@@ -492,10 +550,11 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     return rq_check_launch("conv3x3_halo_kernel");
 }
 
+// nchunk_have > 0: `part` already holds that many partials per image (written by the producing conv's epilogue)
 int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
-                        hipStream_t s) {
-    int nchunk = 0;
-    RQ_TRY(rq_launch_gn_stats(x, part, B, HW, C, &nchunk, s));
+                        int nchunk_have, hipStream_t s) {
+    int nchunk = nchunk_have;
+    if (nchunk <= 0) RQ_TRY(rq_launch_gn_stats(x, part, B, HW, C, &nchunk, s));
     const int n = B * C;
     RQ_LAUNCH(gn_params_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, gamma, beta, gn, B, HW, C, nchunk, 1e-6f);
     return rq_check_launch("gn_params_kernel");
@@ -503,10 +562,10 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
 
 // diagnostics entry (include/rqamd.h)
 extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
-                                        int B, int H, int W, int Cin, int Cout, void* out, void* stream) {
+                                        int B, int H, int W, int Cin, int Cout, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
-    return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, B, H, W, Cin, Cout,
-                               (hipStream_t)stream);
+    return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W, Cin,
+                               Cout, (hipStream_t)stream);
 }
 
 extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,

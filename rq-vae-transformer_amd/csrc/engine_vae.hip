@@ -28,7 +28,7 @@ struct rqamd_vae {
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
-    bool no_halo = false, no_fuse_gn = false;
+    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false;
     std::string missing;
 };
 
@@ -51,6 +51,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     if (const char* e = getenv("RQAMD_VAE_CHUNK")) { int v = atoi(e); if (v >= 1 && v <= 1024) h->chunk_max = v; }
     h->no_halo = getenv("RQAMD_NO_HALO") != nullptr;      // A/B switches (diagnostics)
     h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
+    h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     *out = h;
     return RQAMD_OK;
 }
@@ -123,6 +124,9 @@ struct VaeRun {
     int B;
     int err = RQAMD_OK;
     bf16_t *X, *Y, *T1, *T2, *T3;
+    // GroupNorm partials currently held in h->part: of which tensor, how many per image (0 = none)
+    const bf16_t* stats_of = nullptr;
+    int stats_n = 0;
 
     void* P(const std::string& name) {
         auto it = h->params.find(name);
@@ -146,9 +150,14 @@ struct VaeRun {
         // high-resolution 3x3 / stride-1 layers: halo-reuse kernel (one patch staged per 64-channel chunk, 9 taps)
         if (ks == 3 && stride == 1 && !ups && (epi == EPI_BF16 || epi == EPI_BF16_RESID) && !h->no_halo &&
             rq_conv_halo_supported(Hin, Win, Cin, Cout)) {
-            err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst, B, Hin, Win, Cin, Cout, st);
+            const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(Hin, Win);
+            err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst,
+                                      st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, st);
+            stats_of = st_ok ? (const bf16_t*)dst : nullptr;
+            stats_n = st_ok ? rq_conv_halo_stat_tiles(Hin, Win) : 0;
             return;
         }
+        if ((const void*)stats_of == (const void*)dst) stats_of = nullptr;      // dst is overwritten without new statistics
         GemmArgs a{};
         a.A = src; a.W = w; a.M = B * Hout * Wout; a.N = Cout; a.K = ks * ks * Cin; a.lda = Cin;
         a.conv = (ks == 3 || stride != 1 || ups) ? 1 : 0;
@@ -159,8 +168,10 @@ struct VaeRun {
         if (bn == 128 && (long)(a.M / 256) * (Cout / 128) >= 512) bm = 256;     // 8-wave tile for the big layers
         err = rq_gemm_launch(a, bm, bn, st);
     }
+    bool stat_fits(int H, int W) const { return (size_t)B * rq_conv_halo_stat_tiles(H, W) * 32 * 2 * 4 <= h->part.bytes; }
     void norm(const std::string& name, const bf16_t* src, bf16_t* dst, int HW, int C, int silu) {
         if (err) return;
+        stats_of = nullptr;                          // the statistics pass below overwrites h->part
         const float* g = (const float*)P(name + ".weight");
         const float* b = (const float*)P(name + ".bias");
         if (err) return;
@@ -178,9 +189,15 @@ struct VaeRun {
             const bf16_t* w = (const bf16_t*)P(cname + ".weight");
             const float* b = (const float*)P(cname + ".bias");
             if (err) return;
-            err = rq_launch_gn_params(src, h->part.as<float>(), g, be, h->gnp.as<float>(), B, H * W, Cin, st);
+            // statistics of src: left in h->part by the conv that produced it, else one read-only pass
+            err = rq_launch_gn_params(src, h->part.as<float>(), g, be, h->gnp.as<float>(), B, H * W, Cin,
+                                      stats_of == src ? stats_n : 0, st);
             if (err) return;
-            err = rq_launch_conv_halo(src, w, b, h->gnp.as<float>(), epi == EPI_BF16_RESID ? resid : nullptr, dst, B, H, W, Cin, Cout, st);
+            const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(H, W);
+            err = rq_launch_conv_halo(src, w, b, h->gnp.as<float>(), epi == EPI_BF16_RESID ? resid : nullptr, dst,
+                                      st_ok ? h->part.as<float>() : nullptr, B, H, W, Cin, Cout, st);
+            stats_of = st_ok ? dst : nullptr;
+            stats_n = st_ok ? rq_conv_halo_stat_tiles(H, W) : 0;
             return;
         }
         norm(nname, src, tmp, H * W, Cin, 1);
@@ -228,7 +245,12 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
     const size_t bytes = (elems * 2 + 255) & ~(size_t)255;
     RQ_TRY(h->ws.reserve(bytes * 5));
     for (int i = 0; i < 5; ++i) h->buf[i] = (bf16_t*)((char*)h->ws.p + bytes * i);
-    RQ_TRY(h->part.reserve((size_t)chunk * RQ_GN_MAX_CHUNK * 32 * 2 * 4));
+    {   // GroupNorm partials: gn_stats uses <= RQ_GN_MAX_CHUNK per image, the conv epilogues one per 8x32 output tile
+        size_t per_img_parts = RQ_GN_MAX_CHUNK;
+        const size_t tiles = (size_t)(c.resolution / 8) * ((c.resolution + 31) / 32);
+        if (tiles > per_img_parts) per_img_parts = tiles;
+        RQ_TRY(h->part.reserve((size_t)chunk * per_img_parts * 32 * 2 * 4));
+    }
     RQ_TRY(h->gnp.reserve((size_t)chunk * 2048 * 2 * 4));
     h->cap_elems = elems;
     h->chunk = chunk;
@@ -272,7 +294,8 @@ static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipSt
         const float* g = (const float*)r.P("decoder.norm_out.weight");
         const float* be = (const float*)r.P("decoder.norm_out.bias");
         if (r.err) return r.err;
-        RQ_TRY(rq_launch_gn_params(r.X, h->part.as<float>(), g, be, h->gnp.as<float>(), B, res * res, block_in, st));
+        RQ_TRY(rq_launch_gn_params(r.X, h->part.as<float>(), g, be, h->gnp.as<float>(), B, res * res, block_in,
+                                   r.stats_of == r.X ? r.stats_n : 0, st));
         return rq_launch_conv_out_halo(r.X, w, b, h->gnp.as<float>(), out, B, res, res, block_in, c.out_ch, st);
     }
     r.norm("decoder.norm_out", r.X, r.T1, res * res, block_in, 1);

@@ -236,8 +236,13 @@ def test_emu_conv_halo(nat):
     xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
     xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
-    out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid).float().numpy()
+    stats = torch.zeros((B, (H // 8) * (W // 32), 32, 2), dtype=torch.float32)
+    out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats).float().numpy()
     assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max()
+    # epilogue statistics: per (8x32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
+    t = out.reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32).astype(np.float64)
+    want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
+    assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max()
 
 
 def test_emu_conv_out_mfma(nat):

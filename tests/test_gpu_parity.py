@@ -341,16 +341,18 @@ def test_vae_tiny_golden(nat, golden):
 @pytest.mark.parametrize('tag,cfg', [('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)])
 def test_vae_full_size_golden(nat, golden, tag, cfg):
     """Released RQ-VAE shapes (104.4 M params, 256x256): decode_code and encode vs the reference fp32
-    outputs on seeded weights.  Pixel tolerance: max |err| <= 4 % of max |ref| (0.17 on outputs spanning
-    about [-4.3, 4.3]), mean |err| <= 0.012 (outputs have std 0.31): bf16 activations through ~70 layers;
-    measured 0.134 / 0.0068 (imagenet shape) and 0.098 / 0.0068 (ffhq shape)."""
+    outputs on seeded weights.  Pixel tolerance: mean |err| <= 0.012 (outputs have std 0.31) and max |err| <= 5 %
+    of max |ref| (0.21 / 0.15 on outputs spanning about +-4.3 / +-3.0): bf16 activations through ~70 layers.
+    Measured mean 0.0068 for both shapes in every version of the kernels; the max is the tail of 196 608 pixels and
+    moves with the summation order of the GroupNorm statistics (0.134 / 0.098 with a separate statistics pass,
+    0.127 on the ffhq shape with the statistics taken in the conv epilogues)."""
     g = golden(f'vae_{tag}.npz')
     vae, vparams, _, _ = _models(cfg, None, int(g['seed']), 0)
     dec = N(vae.decode_code(G(g['codes'], torch.long)))
     ref = g['decode_code'].astype(np.float32)
     err = np.abs(dec - ref)
     print(f'vae {tag} decode_code: max err %.4f mean %.5f (|ref| max %.2f, std %.3f)' % (err.max(), err.mean(), np.abs(ref).max(), ref.std()))
-    assert err.max() < 0.04 * np.abs(ref).max() and err.mean() < 0.012
+    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
     rng = np.random.default_rng(int(g['data_seed']))
     rng.integers(0, cfg[0]['n_embed'], (1, 8, 8, 4))
     x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
@@ -387,7 +389,7 @@ def test_conv_kernels_vs_torch(nat):
 
     def rn(*shape, scale=1.0):
         return scale * torch.randn(shape, device=DEV, generator=gen)
-    for (B, H, W, Cin, Cout) in ((2, 64, 64, 128, 128), (1, 128, 96, 64, 256)):
+    for (B, H, W, Cin, Cout) in ((2, 64, 64, 128, 128), (1, 128, 96, 64, 256), (1, 64, 64, 64, 512)):
         x = rn(B, H, W, Cin).to(torch.bfloat16)
         w = rn(Cout, 3, 3, Cin, scale=0.05).to(torch.bfloat16)
         bias, resid = rn(Cout), rn(B, H, W, Cout).to(torch.bfloat16)
@@ -398,8 +400,13 @@ def test_conv_kernels_vs_torch(nat):
         assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
         xn = F.silu(x.float() * gn[:, None, None, :, 0] + gn[:, None, None, :, 1]).to(torch.bfloat16).float()
         ref = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
-        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid).float()
+        stats = torch.zeros((B, (H // 8) * (W // 32), 32, 2), device=DEV)
+        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats).float()
         assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
+        # epilogue statistics for the next GroupNorm: per (8x32 tile, group) sum / sum of squares of the bf16 output
+        t = out.double().reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32)
+        want = torch.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
+        assert float((stats.double() - want).abs().max()) < 1e-3 * float(want.abs().max())
     for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (1, 64, 64, 256)):
         x = rn(B, H, W, Cin).to(torch.bfloat16)
         w = rn(3, 3, 3, Cin, scale=0.05)
