@@ -271,10 +271,11 @@ static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, in
     GemmArgs a{};
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cfg.gelu_v2;
     a.bias = bias; a.bias_step = bias_step; a.bias_stride = bias_stride; a.out = out; a.ldo = ldo;
-    int bm, bn, sk;
-    rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk);
+    int bm, bn, sk, gl = 0;
+    rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);
     if (sk > h->max_slabs) sk = h->max_slabs;
     a.splitk = sk;
+    a.glds = gl;
     if (n_slabs) *n_slabs = sk;
     GemmProfile& pf = h->prof;
     if (pf.on) {

@@ -55,6 +55,7 @@ struct GemmArgs {
     int splitk;
     int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
     int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
+    int glds;                // 0 = register-staged operands; 2..3 = LDS-DMA ring with that many stages (dense only)
 };
 
 // GELU of the transformer MLP (attentions.py:17-22 of the reference): v1 = x * Phi(x), v2 = x * sigmoid(1.702 x).
@@ -78,7 +79,11 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
 // TR 1: accumulate the transposed tile (4 consecutive output columns per lane -> 16-byte fp32 stores); used
 // for the split-K partial slabs, whose rows are short (N = E).  TR 0: bf16 outputs go through an LDS transpose,
 // wide fp32 outputs (logits) are stored as 2 x 128 contiguous bytes per wavefront store.
-template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2>   // WGM x WGN wavefronts per workgroup
+// GL 0: operands staged global -> registers -> LDS (all modes).  GL = 2..4 (dense operands only): a ring of GL LDS
+// stages filled by LDS-DMA (global_load_lds_dwordx4, 1 KB = 8 tile rows per wavefront instruction): no staging
+// registers, no ds_write pass; the XOR swizzle moves to the per-lane SOURCE address (the DMA writes lane-linear),
+// the loads are counted by hand (s_waitcnt vmcnt(N) before the barrier that publishes a stage).
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0>   // WGM x WGN wavefronts per workgroup
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NTH = 64 * WGM * WGN;      // threads per workgroup
     constexpr int RP = NTH / 8;              // tile rows staged per pass (8 threads x 16 B per 64-wide row)
@@ -88,8 +93,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int MI = WM / 32, NI = WN / 32;
     constexpr int A_IT = BM / RP, B_IT = BN / RP;
     RQ_DYN_SMEM(smem);
-    bf16_t* sA = (bf16_t*)smem;              // [2][BM*64]
-    bf16_t* sB = sA + 2 * BM * BK;           // [2][BN*64]
+    // GL 0: sA[2][BM*64] then sB[2][BN*64].  GL > 0: GL stages of { A tile, B tile }.
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int A_STRIDE = GL ? STAGE_BYTES : BM * BK * 2;      // bytes between buffers of the A / B tile
+    constexpr int B_STRIDE = GL ? STAGE_BYTES : BN * BK * 2;
+    bf16_t* sA = (bf16_t*)smem;
+    bf16_t* sB = sA + (GL ? 1 : 2) * BM * BK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -280,9 +289,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 af[MI], bfr[NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(rd_a[ks] + buf * (BM * BK * 2) + i * (32 * 64 * 2)));
+            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(rd_a[ks] + buf * A_STRIDE + i * (32 * 64 * 2)));
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(rd_b[ks] + buf * (BN * BK * 2) + j * (32 * 64 * 2)));
+            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(rd_b[ks] + buf * B_STRIDE + j * (32 * 64 * 2)));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -294,9 +303,61 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     // Two register sets keep two K-tiles of global loads in flight (tile t+1 landing, tile t+2 issued)
     // while tile t is multiplied out of LDS.  The loop body is branch-free apart from the trip count: loads
     // past the last tile re-read the last tile (harmless), so the compiler can use counted vmcnt waits.
+    const int nk = kt1 - kt0, last = kt1 - 1;
+    if constexpr (GL > 0) {
+        static_assert(MODE == 0 && GL >= 2 && GL <= 4, "LDS-DMA staging: dense operands, 2..4 stages");
+        constexpr int NW = WGM * WGN;
+        constexpr int A_PER = BM / 8 / NW, B_PER = BN / 8 / NW;      // 8-row (1 KB) groups per wavefront and tile
+        constexpr int PER = A_PER + B_PER;
+        static_assert(A_PER * 8 * NW == BM && B_PER * 8 * NW == BN, "tile rows must split evenly over the wavefronts");
+        const int uw = rq_uniform(wave);
+        const rq_lds_t lds0 = rq_lds_addr(smem);
+        // lane l of a group fills LDS position (row lr, chunk lc): it must fetch the chunk that the swizzled read
+        // expects there, lc ^ ((row >> 1) & 7) -- the same involution as the register-staged path's write side
+        const int lr = lane >> 3, lc = lane & 7;
+        unsigned ga[A_PER], gb[B_PER];
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            const int row = (uw * A_PER + q) * 8 + lr;
+            int m = m0 + row;
+            if (m > p.M - 1) m = p.M - 1;
+            ga[q] = ((unsigned)m * p.lda + ((lc ^ ((row >> 1) & 7)) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            const int row = (uw * B_PER + q) * 8 + lr;
+            int n = n0 + row;
+            if (n > p.N - 1) n = p.N - 1;
+            gb[q] = ((unsigned)n * p.K + ((lc ^ ((row >> 1) & 7)) << 3)) * 2u;
+        }
+        auto issue = [&](int kt, int st) {
+            const unsigned kb = (unsigned)kt * (BK * 2);
+            const rq_lds_t base = lds0 + (rq_lds_t)(st * STAGE_BYTES);
+#pragma unroll
+            for (int q = 0; q < A_PER; ++q) rq_glds16(base + (rq_lds_t)((uw * A_PER + q) * 1024), gA + (ga[q] + kb));
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) rq_glds16(base + (rq_lds_t)(BM * 128 + (uw * B_PER + q) * 1024), gW + (gb[q] + kb));
+        };
+        if (nk > 0) {
+#pragma unroll
+            for (int s0 = 0; s0 < GL - 1; ++s0)
+                if (s0 < nk) issue(kt0 + s0, s0);
+            int st = 0;
+            for (int t = 0; t < nk; ++t) {
+                // tile t has landed once at most (tiles issued after it) * PER loads are outstanding
+                const int newer = nk - 1 - t;
+                if (GL >= 4 && newer >= 2) rq_wait_vmcnt<2 * PER>();
+                else if (GL >= 3 && newer >= 1) rq_wait_vmcnt<PER>();
+                else rq_wait_vmcnt<0>();
+                rq_barrier_raw();            // publishes stage st; every wave is past its reads of stage st-1 (refilled next)
+                if (t + GL - 1 < nk) issue(kt0 + t + GL - 1, st == 0 ? GL - 1 : st - 1);
+                compute(st);
+                st = st + 1 == GL ? 0 : st + 1;
+            }
+        }
+    } else {
     rq_u128 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
     unsigned mk0 = 0, mk1 = 0;
-    const int nk = kt1 - kt0, last = kt1 - 1;
     if (nk > 0) {
         mk0 = load_tile(kt0, ra0, rb0);
         mk1 = load_tile(kt0 + 1 < kt1 ? kt0 + 1 : last, ra1, rb1);
@@ -336,6 +397,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
         }
         if (nk & 1) compute(0);      // odd tile count: the last tile already sits in buffer 0
     }
+    }   // GL == 0
 
     // ------------------------------------------------------------------ epilogue
     if (p.dbg & 1) {          // ablation: keep the accumulators live, store one value per wave
@@ -578,4 +640,5 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
 // host-side launcher (gemm.hip)
 int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 // picks (BM, BN, splitk) for a weight-streaming decode GEMM; returns splitk actually used via args
-void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk);
+// glds (may be null): receives the number of LDS-DMA stages to use (0 = register-staged operands)
+void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds);

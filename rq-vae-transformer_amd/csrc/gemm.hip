@@ -3,12 +3,12 @@
 #include <stdlib.h>
 #include "rq_common.h"
 
-template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2>
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
-    const size_t smem = (size_t)(BM + BN) * 64 * 2 * 2;
+    const size_t smem = (size_t)(BM + BN) * 64 * 2 * (GL ? GL : 2);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
@@ -30,7 +30,7 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         nblocks = 8 * ((MT + 7) / 8) * NT;
     }
     dim3 grid(nblocks, 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN>), grid, dim3(64 * WGM * WGN), smem, stream, g);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>), grid, dim3(64 * WGM * WGN), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
 template <int BM, int BN>
@@ -63,6 +63,22 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     }
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
+    {   // LDS-DMA staged variants (dense operands): RQAMD_GEMM_GL = number of LDS stages (experiment switch)
+        static const int gl_env = getenv("RQAMD_GEMM_GL") ? atoi(getenv("RQAMD_GEMM_GL")) : 0;
+        const int gl = a.glds ? a.glds : gl_env;
+        if (!a.conv && gl >= 2) {
+            const bool tr = a.epi != EPI_F32;
+#define RQ_GL_CASE(BM_, BN_, WM_, WN_)                                                                                   \
+            if (bm == BM_ && bn == BN_) {                                                                                  \
+                if (gl == 2) return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 2>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 2>(a, stream); \
+                return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 3>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 3>(a, stream);               \
+            }
+            RQ_GL_CASE(128, 64, 2, 2)
+            RQ_GL_CASE(128, 128, 2, 2)
+            RQ_GL_CASE(256, 128, 4, 2)
+#undef RQ_GL_CASE
+        }
+    }
     if (bm == 64 && bn == 64) return launch_t<64, 64>(a, stream);
     if (bm == 64 && bn == 128) return launch_t<64, 128>(a, stream);
     if (bm == 128 && bn == 64) return launch_t<128, 64>(a, stream);
@@ -84,7 +100,37 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     return rq_fail(RQAMD_ERR_INVALID, "gemm: no tile %dx%d", bm, bn);
 }
 
-void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk) {
+void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds) {
+    // LDS-DMA staged operands win or tie from M = 512 up (profiles/r01_gemm_bench_lds_dma.txt, MI355X): 8-12 % at
+    // M = 4096.  Tiles per shape class, from the same sweep:
+    static const bool no_glds = getenv("RQAMD_NO_GLDS") != nullptr;
+    if (glds) *glds = 0;
+    if (glds && !no_glds && M >= 512 && K % 64 == 0) {
+        *glds = 2;
+        if (N >= 16384 && M >= 512) {                       // classifier: wide N, fp32 rows
+            *bm = 256; *bn = 128; *splitk = 1; *glds = M >= 4096 || M < 2048 ? 3 : 2;
+            return;
+        }
+        if (M >= 4096 && N >= 4096) { *bm = 128; *bn = 128; *splitk = 1; return; }                       // qkv, fc1
+        if (M >= 2048 && allow_splitk && K >= 4096 && N <= 2048) {                                       // fc2
+            *bm = 256; *bn = 128; *splitk = M >= 4096 ? 1 : 2; *glds = 3;
+            return;
+        }
+        // everything else: 128x64 with the split-K rule below
+        *bm = 128; *bn = 64;
+        int maxsplit = 1;
+        if (allow_splitk) {
+            maxsplit = (K / 64) / 8;
+            if (maxsplit > 8) maxsplit = 8;
+            if (maxsplit < 1) maxsplit = 1;
+        }
+        const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
+        int sp = (768 + tiles - 1) / tiles;
+        if (sp > maxsplit) sp = maxsplit;
+        if (sp < 1) sp = 1;
+        *splitk = sp;
+        return;
+    }
     // Rule distilled from scripts/gemm_bench.py on MI355X (profiles/r01_gemm_bench.md), M = 64..2048 batch
     // rows against the 1.4B layer shapes: take the LARGEST tile (most MFMAs per barrier) that still yields
     // >= 512 workgroups (2 per CU) once split-K is allowed to multiply the count (split target: 768); residual-producing GEMMs
@@ -123,15 +169,18 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
 extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
-    int flags = 0;
+    int flags = 0, glds = 0;
+    if (epi >= 64) { glds = epi / 32; epi -= glds * 32; }      // epi + 32 * stages: LDS-DMA operand staging (2 or 3 stages)
     if (epi >= 16) { flags = 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
-    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags;
+    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags; a.glds = glds;
     if (bm <= 0 || bn <= 0) {
-        int sk;
-        rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk);
+        int sk, gl = 0;
+        rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);
         if (splitk <= 0) a.splitk = sk;
+        else if (gl && splitk != sk) { gl = 0; rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, nullptr); }
+        a.glds = gl;
     }
     if (a.splitk <= 0) a.splitk = 1;
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);

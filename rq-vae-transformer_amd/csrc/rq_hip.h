@@ -71,6 +71,20 @@ static __device__ __forceinline__ int rq_shfl_xor_i(int v, int m) { return __shf
 static __device__ __forceinline__ float rq_shfl(float v, int lane) { return __shfl(v, lane, 64); }
 static __device__ __forceinline__ int rq_shfl_i(int v, int lane) { return __shfl(v, lane, 64); }
 static __device__ __forceinline__ void rq_syncthreads() { __syncthreads(); }
+// ---- LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane straight from global memory into LDS at
+// lds_base + lane * 16 (lds_base wave-uniform), no VGPR staging and no ds_write.  hipcc does not count these loads
+// in its s_waitcnt bookkeeping: pair every use with rq_wait_vmcnt<N>() + a barrier before the data is read.
+typedef unsigned rq_lds_t;
+static __device__ __forceinline__ unsigned rq_lds_addr(const void* p) {          // byte address inside the LDS aperture
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p);
+}
+static __device__ __forceinline__ void rq_glds16(unsigned lds_base, const void* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+static __device__ __forceinline__ void rq_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 // pins instruction order at this point (hipcc otherwise sinks independent global loads below LDS writes)
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)
 #define rq_setprio(x) __builtin_amdgcn_s_setprio(x)

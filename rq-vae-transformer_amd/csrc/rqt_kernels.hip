@@ -188,136 +188,175 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
 // occupies the CU's address path for 16 cycles whatever the lanes address, which made the previous
 // one-key-per-lane mapping cost ~100 us per launch even at t = 0 (profiles/r01_attn_trace.txt).
 // NJ = number of 8-key blocks held in registers; DYN = skip blocks >= nblk at run time (long contexts).
-template <int NJ, bool DYN>
-static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, long pair, int t) {
-    const int b = (int)(pair / p.nh), h = (int)(pair - (long)b * p.nh);
+// P = (row, head) pairs per wavefront (heads h0 .. h0+P-1 of one row), processed stage by stage so that the loads of
+// all P pairs are in flight together: at short contexts a wavefront's lifetime is one memory round trip, and with
+// 98 304 pairs per launch the launch time was 12 rounds of 8192 resident wavefronts x that latency (45 us at t = 0).
+template <int NJ, bool DYN, int P>
+static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, int b, int h0, int t) {
     const int E = p.E, Tcap = p.Tcap;
-    const bf16_t* qrow = p.qkv + (long)b * 3 * E + h * 64;
-    const bf16_t* krow = qrow + E;
-    const bf16_t* vrow = qrow + 2 * E;
-    bf16_t* kc = p.kc + pair * Tcap * 64;
-    bf16_t* vc = p.vc + pair * Tcap * 64;
     const int cc = lane & 7, g = lane >> 3;
     const int nblk = (t >> 3) + 1;
     const int tprev = t > 0 ? t - 1 : 0;
     const float NEG_INF = -__int_as_float(0x7f800000);
+    const long kvs = 64;                                // elements between consecutive positions of a pair's cache
+    const bf16_t* qrow[P];
+    bf16_t* kc[P];
+    bf16_t* vc[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const long pair = (long)b * p.nh + h0 + i;
+        qrow[i] = p.qkv + (long)b * 3 * E + (h0 + i) * 64;
+        kc[i] = p.kc + pair * Tcap * 64;                // pair-major [rows][nh][Tcap][64]: a position-major layout
+        vc[i] = p.vc + pair * Tcap * 64;                // measured +10 % at long contexts and no gain at short ones
+    }
 
     // every global load is issued before the first use (q, this token's k|v, all K and V blocks); rows j >= t
     // read this token's k / v straight from qkv (the cache row is written by this launch), clamped, unmasked
-    const rq_u128 qv = ld128(qrow + cc * 8);
-    const rq_u128 kv_new = ld128((lane < 8 ? krow : vrow) + cc * 8);
-    rq_u128 kr[NJ], vr[NJ];
+    rq_u128 qv[P], kv_new[P], kr[P][NJ], vr[P][NJ];
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        if (DYN && jj >= nblk) continue;
-        const int j = jj * 8 + g;
-        const long off = (long)(j < t ? j : tprev) * 64 + cc * 8;
-        kr[jj] = ld128((j >= t) ? (krow + cc * 8) : (kc + off));
+    for (int i = 0; i < P; ++i) {
+        qv[i] = ld128(qrow[i] + cc * 8);
+        kv_new[i] = ld128(qrow[i] + (lane < 8 ? E : 2 * E) + cc * 8);
     }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        if (DYN && jj >= nblk) continue;
-        const int j = jj * 8 + g;
-        const long off = (long)(j < t ? j : tprev) * 64 + cc * 8;
-        vr[jj] = ld128((j >= t) ? (vrow + cc * 8) : (vc + off));
-    }
-    if (lane < 8) st128(kc + (long)t * 64 + cc * 8, kv_new);
-    else if (lane < 16) st128(vc + (long)t * 64 + cc * 8, kv_new);
-
-    float qf[8];
-    unpack8(qv, qf);
-    float sc[NJ];
-    float mx = NEG_INF;
+    for (int i = 0; i < P; ++i) {
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        float s = NEG_INF;
-        if (!DYN || jj < nblk) {
-            float kf[8];
-            unpack8(kr[jj], kf);
-            float dot = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
-            dot += rq_shfl_xor(dot, 1);
-            dot += rq_shfl_xor(dot, 2);
-            dot += rq_shfl_xor(dot, 4);
-            if (jj * 8 + g <= t) s = dot * 0.125f;                  // 1/sqrt(64), attentions.py:87
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (DYN && jj >= nblk) continue;
+            const int j = jj * 8 + g;
+            const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
+            kr[i][jj] = ld128((j >= t) ? (qrow[i] + E + cc * 8) : (kc[i] + off));
         }
-        sc[jj] = s;
-        mx = fmaxf(mx, s);
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        sc[jj] = (sc[jj] == NEG_INF) ? 0.f : rq_fast_exp2((sc[jj] - mx) * 1.4426950408889634f);
-        sum += sc[jj];
+    for (int i = 0; i < P; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (DYN && jj >= nblk) continue;
+            const int j = jj * 8 + g;
+            const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
+            vr[i][jj] = ld128((j >= t) ? (qrow[i] + 2 * E + cc * 8) : (vc[i] + off));
+        }
     }
-    sum += rq_shfl_xor(sum, 8);                                     // over the key groups only: the 8 lanes of a
-    sum += rq_shfl_xor(sum, 16);                                    // group hold the same weights
-    sum += rq_shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (lane < 8) st128(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+        else if (lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+    }
 
-    float acc[8];
+    float sc[P][NJ], mx[P], inv[P];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int i = 0; i < P; ++i) {
+        float qf[8];
+        unpack8(qv[i], qf);
+        mx[i] = NEG_INF;
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-        if (DYN && jj >= nblk) continue;
-        const float pj = sc[jj] * inv;                              // 0 for j > t
-        float vf[8];
-        unpack8(vr[jj], vf);
+        for (int jj = 0; jj < NJ; ++jj) {
+            float s = NEG_INF;
+            if (!DYN || jj < nblk) {
+                float kf[8];
+                unpack8(kr[i][jj], kf);
+                float dot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+                for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+                dot += rq_shfl_xor(dot, 1);
+                dot += rq_shfl_xor(dot, 2);
+                dot += rq_shfl_xor(dot, 4);
+                if (jj * 8 + g <= t) s = dot * 0.125f;              // 1/sqrt(64), attentions.py:87
+            }
+            sc[i][jj] = s;
+            mx[i] = fmaxf(mx[i], s);
+        }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        acc[e] += rq_shfl_xor(acc[e], 8);
-        acc[e] += rq_shfl_xor(acc[e], 16);
-        acc[e] += rq_shfl_xor(acc[e], 32);
+    for (int i = 0; i < P; ++i) mx[i] = wave_max(mx[i]);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            sc[i][jj] = (sc[i][jj] == NEG_INF) ? 0.f : rq_fast_exp2((sc[i][jj] - mx[i]) * 1.4426950408889634f);
+            sum += sc[i][jj];
+        }
+        sum += rq_shfl_xor(sum, 8);                                 // over the key groups only: the 8 lanes of a
+        sum += rq_shfl_xor(sum, 16);                                // group hold the same weights
+        sum += rq_shfl_xor(sum, 32);
+        inv[i] = 1.0f / sum;
     }
-    if (g == 0) {
-        rq_u128 o;
-        o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
-        o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
-        st128(p.y + (long)b * E + h * 64 + cc * 8, o);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (DYN && jj >= nblk) continue;
+            const float pj = sc[i][jj] * inv[i];                    // 0 for j > t
+            float vf[8];
+            unpack8(vr[i][jj], vf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            acc[e] += rq_shfl_xor(acc[e], 8);
+            acc[e] += rq_shfl_xor(acc[e], 16);
+            acc[e] += rq_shfl_xor(acc[e], 32);
+        }
+        if (g == 0) {
+            rq_u128 o;
+            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+            st128(p.y + (long)b * E + (h0 + i) * 64 + cc * 8, o);
+        }
     }
 }
 
 // One kernel per register-block count: the launch picks the smallest NJ that covers the host-known bound on t
 // (engine_rqt.hip keeps one captured graph per NJ), so short contexts and the depth transformer (t < 8) run
-// with ~40 VGPRs and 8 wavefronts per SIMD instead of inheriting the 64-key variant's register budget.
-template <int NJ, bool DYN>
+// with few VGPRs and 8 wavefronts per SIMD instead of inheriting the 64-key variant's register budget.
+template <int NJ, bool DYN, int P>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = rq_uniform((int)(threadIdx.x >> 6));
-    const int h = blockIdx.x * 4 + wave;
-    if (h >= p.nh) return;                                         // whole wave exits together
-    const long pair = (long)blockIdx.y * p.nh + h;
+    const int h0 = (blockIdx.x * 4 + wave) * P;
+    if (h0 >= p.nh) return;                                        // whole wave exits together (nh % P == 0)
     const int t = (p.step ? *p.step : 0) + p.step_off;
     if ((t >> 3) >= NJ) rq_trap();                                 // host bound violated: never drop keys silently
-    attn_run<NJ, DYN>(p, lane, pair, t);
+    attn_run<NJ, DYN, P>(p, lane, (int)blockIdx.y, h0, t);
+}
+
+template <int NJ, bool DYN>
+static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t s) {
+    const dim3 blk(256);
+    if (pairs_per_wave == 2) {
+        RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    } else {
+        RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    }
 }
 
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
     if (a.rows > 65535) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: %d rows > 65535", a.rows);
-    const dim3 grid((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk(256);
     const int nj_cap = (a.Tcap + 7) / 8;
     int nj = a.t_max >= 0 ? (a.t_max >> 3) + 1 : nj_cap;
     if (nj > nj_cap) nj = nj_cap;
+    // two heads per wavefront while the register blocks are small (latency-bound regime) and the heads pair up
+    const int ppw = (a.nh % 2 == 0 && nj <= 4 && a.Tcap <= 64 && (long)a.rows * a.nh >= 16384) ? 2 : 1;
     if (a.Tcap <= 64) {
         switch (nj) {
-            case 1: RQ_LAUNCH((attn_decode_kernel<1, false>), grid, blk, 0, s, a); break;
-            case 2: RQ_LAUNCH((attn_decode_kernel<2, false>), grid, blk, 0, s, a); break;
-            case 3: RQ_LAUNCH((attn_decode_kernel<3, false>), grid, blk, 0, s, a); break;
-            case 4: RQ_LAUNCH((attn_decode_kernel<4, false>), grid, blk, 0, s, a); break;
-            case 5: RQ_LAUNCH((attn_decode_kernel<5, false>), grid, blk, 0, s, a); break;
-            case 6: RQ_LAUNCH((attn_decode_kernel<6, false>), grid, blk, 0, s, a); break;
-            case 7: RQ_LAUNCH((attn_decode_kernel<7, false>), grid, blk, 0, s, a); break;
-            default: RQ_LAUNCH((attn_decode_kernel<8, false>), grid, blk, 0, s, a); break;
+            case 1: launch_attn<1, false>(a, ppw, s); break;
+            case 2: launch_attn<2, false>(a, ppw, s); break;
+            case 3: launch_attn<3, false>(a, ppw, s); break;
+            case 4: launch_attn<4, false>(a, ppw, s); break;
+            case 5: launch_attn<5, false>(a, 1, s); break;
+            case 6: launch_attn<6, false>(a, 1, s); break;
+            case 7: launch_attn<7, false>(a, 1, s); break;
+            default: launch_attn<8, false>(a, 1, s); break;
         }
-    } else if (a.Tcap <= 128) RQ_LAUNCH((attn_decode_kernel<16, true>), grid, blk, 0, s, a);
-    else if (a.Tcap <= 256) RQ_LAUNCH((attn_decode_kernel<32, true>), grid, blk, 0, s, a);
+    } else if (a.Tcap <= 128) launch_attn<16, true>(a, 1, s);
+    else if (a.Tcap <= 256) launch_attn<32, true>(a, 1, s);
     else return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: context %d > 256", a.Tcap);
     return rq_check_launch("attn_decode_kernel");
 }

@@ -176,10 +176,11 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
     M, K = a_bf16.shape
     N = w_bf16.shape[0]
     if out is None:
-        if epi == 4:
+        kind = epi % 16                      # + 16 / + 64 / + 96 are launch options (include/rqamd.h)
+        if kind == 4:
             out = torch.empty((splitk if splitk > 0 else 8, M, N), dtype=torch.float32, device=a_bf16.device)
         else:
-            out = torch.empty((M, N), dtype=torch.float32 if epi == 3 else torch.bfloat16, device=a_bf16.device)
+            out = torch.empty((M, N), dtype=torch.float32 if kind == 3 else torch.bfloat16, device=a_bf16.device)
     check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
                                     ptr(out), bm, bn, splitk, stream_of(a_bf16)))
     return out

@@ -16,19 +16,19 @@ def bench(M, N, K, epi, bm, bn, sk, reps=40):
     a = torch.randn((M, K), device=dev).to(torch.bfloat16)
     ws = [torch.randn((N, K), device=dev).to(torch.bfloat16) * 0.05 for _ in range(8)]     # rotate weights: no L2/MALL reuse
     bias = torch.randn((N,), device=dev)
-    out = _native.dbg_gemm(a, ws[0], bias if epi != 4 else None, epi, bm, bn, sk)
-    ref = a.float() @ ws[0].float().T + (bias if epi != 4 else 0)
-    if epi == 4 and sk <= 0:
+    out = _native.dbg_gemm(a, ws[0], bias if epi % 16 != 4 else None, epi, bm, bn, sk)
+    ref = a.float() @ ws[0].float().T + (bias if epi % 16 != 4 else 0)
+    if epi % 16 == 4 and sk <= 0:
         out.zero_()
         out = _native.dbg_gemm(a, ws[0], None, epi, bm, bn, sk, out=out)
-    got = out.float().sum(0) if epi == 4 else out.float()
+    got = out.float().sum(0) if epi % 16 == 4 else out.float()
     err = (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-9)
     for i in range(5):
-        _native.dbg_gemm(a, ws[i % 8], bias if epi != 4 else None, epi, bm, bn, sk, out=out)
+        _native.dbg_gemm(a, ws[i % 8], bias if epi % 16 != 4 else None, epi, bm, bn, sk, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(reps):
-        _native.dbg_gemm(a, ws[i % 8], bias if epi != 4 else None, epi, bm, bn, sk, out=out)
+        _native.dbg_gemm(a, ws[i % 8], bias if epi % 16 != 4 else None, epi, bm, bn, sk, out=out)
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
@@ -43,16 +43,17 @@ if __name__ == '__main__':
         for name, N, K, epi in shapes:
             best = None
             rows = []
-            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128), (257, 128), (129, 128)):
-                if bm == 64 and M > 128 and bn == 64:
-                    pass
-                for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
-                    try:
-                        us, tf, gbs, err = bench(M, N, K, epi, bm, bn, sk)
-                    except Exception as e:
-                        print('fail', M, name, bm, bn, sk, e)
-                        continue
-                    rows.append((us, bm, bn, sk, tf, gbs, err))
+            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128)):
+                for gl in ((0, 64, 96) if bm >= 128 and os.environ.get('RQ_GL', '1') != '0' else (0,)):   # LDS-DMA staging: +64 / +96
+                    for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
+                        try:
+                            us, tf, gbs, err = bench(M, N, K, epi + gl, bm, bn, sk)
+                        except Exception as e:
+                            print('fail', M, name, bm, bn, sk, gl, e)
+                            continue
+                        if err > 0.02 and epi != 1:
+                            print('WRONG', M, name, bm, bn, sk, gl, err)
+                        rows.append((us, f'{bm}g{gl // 32}' if gl else bm, bn, sk, tf, gbs, err))
             us, tf_, gbs_, err_ = bench(M, N, K, epi, 0, 0, 0)
             rows.sort()
             b = rows[0]

@@ -12,6 +12,7 @@ std::function<void()> g_entry;
 static std::vector<char*> g_stacks;
 
 unsigned char* dyn_smem() { return g_blk->dyn.data(); }
+size_t dyn_smem_size() { return g_blk->dyn.size(); }
 
 static void trampoline() {
     g_entry();

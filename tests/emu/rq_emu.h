@@ -94,6 +94,7 @@ inline const unsigned char (*wave_exchange(const void* mine, int bytes))[kMail] 
 
 void run_grid(dim3 grid, dim3 block, size_t smem);
 unsigned char* dyn_smem();
+size_t dyn_smem_size();
 
 template <typename K, typename... A>
 inline void launch(K kern, dim3 grid, dim3 block, size_t smem, A... args) {
@@ -117,6 +118,19 @@ typedef float f32x16_emu __attribute__((ext_vector_type(16)));
 typedef short bf16x8_emu __attribute__((ext_vector_type(8)));
 
 static inline void rq_syncthreads() { rqemu::block_barrier(); }
+// LDS-DMA: each lane copies its 16 bytes to lds_base + lane * 16; the "address" is the host pointer itself
+typedef uintptr_t rq_lds_t;
+static inline uintptr_t rq_lds_addr(const void* p) { return (uintptr_t)p; }
+static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
+    char* dst = (char*)lds_base + 16 * rqemu::g_cur->lane;
+    if (dst < (char*)rqemu::dyn_smem() || dst + 16 > (char*)rqemu::dyn_smem() + rqemu::dyn_smem_size()) {
+        fprintf(stderr, "rq_glds16: LDS destination %ld outside the %zu-byte dynamic segment\n", (long)(dst - (char*)rqemu::dyn_smem()), rqemu::dyn_smem_size());
+        abort();
+    }
+    memcpy(dst, gsrc, 16);
+}
+template <int N> static inline void rq_wait_vmcnt() {}
+static inline void rq_barrier_raw() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)
 #define rq_sched_group(mask, n) ((void)0)

@@ -215,6 +215,28 @@ def test_emu_vae_tiny(nat, golden):
     assert err.max() < 0.05 and err.mean() < 0.008
 
 
+def test_emu_gemm_tiles_and_lds_dma(nat):
+    """Decode-step GEMM through the diagnostics entry: register-staged and LDS-DMA staged (2 / 3 stages) operand paths,
+    ragged M / N (clamped rows), odd and even K-tile counts, bf16 / fp32 / split-K epilogues, vs fp32 matmul."""
+    rng = np.random.default_rng(17)
+    for (M, N, K) in ((200, 192, 320), (128, 64, 64), (130, 70, 448)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+        for gl in (0, 64, 96):
+            for (bm, bn) in ((128, 64), (128, 128), (256, 128)):
+                if N % 4 and bn:                      # ragged N: fp32 epilogue only (bf16 rows need N % 8 == 0 for vector stores)
+                    pass
+                out = nat.dbg_gemm(a, w, bias, epi=3 + gl, bm=bm, bn=bn, splitk=1).numpy()
+                assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max(), (M, N, K, gl, bm, bn)
+            out = nat.dbg_gemm(a, w, bias, epi=0 + gl, bm=128, bn=64, splitk=1).float().numpy()
+            assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max(), (M, N, K, gl)
+            if K >= 128:
+                out = nat.dbg_gemm(a, w, None, epi=4 + gl, bm=128, bn=64, splitk=2).numpy().sum(0)
+                assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K, gl)
+
+
 def test_emu_conv_halo(nat):
     """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual;
     against the oracle's conv2d / silu on the bf16-rounded operands."""
