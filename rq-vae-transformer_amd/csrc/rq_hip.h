@@ -96,6 +96,19 @@ static __device__ __forceinline__ int rq_uniform(int x) { return __builtin_amdgc
 static __device__ __forceinline__ unsigned long long rq_ballot(bool pred) { return __ballot(pred); }
 static __device__ __forceinline__ int rq_popc64(unsigned long long m) { return __popcll(m); }
 static __device__ __forceinline__ void rq_threadfence_block() { __threadfence_block(); }
+// DPP lane exchanges (one VALU op, no LDS round trip -- a ds_bpermute shuffle costs ~100 cycles of latency):
+// xor 1 / xor 2 inside a quad, mirror inside 8 lanes (pairs quad 0 with quad 1: a valid "xor 4" once the quads are
+// uniform), rotate by 8 inside a row of 16 (= xor 8), and a scalar read of one lane.
+template <int CTRL> static __device__ __forceinline__ float rq_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+static __device__ __forceinline__ float rq_dpp_xor1(float v) { return rq_dpp<0xB1>(v); }          // quad_perm [1,0,3,2]
+static __device__ __forceinline__ float rq_dpp_xor2(float v) { return rq_dpp<0x4E>(v); }          // quad_perm [2,3,0,1]
+static __device__ __forceinline__ float rq_dpp_half_mirror(float v) { return rq_dpp<0x141>(v); }   // lane i <- lane 7 - i (per 8)
+static __device__ __forceinline__ float rq_dpp_ror8(float v) { return rq_dpp<0x128>(v); }          // lane i <- lane (i + 8) % 16 (per 16)
+static __device__ __forceinline__ float rq_readlane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

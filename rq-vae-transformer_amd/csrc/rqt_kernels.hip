@@ -259,17 +259,22 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
                 float dot = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
-                dot += rq_shfl_xor(dot, 1);
-                dot += rq_shfl_xor(dot, 2);
-                dot += rq_shfl_xor(dot, 4);
+                dot += rq_dpp_xor1(dot);                            // the 8 lanes of a key group: DPP, no LDS round trip
+                dot += rq_dpp_xor2(dot);
+                dot += rq_dpp_half_mirror(dot);
                 if (jj * 8 + g <= t) s = dot * 0.125f;              // 1/sqrt(64), attentions.py:87
             }
             sc[i][jj] = s;
             mx[i] = fmaxf(mx[i], s);
         }
     }
+    // scores are uniform inside a key group; across the 8 groups: rotate-by-8 inside each row of 16 lanes, then the
+    // four rows through scalar lane reads (no ds_bpermute chain: its latency, not bandwidth, set the launch time)
 #pragma unroll
-    for (int i = 0; i < P; ++i) mx[i] = wave_max(mx[i]);
+    for (int i = 0; i < P; ++i) {
+        float m = fmaxf(mx[i], rq_dpp_ror8(mx[i]));
+        mx[i] = fmaxf(fmaxf(rq_readlane(m, 0), rq_readlane(m, 16)), fmaxf(rq_readlane(m, 32), rq_readlane(m, 48)));
+    }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         float sum = 0.f;
@@ -278,9 +283,8 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             sc[i][jj] = (sc[i][jj] == NEG_INF) ? 0.f : rq_fast_exp2((sc[i][jj] - mx[i]) * 1.4426950408889634f);
             sum += sc[i][jj];
         }
-        sum += rq_shfl_xor(sum, 8);                                 // over the key groups only: the 8 lanes of a
-        sum += rq_shfl_xor(sum, 16);                                // group hold the same weights
-        sum += rq_shfl_xor(sum, 32);
+        sum += rq_dpp_ror8(sum);                                    // over the key groups only: the 8 lanes of a
+        sum = (rq_readlane(sum, 0) + rq_readlane(sum, 16)) + (rq_readlane(sum, 32) + rq_readlane(sum, 48));   // group hold the same weights
         inv[i] = 1.0f / sum;
     }
 #pragma unroll
@@ -297,12 +301,18 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
         }
+        // lanes 0..7 (group 0) collect the other groups: the row partner by DPP, rows 1..3 by three independent pulls
+        float r1[8], r2[8], r3[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += rq_dpp_ror8(acc[e]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            acc[e] += rq_shfl_xor(acc[e], 8);
-            acc[e] += rq_shfl_xor(acc[e], 16);
-            acc[e] += rq_shfl_xor(acc[e], 32);
+            r1[e] = rq_shfl(acc[e], (lane + 16) & 63);
+            r2[e] = rq_shfl(acc[e], (lane + 32) & 63);
+            r3[e] = rq_shfl(acc[e], (lane + 48) & 63);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (acc[e] + r1[e]) + (r2[e] + r3[e]);
         if (g == 0) {
             rq_u128 o;
             o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
