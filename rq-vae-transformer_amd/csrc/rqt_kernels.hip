@@ -301,24 +301,25 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
         }
-        // lanes 0..7 (group 0) collect the other groups: the row partner by DPP, rows 1..3 by three independent pulls
-        float r1[8], r2[8], r3[8];
+        // Reduce-scatter over the 8 key groups so that every lane ends with ONE of the 64 outputs (6 cross-row
+        // shuffles instead of 24: the ds_bpermute count, 2.4 M per launch, was the LDS pipe's whole budget):
+        //   rows {0,1} <-> {2,3}: keep e in 0..3 / 4..7;  row <-> row^1: keep 2 of those;  halves of a row: keep 1.
+        const bool up32 = (lane & 32) != 0, up16 = (lane & 16) != 0, up8 = (lane & 8) != 0;
+        float a4[4], a2[2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += rq_dpp_ror8(acc[e]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            r1[e] = rq_shfl(acc[e], (lane + 16) & 63);
-            r2[e] = rq_shfl(acc[e], (lane + 32) & 63);
-            r3[e] = rq_shfl(acc[e], (lane + 48) & 63);
+        for (int e = 0; e < 4; ++e) {
+            const float keep = up32 ? acc[e + 4] : acc[e], send = up32 ? acc[e] : acc[e + 4];
+            a4[e] = keep + rq_shfl_xor(send, 32);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = (acc[e] + r1[e]) + (r2[e] + r3[e]);
-        if (g == 0) {
-            rq_u128 o;
-            o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
-            o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
-            st128(p.y + (long)b * E + (h0 + i) * 64 + cc * 8, o);
+        for (int e = 0; e < 2; ++e) {
+            const float keep = up16 ? a4[e + 2] : a4[e], send = up16 ? a4[e] : a4[e + 2];
+            a2[e] = keep + rq_shfl_xor(send, 16);
         }
+        const float keep1 = up8 ? a2[1] : a2[0], send1 = up8 ? a2[0] : a2[1];
+        const float o1 = keep1 + rq_dpp_ror8(send1);
+        const int eo = (up32 ? 4 : 0) + (up16 ? 2 : 0) + (up8 ? 1 : 0);            // which of the 8 channels of chunk cc
+        p.y[(long)b * E + (h0 + i) * 64 + cc * 8 + eo] = (bf16_t)(pack_bf16x2(o1, 0.f) & 0xffffu);
     }
 }
 
