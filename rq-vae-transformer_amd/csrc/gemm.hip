@@ -17,6 +17,13 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
     int nblocks;
     if (getenv("RQAMD_GEMM_SCHED0")) {
         g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
+    } else if (NT >= 8 && !a.conv && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6 && !getenv("RQAMD_GEMM_SCHED1")) {
+        // dense, weights much smaller than activations (fc2 at large batch): give every XCD a band of m-tiles instead.
+        // An XCD then streams its own slice of A once and all of W (N*K bytes, 8x in total) rather than all of A
+        // (M*K bytes, 8x): PMC showed 446 MB per fc2 launch at M=4096 against 94 MB algorithmic with n-ranges, 226 MB
+        // and 99 -> 90 us with m-bands (proj, where the saving is 55 MB, measured 5 % slower: threshold 100 MB).
+        g.sched = 2; g.sched_gm = 1;
+        nblocks = 8 * ((MT + 7) / 8) * NT;
     } else if (NT >= 8) {
         const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
         long panel = (long)BM * ktiles * 64 * 2;                   // bytes of one m-tile's A panel for this K split
