@@ -79,6 +79,255 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
 // TR 1: accumulate the transposed tile (4 consecutive output columns per lane -> 16-byte fp32 stores); used
 // for the split-K partial slabs, whose rows are short (N = E).  TR 0: bf16 outputs go through an LDS transpose,
 // wide fp32 outputs (logits) are stored as 2 x 128 contiguous bytes per wavefront store.
+// Epilogue shared by the GEMM kernels: bias / GELU / residual / bf16 packing / fp32 and split-K slab stores from the
+// accumulators of a WGM x WGN wavefront grid over a BM x BN tile.  `smem` is the workgroup's dynamic LDS segment of
+// SMEM_BYTES bytes (the operand buffers, free once every wave has passed the barrier inside); TR as in the kernels.
+template <int BM, int BN, int TR, int WGM, int WGN, int SMEM_BYTES>
+static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
+                                                        unsigned char* smem, int m0, int n0) {
+    constexpr int NTH = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 32, NI = WN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    // ------------------------------------------------------------------ epilogue
+    if (p.dbg & 1) {          // ablation: keep the accumulators live, store one value per wave
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+        if (keep == 12345.678f) ((float*)p.out)[0] = keep;
+        return;
+    }
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const int epi = p.epi;
+    if (TR && epi <= EPI_BF16_RESID) {
+        // bf16 outputs: each lane packs its 4 consecutive columns to 8 bytes and writes them into a padded
+        // [BM][BN] bf16 tile in LDS (over the operand buffers); the tile is then streamed out as 16-byte,
+        // row-contiguous global stores, the residual being read the same way.  (Ablation on the decoder convs:
+        // the first, scattered 2-byte epilogue cost +33..80 %; an fp32 LDS transpose +24 %.)
+        constexpr int LDR = BN * 2 + 16;           // padded row stride in bytes (16-byte aligned rows)
+        static_assert(BM * LDR <= SMEM_BYTES, "bf16 epilogue tile must fit the operand buffers");
+        char* sT = (char*)smem;
+        rq_syncthreads();                          // every wave is done reading the operand buffers
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * WM + i * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                    const int n = n0 + nl;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                    if (bias) {
+                        if (n + 3 < p.N) {
+                            const f32x4 bv = *(const f32x4*)(bias + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                        } else {
+                            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
+                        }
+                    }
+                    if (epi == EPI_BF16_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                    }
+                    if (epi == EPI_BF16_RESID) {
+                        // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
+                        const int m = m0 + ml;
+                        if (m < p.M && n < p.N) {
+                            const bf16_t* rp = p.resid + (long)m * p.ldr + n;
+                            if ((p.ldr & 3) == 0 && n + 3 < p.N) {
+                                const uint32_t r0 = ((const uint32_t*)rp)[0], r1 = ((const uint32_t*)rp)[1];
+                                v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                                v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                            } else {
+                                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bf16_to_f32(rp[e]);
+                            }
+                        }
+                    }
+                    struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
+                    w.a = pack_bf16x2(v[0], v[1]);
+                    w.b = pack_bf16x2(v[2], v[3]);
+                    *(u64*)(sT + ml * LDR + nl * 2) = w;
+                }
+            }
+        }
+        rq_syncthreads();
+        constexpr int CPR = BN / 8;                // 16-byte chunks per row
+        const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
+#pragma unroll 4
+        for (int c = tid; c < BM * CPR; c += NTH) {
+            const int ml = c / CPR, nl = (c - ml * CPR) * 8;
+            const int m = m0 + ml, n = n0 + nl;
+            if (m >= p.M || n >= p.N) continue;
+            rq_u128 u = ld128(sT + ml * LDR + nl * 2);
+            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+            if (v16) {
+                st128(o, u);
+            } else {
+                const bf16_t* t = (const bf16_t*)(sT + ml * LDR + nl * 2);
+                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = t[e];
+            }
+        }
+        return;
+    }
+    if (TR) {
+    // TR: the MFMAs above computed the TRANSPOSED tile (weight fragment as the "A" operand), so in the C/D
+    // register map (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31) the row index is the output
+    // column n and the col index is the output row m: every lane owns, for its row m, four groups of
+    // FOUR CONSECUTIVE n -- one 8-byte (bf16) or 16-byte (fp32) vector store each, and the residual is
+    // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
+    // time on the decoder convs; an LDS-staged transpose was 19 %.)
+    const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WM + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                if (m >= p.M || n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                const bool full4 = vec_ok && n + 3 < p.N;
+                if (bias && epi != EPI_F32_PARTIAL) {
+                    if (full4) {
+                        const f32x4 bv = *(const f32x4*)(bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
+                    }
+                }
+                if (epi == EPI_BF16_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                }
+                if (epi <= EPI_BF16_RESID) {
+                    bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+                    if (full4) {
+                        if (epi == EPI_BF16_RESID) {
+                            const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                            const uint32_t r0 = rp[0], r1 = rp[1];
+                            v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                            v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                        }
+                        struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
+                        w.a = pack_bf16x2(v[0], v[1]);
+                        w.b = pack_bf16x2(v[2], v[3]);
+                        *(u64*)o = w;
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                            float x = v[e];
+                            if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                            o[e] = f32_to_bf16(x);
+                        }
+                    }
+                } else {
+                    float* o = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
+                    if (full4) {
+                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                    } else {
+                        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = v[e];
+                    }
+                }
+            }
+        }
+    }
+        return;
+    }
+    // TR == 0: untransposed accumulators (row = output row m, col = output column n)
+    if (epi <= EPI_BF16_RESID) {
+        // bf16 outputs: stage the fp32 tile through LDS (reusing the operand buffers) so that global
+        // stores -- and the residual reads -- are row-contiguous 8-byte accesses instead of one scattered
+        // 2-byte access per accumulator register (ablation: the scattered epilogue cost 33-80 % on top of
+        // the main loop on the decoder convs).
+        float* sC = (float*)smem;                  // [HB][BN] fp32 slab of the tile, reusing the operand buffers
+        constexpr int SM_BYTES = SMEM_BYTES;
+        constexpr int NH = (BM * BN * 4 + SM_BYTES - 1) / SM_BYTES;     // passes (1, or 2 for the 256-row tile)
+        constexpr int HB = BM / NH;                                     // rows per pass (multiple of WM)
+        static_assert(HB % WM == 0 && HB * BN * 4 <= SM_BYTES, "epilogue slab must fit the operand buffers");
+        constexpr int QPR = BN / 4;                // float4 groups per row
+        const bool n_vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            rq_syncthreads();                      // operand buffers / previous slab are free
+            if (wm * WM >= hh * HB && wm * WM < (hh + 1) * HB) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int nl = wn * WN + j * 32 + (lane & 31);
+                        const int n = n0 + nl;
+                        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ml = wm * WM - hh * HB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            float v = acc[i][j][r] + bv;
+                            if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
+                            sC[ml * BN + nl] = v;
+                        }
+                    }
+            }
+            rq_syncthreads();
+#pragma unroll 4
+            for (int q = tid; q < HB * QPR; q += NTH) {
+                const int ml = q / QPR, nl = (q - ml * QPR) * 4;
+                const int m = m0 + hh * HB + ml, n = n0 + nl;
+                if (m >= p.M || n >= p.N) continue;
+                f32x4 v = *(const f32x4*)(sC + ml * BN + nl);
+                bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+                if (n_vec_ok) {
+                    if (epi == EPI_BF16_RESID) {
+                        const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                        const uint32_t r0 = rp[0], r1 = rp[1];
+                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                    }
+                    uint32_t* op = (uint32_t*)o;
+                    const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
+                    op[0] = w0;
+                    op[1] = w1;
+                } else {
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                        float x = v[e];
+                        if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                        o[e] = f32_to_bf16(x);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // fp32 outputs: a wavefront store already covers 2 x 128 contiguous bytes
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 32 + (lane & 31);
+            const float bv = (bias && n < p.N && epi != EPI_F32_PARTIAL) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= p.M || n >= p.N) continue;
+                const float v = acc[i][j][r] + bv;
+                const long o = (long)m * p.ldo + n;
+                if (epi == EPI_F32) ((float*)p.out)[o] = v;
+                else ((float*)p.out)[(long)blockIdx.z * p.M * p.ldo + o] = v;
+            }
+        }
+}
+
 // GL 0: operands staged global -> registers -> LDS (all modes).  GL = 2..4 (dense operands only): a ring of GL LDS
 // stages filled by LDS-DMA (global_load_lds_dwordx4, 1 KB = 8 tile rows per wavefront instruction): no staging
 // registers, no ds_write pass; the XOR swizzle moves to the per-lane SOURCE address (the DMA writes lane-linear),
@@ -399,242 +648,140 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     }
     }   // GL == 0
 
-    // ------------------------------------------------------------------ epilogue
-    if (p.dbg & 1) {          // ablation: keep the accumulators live, store one value per wave
-        float keep = 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-        if (keep == 12345.678f) ((float*)p.out)[0] = keep;
-        return;
-    }
-    const float* bias = p.bias;
-    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
-    const int epi = p.epi;
-    if (TR && epi <= EPI_BF16_RESID) {
-        // bf16 outputs: each lane packs its 4 consecutive columns to 8 bytes and writes them into a padded
-        // [BM][BN] bf16 tile in LDS (over the operand buffers); the tile is then streamed out as 16-byte,
-        // row-contiguous global stores, the residual being read the same way.  (Ablation on the decoder convs:
-        // the first, scattered 2-byte epilogue cost +33..80 %; an fp32 LDS transpose +24 %.)
-        constexpr int LDR = BN * 2 + 16;           // padded row stride in bytes (16-byte aligned rows)
-        static_assert(BM * LDR <= (BM + BN) * 64 * 2 * 2, "bf16 epilogue tile must fit the operand buffers");
-        char* sT = (char*)smem;
-        rq_syncthreads();                          // every wave is done reading the operand buffers
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int ml = wm * WM + i * 32 + (lane & 31);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nl = wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
-                    const int n = n0 + nl;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                    if (bias) {
-                        if (n + 3 < p.N) {
-                            const f32x4 bv = *(const f32x4*)(bias + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                        } else {
-                            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
-                        }
-                    }
-                    if (epi == EPI_BF16_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
-                    }
-                    if (epi == EPI_BF16_RESID) {
-                        // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
-                        const int m = m0 + ml;
-                        if (m < p.M && n < p.N) {
-                            const bf16_t* rp = p.resid + (long)m * p.ldr + n;
-                            if ((p.ldr & 3) == 0 && n + 3 < p.N) {
-                                const uint32_t r0 = ((const uint32_t*)rp)[0], r1 = ((const uint32_t*)rp)[1];
-                                v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                                v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
-                            } else {
-                                for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bf16_to_f32(rp[e]);
-                            }
-                        }
-                    }
-                    struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
-                    w.a = pack_bf16x2(v[0], v[1]);
-                    w.b = pack_bf16x2(v[2], v[3]);
-                    *(u64*)(sT + ml * LDR + nl * 2) = w;
-                }
-            }
-        }
-        rq_syncthreads();
-        constexpr int CPR = BN / 8;                // 16-byte chunks per row
-        const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
-#pragma unroll 4
-        for (int c = tid; c < BM * CPR; c += NTH) {
-            const int ml = c / CPR, nl = (c - ml * CPR) * 8;
-            const int m = m0 + ml, n = n0 + nl;
-            if (m >= p.M || n >= p.N) continue;
-            rq_u128 u = ld128(sT + ml * LDR + nl * 2);
-            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
-            if (v16) {
-                st128(o, u);
-            } else {
-                const bf16_t* t = (const bf16_t*)(sT + ml * LDR + nl * 2);
-                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = t[e];
-            }
-        }
-        return;
-    }
-    if (TR) {
-    // TR: the MFMAs above computed the TRANSPOSED tile (weight fragment as the "A" operand), so in the C/D
-    // register map (row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31) the row index is the output
-    // column n and the col index is the output row m: every lane owns, for its row m, four groups of
-    // FOUR CONSECUTIVE n -- one 8-byte (bf16) or 16-byte (fp32) vector store each, and the residual is
-    // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
-    // time on the decoder convs; an LDS-staged transpose was 19 %.)
-    const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * WM + i * 32 + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
-                if (m >= p.M || n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                const bool full4 = vec_ok && n + 3 < p.N;
-                if (bias && epi != EPI_F32_PARTIAL) {
-                    if (full4) {
-                        const f32x4 bv = *(const f32x4*)(bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
-                    }
-                }
-                if (epi == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
-                }
-                if (epi <= EPI_BF16_RESID) {
-                    bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
-                    if (full4) {
-                        if (epi == EPI_BF16_RESID) {
-                            const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
-                            const uint32_t r0 = rp[0], r1 = rp[1];
-                            v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                            v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
-                        }
-                        struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
-                        w.a = pack_bf16x2(v[0], v[1]);
-                        w.b = pack_bf16x2(v[2], v[3]);
-                        *(u64*)o = w;
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                            float x = v[e];
-                            if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
-                            o[e] = f32_to_bf16(x);
-                        }
-                    }
-                } else {
-                    float* o = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
-                    if (full4) {
-                        *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) o[e] = v[e];
-                    }
-                }
-            }
+    rq_gemm_epilogue<BM, BN, TR, WGM, WGN, (GL ? GL : 2) * (BM + BN) * 64 * 2>(p, acc, smem, m0, n0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Register-blocked dense GEMM: 256 x 128 tile, FOUR wavefronts (2 x 2) of 128 x 64 each, K-steps of 32 through a ring
+// of NS 24-KB LDS stages filled by LDS-DMA.  The 64 x 64 wave tile of the kernel above reads 1 KB of fragments from
+// LDS per MFMA -- exactly the LDS port's rate at full MFMA rate, so that loop tops out near 50 % of peak; 128 x 64
+// reads 0.75 KB.  128 accumulator registers per lane are affordable here only because LDS-DMA needs no staging
+// registers; the half-depth stage keeps LDS at 72 KB (= the bf16 epilogue tile) so that two workgroups share a CU and
+// one's barrier / LDS latency is covered by the other.  Tile rows are 64 bytes: 16-byte chunk c of row r sits at
+// slot c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 over 16 consecutive rows); the DMA writes lane-linear, so the
+// permutation is applied to each lane's source address.
+template <int TR, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_rb_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NW = 4;
+    constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;                      // 24 KB
+    constexpr int SMEM_BYTES = NS * STAGE_BYTES > BM * (BN * 2 + 16) ? NS * STAGE_BYTES : BM * (BN * 2 + 16);
+    constexpr int A_PER = BM / 16 / NW, B_PER = BN / 16 / NW, PER = A_PER + B_PER;      // 16-row (1 KB) groups per wave
+    RQ_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rq_uniform(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
+    int mt, nt;
+    {   // same XCD-aware schedules as gemm_bf16_kernel
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        if (p.sched == 1) {
+            const int nb = NT >> 3, rem = NT & 7;
+            const int nn = nb + (xcd < rem ? 1 : 0);
+            const int n_lo = xcd * nb + (xcd < rem ? xcd : rem);
+            if (slot >= nn * MT) return;
+            const int per_group = p.sched_gm * nn;
+            const int mg = slot / per_group, r = slot - mg * per_group;
+            int gm = MT - mg * p.sched_gm;
+            gm = gm < p.sched_gm ? gm : p.sched_gm;
+            nt = n_lo + r / gm;
+            mt = mg * p.sched_gm + (r - (r / gm) * gm);
+        } else if (p.sched == 2) {
+            const int mm = (MT + 7) >> 3;
+            mt = xcd * mm + slot / NT;
+            nt = slot - (slot / NT) * NT;
+            if (slot >= mm * NT || mt >= MT) return;
+        } else {
+            mt = id / NT;
+            nt = id - mt * NT;
         }
     }
-        return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt_total = p.K / BK;
+    const int per = (kt_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = (kt0 + per < kt_total) ? kt0 + per : kt_total;
+    const int nk = kt1 - kt0;
+
+    const char* gA = (const char*)p.A;
+    const char* gW = (const char*)p.W;
+    const rq_lds_t lds0 = rq_lds_addr(smem);
+    const int lr = lane >> 2, lc = lane & 3;             // lane fills (row lr of its group, slot lc)
+    unsigned ga[A_PER], gb[B_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) {
+        const int row = (wave * A_PER + q) * 16 + lr;
+        int m = m0 + row;
+        if (m > p.M - 1) m = p.M - 1;
+        ga[q] = ((unsigned)m * p.lda + ((lc ^ ((row >> 2) & 3)) << 3)) * 2u;
     }
-    // TR == 0: untransposed accumulators (row = output row m, col = output column n)
-    if (epi <= EPI_BF16_RESID) {
-        // bf16 outputs: stage the fp32 tile through LDS (reusing the operand buffers) so that global
-        // stores -- and the residual reads -- are row-contiguous 8-byte accesses instead of one scattered
-        // 2-byte access per accumulator register (ablation: the scattered epilogue cost 33-80 % on top of
-        // the main loop on the decoder convs).
-        float* sC = (float*)smem;                  // [HB][BN] fp32 slab of the tile, reusing the operand buffers
-        constexpr int SM_BYTES = (BM + BN) * 64 * 2 * 2;
-        constexpr int NH = (BM * BN * 4 + SM_BYTES - 1) / SM_BYTES;     // passes (1, or 2 for the 256-row tile)
-        constexpr int HB = BM / NH;                                     // rows per pass (multiple of WM)
-        static_assert(HB % WM == 0 && HB * BN * 4 <= SM_BYTES, "epilogue slab must fit the operand buffers");
-        constexpr int QPR = BN / 4;                // float4 groups per row
-        const bool n_vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
 #pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            rq_syncthreads();                      // operand buffers / previous slab are free
-            if (wm * WM >= hh * HB && wm * WM < (hh + 1) * HB) {
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int nl = wn * WN + j * 32 + (lane & 31);
-                        const int n = n0 + nl;
-                        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int ml = wm * WM - hh * HB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                            float v = acc[i][j][r] + bv;
-                            if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
-                            sC[ml * BN + nl] = v;
-                        }
-                    }
-            }
-            rq_syncthreads();
-#pragma unroll 4
-            for (int q = tid; q < HB * QPR; q += NTH) {
-                const int ml = q / QPR, nl = (q - ml * QPR) * 4;
-                const int m = m0 + hh * HB + ml, n = n0 + nl;
-                if (m >= p.M || n >= p.N) continue;
-                f32x4 v = *(const f32x4*)(sC + ml * BN + nl);
-                bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
-                if (n_vec_ok) {
-                    if (epi == EPI_BF16_RESID) {
-                        const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
-                        const uint32_t r0 = rp[0], r1 = rp[1];
-                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
-                    }
-                    uint32_t* op = (uint32_t*)o;
-                    const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);
-                    op[0] = w0;
-                    op[1] = w1;
-                } else {
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                        float x = v[e];
-                        if (epi == EPI_BF16_RESID) x += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
-                        o[e] = f32_to_bf16(x);
-                    }
-                }
-            }
-        }
-        return;
+    for (int q = 0; q < B_PER; ++q) {
+        const int row = (wave * B_PER + q) * 16 + lr;
+        int n = n0 + row;
+        if (n > p.N - 1) n = p.N - 1;
+        gb[q] = ((unsigned)n * p.K + ((lc ^ ((row >> 2) & 3)) << 3)) * 2u;
     }
-    // fp32 outputs: a wavefront store already covers 2 x 128 contiguous bytes
+    auto issue = [&](int kt, int st) {
+        const unsigned kb = (unsigned)kt * (BK * 2);
+        const rq_lds_t base = lds0 + (rq_lds_t)(st * STAGE_BYTES);
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) rq_glds16(base + (rq_lds_t)((wave * A_PER + q) * 1024), gA + (ga[q] + kb));
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) rq_glds16(base + (rq_lds_t)(BM * BK * 2 + (wave * B_PER + q) * 1024), gW + (gb[q] + kb));
+    };
+
+    f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn * WN + j * 32 + (lane & 31);
-            const float bv = (bias && n < p.N && epi != EPI_F32_PARTIAL) ? bias[n] : 0.f;
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M || n >= p.N) continue;
-                const float v = acc[i][j][r] + bv;
-                const long o = (long)m * p.ldo + n;
-                if (epi == EPI_F32) ((float*)p.out)[o] = v;
-                else ((float*)p.out)[(long)blockIdx.z * p.M * p.ldo + o] = v;
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment reads: row = wave tile base + 32 i + (lane & 31), chunk = 2 ks + (lane >> 5)
+    const int frow = lane & 31, fk = lane >> 5;
+    unsigned rd_a[2], rd_b[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned c = (unsigned)(((ks * 2 + fk) ^ ((frow >> 2) & 3)) << 4);
+        rd_a[ks] = (unsigned)((wm * WM + frow) * (BK * 2)) + c;
+        rd_b[ks] = (unsigned)(BM * BK * 2 + (wn * WN + frow) * (BK * 2)) + c;
+    }
+    auto compute = [&](int st) {
+        const char* sb = (const char*)smem + st * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[MI], bfr[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = as_bf16x8(ld128(sb + rd_a[ks] + i * (32 * BK * 2)));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bfr[j] = as_bf16x8(ld128(sb + rd_b[ks] + j * (32 * BK * 2)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = TR ? rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]) : rq_mfma_32x32x16_bf16(af[i], bfr[j], acc[i][j]);
         }
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nk) issue(kt0 + s0, s0);
+        int st = 0;
+        for (int t = 0; t < nk; ++t) {
+            const int newer = nk - 1 - t;                // stages issued after tile t that may still be in flight
+            if (NS >= 4 && newer >= 2) rq_wait_vmcnt<2 * PER>();
+            else if (NS >= 3 && newer >= 1) rq_wait_vmcnt<PER>();
+            else rq_wait_vmcnt<0>();
+            rq_barrier_raw();
+            if (t + NS - 1 < nk) issue(kt0 + t + NS - 1, st == 0 ? NS - 1 : st - 1);
+            compute(st);
+            st = st + 1 == NS ? 0 : st + 1;
+        }
+    }
+    rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0);
 }
 
 // host-side launcher (gemm.hip)

@@ -40,6 +40,39 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
     RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>), grid, dim3(64 * WGM * WGN), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
+// register-blocked 256x128 / 4-wave / BK 32 kernel (gemm.h): dense operands, K % 32 == 0
+template <int TR, int NS>
+static int launch_rb(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = 256, BN = 128;
+    constexpr size_t stage = (size_t)(BM + BN) * 32 * 2, epi = (size_t)BM * (BN * 2 + 16);
+    const size_t smem = NS * stage > epi ? NS * stage : epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_rb_kernel<TR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    GemmArgs g = a;
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    int nblocks;
+    if (NT >= 8 && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6) {
+        g.sched = 2; g.sched_gm = 1;
+        nblocks = 8 * ((MT + 7) / 8) * NT;
+    } else if (NT >= 8) {
+        const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
+        long panel = (long)BM * ktiles * 64 * 2;
+        int gm = (int)((3 << 19) / (panel > 0 ? panel : 1));
+        if (gm < 1) gm = 1;
+        if (gm > MT) gm = MT;
+        g.sched = 1; g.sched_gm = gm;
+        nblocks = 8 * ((NT + 7) / 8) * MT;
+    } else {
+        g.sched = 2; g.sched_gm = 1;
+        nblocks = 8 * ((MT + 7) / 8) * NT;
+    }
+    RQ_LAUNCH((gemm_rb_kernel<TR, NS>), dim3(nblocks, 1, a.splitk), dim3(256), smem, stream, g);
+    return rq_check_launch("gemm_rb_kernel");
+}
+
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     // transposed accumulators (TR = 1) for everything except wide fp32 rows (logits / fp32 activations)
@@ -83,6 +116,10 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
             RQ_GL_CASE(128, 64, 2, 2)
             RQ_GL_CASE(128, 128, 2, 2)
             RQ_GL_CASE(256, 128, 4, 2)
+            if (bm == 257 && bn == 128) {     // tile code 257x128: the register-blocked kernel (4 waves, 128x64 wave tiles, BK 32)
+                if (gl == 2) return tr ? launch_rb<1, 2>(a, stream) : launch_rb<0, 2>(a, stream);
+                return tr ? launch_rb<1, 3>(a, stream) : launch_rb<0, 3>(a, stream);
+            }
 #undef RQ_GL_CASE
         }
     }
@@ -116,6 +153,7 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
         *glds = 2;
         if (N >= 16384 && M >= 512) {                       // classifier: wide N, fp32 rows
             *bm = 256; *bn = 128; *splitk = 1; *glds = M >= 4096 || M < 2048 ? 3 : 2;
+            if (M >= 4096) { *bm = 257; *glds = 2; }        // register-blocked kernel: 267 vs 281 us at M = 4096
             return;
         }
         if (M >= 4096 && N >= 4096) { *bm = 128; *bn = 128; *splitk = 1; return; }                       // qkv, fc1

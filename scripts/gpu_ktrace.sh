@@ -5,7 +5,11 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
 mkdir -p gpurun_out
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/rocprof.log 2>&1
+if [ -n "$RQ_CMD" ]; then
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o trace -- python $R/$RQ_CMD > $R/gpurun_out/rocprof.log 2>&1
+else
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile "$@" > $R/gpurun_out/rocprof.log 2>&1
+fi
 cd $R
 python - <<'PY'
 import sqlite3, glob
