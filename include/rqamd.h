@@ -154,9 +154,11 @@ int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const v
  * [B][Cin][2] (scale, shift): the input is then read as silu(x*scale + shift), i.e. GroupNorm+SiLU fused into the
  * staging (ResnetBlock norm -> swish -> conv, layers.py:100-120).  stats = NULL or fp32 [B][(H/8)*(W/32)][32][2]:
  * per-tile (sum, sum of squares) of the 32 GroupNorm groups of `out` (Cout 128/256/512), taken in the epilogue for
- * the next layer's Normalize.  Needs H % 8 == 0, W % 32 == 0, H >= 64, Cin % 64 == 0, Cout % 128 == 0. */
+ * the next layer's Normalize.  ups != 0: x is [B][H/2][W/2][Cin], read through the nearest 2x upsample of
+ * Upsample.forward (layers.py:31-35; gn and resid must be NULL).  Needs H % 8 == 0, W % 32 == 0, H >= 64,
+ * Cin % 64 == 0, Cout % 128 == 0. */
 int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
-                             int B, int H, int W, int Cin, int Cout, void* out, float* stats, void* stream);
+                             int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream);
 
 /* One launch of the MFMA Decoder.conv_out kernel (modules.py:165-169): x NHWC bf16 [B][H][W][Cin], w fp32
  * [Cout][3][3][Cin] (Cout <= 4), y NCHW fp32 [B][Cout][H][W]; gn as above (norm_out + swish fused into the

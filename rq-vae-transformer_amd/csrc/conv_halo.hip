@@ -31,24 +31,33 @@ struct ConvHaloArgs {
 };
 
 constexpr int HT_H = 8, HT_W = 32;                 // output tile
-constexpr int HP_W = HT_W + 2, HP_N = (HT_H + 2) * HP_W;   // halo patch: 34 x 10 = 340 pixels
+constexpr int HP_W = HT_W + 2;                     // halo patch of the plain conv: 34 x 10 = 340 pixels
 constexpr int H_BN = 128;
 constexpr int H_NTH = 512;
-constexpr int HALO_BYTES = HP_N * 128;             // one 64-channel chunk of the patch (bf16)
 constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
-constexpr int H_IT = (HP_N * 8 + H_NTH - 1) / H_NTH;        // 16-byte chunks of the patch per thread (6)
+constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + 2 * HW_BYTES;     // both variants allocate the plain conv's 119 KB
 
 // LDS byte offset of 16-byte chunk c8 of patch pixel (hy, hx).  The XOR swizzle depends on the patch COLUMN
 // only, so a tap's row shift (and the fragment row i, and the double-buffer index) are plain multiples of 128
 // added to one per-kx base address -- they fold into the ds_read immediate, and the k-step is an XOR of bits
 // 5..6.  (With the swizzle on the linear pixel index every (tap, i, k-step) needed its own address register:
 // 72 of them, which pushed the kernel past 256 VGPRs and into scratch.)
+template <int PW = HP_W>
 static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) {
-    return (unsigned)((hy * HP_W + hx) * 128 + ((c8 ^ ((hx >> 1) & 7)) << 4));
+    return (unsigned)((hy * PW + hx) * 128 + ((c8 ^ ((hx >> 1) & 7)) << 4));
 }
 
-template <int FUSE_GN>
+// UPS = 1: the conv reads its input through a nearest-neighbour 2x upsample (Upsample.forward, layers.py:31-35): x is
+// [B][H/2][W/2][Cin], output pixel (oy, ox) tap (ky, kx) reads source pixel ((oy+ky-1) >> 1, (ox+kx-1) >> 1).  The
+// patch of an 8 x 32 output tile is then only (4+2) x (16+2) source pixels; the fragment address of a lane becomes
+// row wm + ((i+ky+1) >> 1) (still an immediate) and column (lane + kx + 1) >> 1 (one base register per kx).
+template <int FUSE_GN, int UPS>
 __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
+    constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? HT_H / 2 + 2 : HT_H + 2;
+    constexpr int HP_N = PW * PH;                  // patch pixels: 340, or 108 through the upsample
+    constexpr int HALO_BYTES = HP_N * 128;
+    constexpr int H_IT = (HP_N * 8 + H_NTH - 1) / H_NTH;
     RQ_DYN_SMEM(smem);
     char* sH = (char*)smem;                        // [2][HALO_BYTES]
     char* sW = sH + 2 * HALO_BYTES;                // [2][HW_BYTES]
@@ -76,12 +85,13 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         const int q = tid + H_NTH * it;
         const int hp = q >> 3, c8 = q & 7;
         h_in[it] = hp < HP_N;
-        const int hy = hp / HP_W, hx = hp - hy * HP_W;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        h_ok[it] = h_in[it] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-        h_goff[it] = (unsigned)((((long)img * p.H + cy) * p.W + cx) * p.Cin + c8 * 8) * 2u;   // clamped: always readable
-        h_loff[it] = h_in[it] ? halo_lds_off(hy, hx, c8) : 0u;
+        const int hy = hp / PW, hx = hp - hy * PW;
+        const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;                       // source image
+        const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
+        h_ok[it] = h_in[it] && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
+        h_goff[it] = (unsigned)((((long)img * Hs + cy) * Ws + cx) * p.Cin + c8 * 8) * 2u;     // clamped: always readable
+        h_loff[it] = h_in[it] ? halo_lds_off<PW>(hy, hx, c8) : 0u;
     }
     // weight staging: 128 rows x 8 chunks = 1024 chunks, 2 per thread
     const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row and w_row + 64
@@ -164,7 +174,8 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     const unsigned rd_w0 = (unsigned)((wn * 64 + ftx) * 128 + ((fk ^ ((ftx >> 1) & 7)) << 4));
     unsigned rd_h0[3];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) rd_h0[kx] = halo_lds_off(wm * 2, ftx + kx, fk);
+    for (int kx = 0; kx < 3; ++kx)
+        rd_h0[kx] = UPS ? halo_lds_off<PW>(wm, (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * 2, ftx + kx, fk);
 
     auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
         const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES);
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             const char* hb = sH + (ha ^ (unsigned)(ks << 5));
             const char* wb = sW + (wa ^ (unsigned)(ks << 5));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + (i + ky) * (HP_W * 128)));
+            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
             for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
 #pragma unroll
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 
     // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
     constexpr int LDR = H_BN * 2 + 16;
-    static_assert(256 * LDR <= 2 * HALO_BYTES + 2 * HW_BYTES, "epilogue tile must fit");
+    static_assert(256 * LDR <= H_SMEM_BYTES, "epilogue tile must fit");
     char* sT = (char*)smem;
     constexpr int CPR = H_BN / 8;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
@@ -530,23 +541,26 @@ bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
 int rq_conv_halo_stat_tiles(int H, int W) { return (H / HT_H) * (W / HT_W); }
 
 int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
-                        float* stats, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+                        float* stats, int B, int H, int W, int Cin, int Cout, int ups, hipStream_t s) {
     if (stats && Cout != 128 && Cout != 256 && Cout != 512) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: fused statistics need Cout 128/256/512");
     if (!rq_conv_halo_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: shape %dx%d %d->%d", H, W, Cin, Cout);
+    if (ups && (gn || resid)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: the upsample conv takes no GroupNorm / residual");
     if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const size_t smem = 2 * HALO_BYTES + 2 * HW_BYTES;
+    const size_t smem = H_SMEM_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     const int n_mt = B * (H / HT_H) * (W / HT_W), NT = Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (gn) RQ_LAUNCH(conv3x3_halo_kernel<1>, dim3(nblocks), dim3(H_NTH), smem, s, a);
-    else RQ_LAUNCH(conv3x3_halo_kernel<0>, dim3(nblocks), dim3(H_NTH), smem, s, a);
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1>), dim3(nblocks), dim3(H_NTH), smem, s, a);
+    else if (gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0>), dim3(nblocks), dim3(H_NTH), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0>), dim3(nblocks), dim3(H_NTH), smem, s, a);
     return rq_check_launch("conv3x3_halo_kernel");
 }
 
@@ -562,10 +576,10 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
 
 // diagnostics entry (include/rqamd.h)
 extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
-                                        int B, int H, int W, int Cin, int Cout, void* out, float* stats, void* stream) {
+                                        int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
     return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W, Cin,
-                               Cout, (hipStream_t)stream);
+                               Cout, ups, (hipStream_t)stream);
 }
 
 extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,

@@ -28,7 +28,7 @@ struct rqamd_vae {
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
-    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false;
+    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false;
     std::string missing;
 };
 
@@ -52,6 +52,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_halo = getenv("RQAMD_NO_HALO") != nullptr;      // A/B switches (diagnostics)
     h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
+    h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
     *out = h;
     return RQAMD_OK;
 }
@@ -148,11 +149,11 @@ struct VaeRun {
         int Hout = Hin, Wout = Win, pad = ks / 2;
         if (stride == 2) { Hout = Hin / 2; Wout = Win / 2; pad = 0; }      // F.pad(0,1,0,1) + conv(s2, p0), layers.py:50-54
         // high-resolution 3x3 / stride-1 layers: halo-reuse kernel (one patch staged per 64-channel chunk, 9 taps)
-        if (ks == 3 && stride == 1 && !ups && (epi == EPI_BF16 || epi == EPI_BF16_RESID) && !h->no_halo &&
-            rq_conv_halo_supported(Hin, Win, Cin, Cout)) {
+        if (ks == 3 && stride == 1 && (!ups || (epi == EPI_BF16 && !h->no_halo_ups)) && (epi == EPI_BF16 || epi == EPI_BF16_RESID) &&
+            !h->no_halo && rq_conv_halo_supported(Hin, Win, Cin, Cout)) {
             const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(Hin, Win);
             err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst,
-                                      st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, st);
+                                      st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, ups, st);
             stats_of = st_ok ? (const bf16_t*)dst : nullptr;
             stats_n = st_ok ? rq_conv_halo_stat_tiles(Hin, Win) : 0;
             return;
@@ -195,7 +196,7 @@ struct VaeRun {
             if (err) return;
             const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(H, W);
             err = rq_launch_conv_halo(src, w, b, h->gnp.as<float>(), epi == EPI_BF16_RESID ? resid : nullptr, dst,
-                                      st_ok ? h->part.as<float>() : nullptr, B, H, W, Cin, Cout, st);
+                                      st_ok ? h->part.as<float>() : nullptr, B, H, W, Cin, Cout, 0, st);
             stats_of = st_ok ? dst : nullptr;
             stats_n = st_ok ? rq_conv_halo_stat_tiles(H, W) : 0;
             return;

@@ -13,10 +13,11 @@ int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int
 int rq_launch_gn_stats(const bf16_t* x, float* part, int B, int HW, int C, int* nchunk_out, hipStream_t s);
 // conv_halo.hip: halo-reuse 3x3 conv with optional fused GroupNorm+SiLU on the input
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout);
-// stats != null: the epilogue also writes the GroupNorm partials of `out` ([B][rq_conv_halo_stat_tiles][32][2])
+// stats != null: the epilogue also writes the GroupNorm partials of `out` ([B][rq_conv_halo_stat_tiles][32][2]);
+// ups != 0: x is [B][H/2][W/2][Cin] and is read through a nearest 2x upsample (gn and resid must be null)
 int rq_conv_halo_stat_tiles(int H, int W);
 int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
-                        float* stats, int B, int H, int W, int Cin, int Cout, hipStream_t s);
+                        float* stats, int B, int H, int W, int Cin, int Cout, int ups, hipStream_t s);
 // MFMA conv_out (Cin -> Cout <= 4, NCHW fp32 image out) with optional fused GroupNorm+SiLU of norm_out
 bool rq_conv_out_halo_supported(int H, int W, int Cin, int Cout);
 int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, const float* gn, float* y, int B, int H, int W,

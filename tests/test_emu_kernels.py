@@ -265,6 +265,13 @@ def test_emu_conv_halo(nat):
     t = out.reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32).astype(np.float64)
     want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
     assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max()
+    # Upsample.conv (layers.py:31-35): nearest 2x folded into the patch staging; 32x32 source -> 64x64 output
+    xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
+    xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
+    ref_up = conv2d(xu, wf, bias.numpy())
+    out = nat.dbg_conv_halo(xs, w, bias, ups=True).float().numpy()
+    assert out.shape == (B, H, W, Cout)
+    assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max()
 
 
 def test_emu_conv_out_mfma(nat):

@@ -407,6 +407,12 @@ def test_conv_kernels_vs_torch(nat):
         t = out.double().reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32)
         want = torch.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
         assert float((stats.double() - want).abs().max()) < 1e-3 * float(want.abs().max())
+        # the same conv through a folded nearest 2x upsample (Upsample.forward)
+        xs = rn(B, H // 2, W // 2, Cin).to(torch.bfloat16)
+        xu = F.interpolate(xs.float().permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest')
+        ref = F.conv2d(xu, wt, bias, padding=1).permute(0, 2, 3, 1)
+        out = nat.dbg_conv_halo(xs, w, bias, ups=True).float()
+        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
     for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (1, 64, 64, 256)):
         x = rn(B, H, W, Cin).to(torch.bfloat16)
         w = rn(3, 3, 3, Cin, scale=0.05)
