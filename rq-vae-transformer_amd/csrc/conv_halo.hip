@@ -15,6 +15,7 @@
 // shift of the pixel index, XOR-swizzled like gemm.h's tiles (conflict-free ds_read_b128).
 // 8 wavefronts (4 x 2), wave tile 64 pixels x 64 channels, transposed accumulators and the packed-bf16
 // LDS epilogue of gemm.h.  Used when H % 8 == 0, W % 32 == 0, Cin % 64 == 0, Cout % 128 == 0.
+#include <type_traits>
 #include "gemm.h"
 #include "rq_common.h"
 #include "vae_kernels.h"
@@ -216,20 +217,37 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     store_w(0, rw[0]);
     rq_syncthreads();
     int wbuf = 0;
-    for (int c = 0; c < NC; ++c) {
+    // residual tile (epilogue operand): its 8 pieces per thread are fetched during the LAST chunk's taps, where the
+    // patch registers would otherwise reload a chunk nobody needs, so the epilogue starts with the data in hand
+    // (its global round trip was exposed: one workgroup per CU, nothing else to run meanwhile)
+    constexpr int CPR = H_BN / 8;
+    constexpr int R_IT = 256 * CPR / H_NTH;        // 8
+    rq_u128 rr[R_IT];
+    const bf16_t* rsrc = p.resid;
+    // one chunk of the reduction; LAST (compile time): no next patch to stage -- fetch the residual instead
+    auto run_chunk = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int hbuf = c & 1;
-        const bool more_c = c + 1 < NC;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             // prefetch: unit g+3 into the set unit g just left; next chunk's halo patch once, a few taps ahead
             load_unit(c, tap + 3, rw[tap % 3]);
-            if (tap == 0) load_halo(more_c ? c + 1 : c, rh);
+            if (!LAST && tap == 0) load_halo(c + 1, rh);
+            if (LAST && tap == 2 && p.resid) {             // uniform; one conservative vmcnt drain per workgroup at worst
+#pragma unroll
+                for (int k = 0; k < R_IT; ++k) {
+                    const int cidx = tid + H_NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+                    const int ty = ml / HT_W, tx = ml - ty * HT_W;
+                    const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+                    rr[k] = ld128(rsrc + pix * p.Cout + n0 + nl);
+                }
+            }
             rq_sched_barrier();
             // next chunk's patch: pieces 0..5 in taps 3..8 (the loads were issued three taps earlier).  The fused
             // GroupNorm+SiLU arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no
             // fence in between) so that its VALU / transcendental instructions issue in the MFMAs' shadow.
-            const bool piece = tap >= 9 - H_IT;
+            const bool piece = !LAST && tap >= 9 - H_IT;
             const int it = piece ? tap - (9 - H_IT) : 0;
             rq_u128 pv = zero128();
             if (piece) pv = halo_piece_value(rh, it);
@@ -244,24 +262,23 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             rq_syncthreads();
             wbuf ^= 1;
         }
-    }
+    };
+    for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
+    run_chunk(NC - 1, std::true_type{});
 
     // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
     constexpr int LDR = H_BN * 2 + 16;
     static_assert(256 * LDR <= H_SMEM_BYTES, "epilogue tile must fit");
     char* sT = (char*)smem;
-    constexpr int CPR = H_BN / 8;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
     if (p.resid) {
-        // the residual tile comes in as row-contiguous 16-byte loads and waits in the LDS tile, where the lane that
-        // owns an 8-byte slot adds it in fp32 before the single rounding and overwrites it in place (the per-lane
-        // 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
-#pragma unroll 4
-        for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
-            const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-            const int ty = ml / HT_W, tx = ml - ty * HT_W;
-            const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-            st128(sT + ml * LDR + nl * 2, ld128(p.resid + pix * p.Cout + n0 + nl));
+        // the residual tile (fetched as row-contiguous 16-byte pieces during the last taps) waits in the LDS tile, where
+        // the lane that owns an 8-byte slot adds it in fp32 before the single rounding and overwrites it in place (the
+        // per-lane 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
+#pragma unroll
+        for (int k = 0; k < R_IT; ++k) {
+            const int cidx = tid + H_NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+            st128(sT + ml * LDR + nl * 2, rr[k]);
         }
         rq_syncthreads();
     }
