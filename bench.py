@@ -194,6 +194,22 @@ def main():
                              'algorithmic_GB_per_batch': pf['gemm_bytes'] / 1e9, 'algorithmic_TFLOP_per_batch': pf['gemm_flops'] / 1e12,
                              'achieved_GBps': gbs, 'achieved_TFLOPs': tfl, 'flop_per_byte': intensity})
 
+    # ---- BASELINE.json's second metric, codes/sec of the RQ-VAE (encode + residual quantisation), outside the timed region
+    enc = None
+    if rank == 0 and not args.no_profile:
+        xb = torch.randn((256, 3, 256, 256), device=device).clamp(-1, 1)
+        vae.get_codes(xb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            vae.get_codes(xb)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        enc = {'codes_per_sec': 256 * 256 / ms * 1e3, 'images_per_sec': 256 / ms * 1e3, 'batch': 256,
+               'what': 'RQVAE.get_codes: 256x256 encode + depth-4 residual quantisation (K=16384), 256 codes per image'}
+        del xb
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -216,7 +232,7 @@ def main():
                        'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather per step' if world > 1 else 'single GPU',
                        'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU'},
             'ar_ms_per_image': t_ar / (args.steps * B), 'decode_ms_per_image': t_dec / (args.steps * B),
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

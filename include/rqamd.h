@@ -166,6 +166,10 @@ int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, co
 int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,
                             int Cin, int Cout, float* y, void* stream);
 
+/* One launch of the MFMA Encoder.conv_in kernel (modules.py:23-27): x NCHW fp32 [B][3][H][W], w fp32 [3][3][3][128]
+ * = (ky, kx, ci, cout), y NHWC bf16 [B][H][W][128].  Needs H % 8 == 0, W % 32 == 0. */
+int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, int B, int H, int W, void* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -529,6 +529,128 @@ int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, 
     return rq_check_launch("conv_out_halo_kernel");
 }
 
+// -------------------------------------------------------------------------------------------------
+// Encoder.conv_in (modules.py:23-27 of the reference): 3 -> 128 channels at full resolution, NCHW fp32 image in,
+// NHWC bf16 out.  K = 27 is padded to 32 = two MFMA k-steps; the A fragment of a pixel is gathered from an fp32
+// patch of the image in LDS through a 32-entry offset table (k -> (ci, ky, kx), entries 27..31 point at a zero),
+// the weights sit in LDS as bf16 [128][32].  The VALU version (conv_in3_kernel) read one LDS weight per FMA:
+// 40 us per image, 12 % of the encoder; this one is bound by writing the 16.8 MB output.
+struct ConvInArgs {
+    const float* x;         // NCHW [B][3][H][W]
+    const float* w;         // [ky][kx][ci][Cout] fp32 (repacked conv_in weight)
+    const float* bias;      // [Cout]
+    bf16_t* y;              // NHWC [B][H][W][Cout]
+    int B, H, W;
+};
+constexpr int CI_COUT = 128, CI_PATCH = 3 * (HT_H + 2) * HP_W;        // 1020 floats (+ zero slot)
+constexpr int CI_WROW = 80;                                            // bytes per weight row: 32 bf16 + 16 pad
+constexpr int CI_STG = 32 * (CI_COUT * 2 + 16);                        // per-wave output staging: 32 pixels x 272 B
+
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInArgs p) {
+    RQ_DYN_SMEM(smem);
+    float* sP = (float*)smem;                                          // [3][10][34] + zero slot (+ pad to 16 B)
+    int* sK = (int*)(smem + 4096);                                     // [32] patch offset of k (row 0, column 0)
+    char* sWt = (char*)smem + 4096 + 128;                              // [128][CI_WROW]
+    char* sO = sWt + CI_COUT * CI_WROW;                                // [4 waves][CI_STG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / HT_H;
+    const int tile = blockIdx.x;
+    const int img = tile / (tiles_y * tiles_x), trem = tile - img * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * HT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+
+    for (int i = tid; i < CI_PATCH + 4; i += 256) {
+        float v = 0.f;
+        if (i < CI_PATCH) {
+            const int ci = i / ((HT_H + 2) * HP_W), r = i - ci * ((HT_H + 2) * HP_W);
+            const int hy = r / HP_W, hx = r - hy * HP_W;
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.x[(((long)img * 3 + ci) * p.H + gy) * p.W + gx];
+        }
+        sP[i] = v;
+    }
+    if (tid < 32) {
+        const int k = tid, tap = k / 3, ci = k - tap * 3, ky = tap / 3, kx = tap - ky * 3;
+        sK[k] = k < 27 ? ci * ((HT_H + 2) * HP_W) + ky * HP_W + kx : -1;
+    }
+    for (int i = tid; i < CI_COUT * 16; i += 256) {                    // two k per thread-iteration
+        const int co = i >> 4, k2 = (i & 15) * 2;
+        const float a = k2 < 27 ? p.w[k2 * CI_COUT + co] : 0.f, b = k2 + 1 < 27 ? p.w[(k2 + 1) * CI_COUT + co] : 0.f;
+        *(uint32_t*)(sWt + co * CI_WROW + k2 * 2) = pack_bf16x2(a, b);
+    }
+    rq_syncthreads();
+
+    const int px = lane & 31, g = lane >> 5;
+    int koff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) koff[ks][e] = sK[ks * 16 + g * 8 + e];
+    bf16x8 bfr[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[ks][j] = as_bf16x8(ld128(sWt + (j * 32 + px) * CI_WROW + (ks * 16 + g * 8) * 2));
+    char* stg = sO + wave * CI_STG;
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+        const int row = wave * 2 + i;                                  // output row of the tile
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = koff[ks][e] >= 0 ? sP[koff[ks][e] + row * HP_W + px] : 0.f;
+            rq_u128 u;
+            u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+            u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+            const bf16x8 af = as_bf16x8(u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = rq_mfma_32x32x16_bf16(bfr[ks][j], af, acc[j]);   // D[cout][pixel]
+        }
+        // lane (px, g) holds couts j*32 + 8q + 4g .. +3 in acc[j][4q..4q+3]: 8-byte pieces into the wave's staging tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = j * 32 + 8 * q + 4 * g;
+                const f32x4 bv = *(const f32x4*)(p.bias + co);
+                struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
+                w2.a = pack_bf16x2(acc[j][4 * q] + bv[0], acc[j][4 * q + 1] + bv[1]);
+                w2.b = pack_bf16x2(acc[j][4 * q + 2] + bv[2], acc[j][4 * q + 3] + bv[3]);
+                *(u64*)(stg + px * (CI_COUT * 2 + 16) + co * 2) = w2;
+            }
+        rq_syncthreads();                                              // (a wave-level sync would do; all waves run both rows)
+        const long pix0 = ((long)img * p.H + ty0 + row) * p.W + tx0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = lane + 64 * k, opx = c >> 4, part = c & 15;
+            st128(p.y + (pix0 + opx) * CI_COUT + part * 8, ld128(stg + opx * (CI_COUT * 2 + 16) + part * 16));
+        }
+        rq_syncthreads();
+    }
+}
+
+bool rq_conv_in_mfma_supported(int H, int W, int Cin, int Cout) {
+    return Cin == 3 && Cout == CI_COUT && H % HT_H == 0 && W % HT_W == 0;
+}
+
+int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, hipStream_t s) {
+    ConvInArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W;
+    const size_t smem = 4096 + 128 + (size_t)CI_COUT * CI_WROW + 4 * (size_t)CI_STG;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv_in_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    RQ_LAUNCH(conv_in_mfma_kernel, dim3((unsigned)(B * (H / HT_H) * (W / HT_W))), dim3(256), smem, s, a);
+    return rq_check_launch("conv_in_mfma_kernel");
+}
+
 // (scale, shift) per (image, channel) from the GroupNorm partial statistics of gn_stats_kernel
 __global__ void gn_params_kernel(const float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
                                  int nchunk, float eps) {
@@ -603,4 +725,10 @@ extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const floa
                                        int Cin, int Cout, float* y, void* stream) {
     if (!x || !w || !bias || !y) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_out: null argument");
     return rq_launch_conv_out_halo((const bf16_t*)x, w, bias, gn, y, B, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+extern "C" int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, int B, int H, int W, void* y, void* stream) {
+    if (!x || !w || !bias || !y) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_in: null argument");
+    if (!rq_conv_in_mfma_supported(H, W, 3, CI_COUT)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "dbg_conv_in: shape %dx%d", H, W);
+    return rq_launch_conv_in_mfma(x, w, bias, (bf16_t*)y, B, H, W, (hipStream_t)stream);
 }

@@ -314,7 +314,8 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
         const float* w = (const float*)r.P("encoder.conv_in.weight");
         const float* b = (const float*)r.P("encoder.conv_in.bias");
         if (r.err) return r.err;
-        RQ_TRY(rq_launch_conv_in3(x, w, b, r.X, B, res, res, c.in_channels, c.ch, st));
+        if (!h->no_halo && rq_conv_in_mfma_supported(res, res, c.in_channels, c.ch)) RQ_TRY(rq_launch_conv_in_mfma(x, w, b, r.X, B, res, res, st));
+        else RQ_TRY(rq_launch_conv_in3(x, w, b, r.X, B, res, res, c.in_channels, c.ch, st));
     }
     int block_in = c.ch;
     for (int l = 0; l < nl; ++l) {

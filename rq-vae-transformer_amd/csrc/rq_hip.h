@@ -109,6 +109,9 @@ static __device__ __forceinline__ float rq_dpp_ror8(float v) { return rq_dpp<0x1
 static __device__ __forceinline__ float rq_readlane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// makes `x` opaque to the optimiser at this point (keeps loop-invariant address arithmetic from being hoisted out of a
+// persistent tile loop, where it would hold dozens of registers across the whole main loop)
+static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v"(x)); }
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

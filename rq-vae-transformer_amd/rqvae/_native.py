@@ -61,6 +61,7 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_dbg_conv_in_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_conv_out_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]),
 }
@@ -211,6 +212,15 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
     check(lib().rqamd_dbg_conv_halo_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias, torch.float32), ptr(gn), ptr(resid),
                                          B, H, W, Cin, Cout, 1 if ups else 0, ptr(out), ptr(stats), stream_of(x)))
     return out
+
+
+def dbg_conv_in(x, w, bias):
+    """diagnostics: MFMA conv_in; x (B,3,H,W) fp32, w (3,3,3,128) fp32 = (ky,kx,ci,cout), returns (B,H,W,128) bf16."""
+    B, _, H, W = x.shape
+    y = torch.empty((B, H, W, 128), dtype=torch.bfloat16, device=x.device)
+    check(lib().rqamd_dbg_conv_in_bf16(ptr(x, torch.float32), ptr(w, torch.float32), ptr(bias, torch.float32), B, H, W, ptr(y),
+                                       stream_of(x)))
+    return y
 
 
 def dbg_conv_out(x, w, bias, gn=None):

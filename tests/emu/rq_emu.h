@@ -144,6 +144,7 @@ static inline unsigned long long rq_ballot(bool pred) {
 }
 static inline int rq_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 static inline void rq_threadfence_block() {}
+static inline void rq_opaque(int&) {}
 static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
 static inline float rq_fast_exp2(float x) { return exp2f(x); }

@@ -274,6 +274,22 @@ def test_emu_conv_halo(nat):
     assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max()
 
 
+def test_emu_conv_in_mfma(nat):
+    """Encoder.conv_in as an MFMA kernel: NCHW fp32 image -> NHWC bf16, K = 27 padded to 32, image borders."""
+    from oracle.vae import conv2d
+    rng = np.random.default_rng(8)
+    B, H, W = 2, 16, 32
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    w = (0.2 * rng.standard_normal((128, 3, 3, 3))).astype(np.float32)         # (cout, ci, ky, kx) like nn.Conv2d
+    bias = rng.standard_normal(128).astype(np.float32)
+    bf = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).float().numpy()
+    ref = conv2d(bf(np.transpose(x, (0, 2, 3, 1))), bf(w), bias)              # NHWC in, (cout, ci, ky, kx) weights
+    w_k = np.ascontiguousarray(np.transpose(w, (2, 3, 1, 0)))                  # (ky, kx, ci, cout)
+    out = nat.dbg_conv_in(T(x), T(w_k), T(bias)).float().numpy()
+    assert out.shape == (B, H, W, 128)
+    assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
+
+
 def test_emu_conv_out_mfma(nat):
     """Decoder.conv_out as an MFMA halo kernel (csrc/conv_halo.hip): Cin -> 3, NCHW fp32 out, optional fused
     norm_out GroupNorm+SiLU; image borders, two channel planes, against the oracle's conv2d."""

@@ -413,6 +413,13 @@ def test_conv_kernels_vs_torch(nat):
         ref = F.conv2d(xu, wt, bias, padding=1).permute(0, 2, 3, 1)
         out = nat.dbg_conv_halo(xs, w, bias, ups=True).float()
         assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
+    # MFMA Encoder.conv_in: NCHW fp32 image -> NHWC bf16
+    x = rn(2, 3, 256, 256).clamp(-1, 1)
+    w = rn(128, 3, 3, 3, scale=0.2)
+    bias = rn(128)
+    ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, padding=1).permute(0, 2, 3, 1)
+    out = nat.dbg_conv_in(x, w.permute(2, 3, 1, 0).contiguous(), bias).float()
+    assert float((out - ref).abs().max()) < 1e-2 * float(ref.abs().max())
     for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (1, 64, 64, 256)):
         x = rn(B, H, W, Cin).to(torch.bfloat16)
         w = rn(3, 3, 3, Cin, scale=0.05)
