@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 4096)), help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 8192)), help='images per GPU per step')
     ap.add_argument('--model', default='huge')
     # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
     ap.add_argument('--top-k', type=int, default=1024)

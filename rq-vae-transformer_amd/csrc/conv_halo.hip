@@ -651,26 +651,42 @@ int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf
     return rq_check_launch("conv_in_mfma_kernel");
 }
 
-// (scale, shift) per (image, channel) from the GroupNorm partial statistics of gn_stats_kernel
-__global__ void gn_params_kernel(const float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
-                                 int nchunk, float eps) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= B * C) return;
-    const int b = gid / C, ch = gid - b * C, g = ch / (C / 32);
+// (scale, shift) per (image, channel) from the GroupNorm partial statistics (gn_stats_kernel or a conv epilogue): one
+// workgroup per image; thread (slice = t >> 5, group = t & 31) sums every 8th partial of its group, the slices are
+// folded in a fixed order through LDS, then the 256 threads write the per-channel pairs.  (One thread per channel
+// walking all partials serially took 45 us per launch with 256 partials per image.)
+__global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const float* gamma, const float* beta, float* gn, int B, int HW,
+                                                        int C, int nchunk, float eps) {
+    __shared__ float sa[8][32], sq[8][32], smean[32], srstd[32];
+    const int b = blockIdx.x, tid = threadIdx.x, g = tid & 31, sl = tid >> 5;
     float a = 0.f, q = 0.f;
-    for (int c = 0; c < nchunk; ++c) {
+    for (int c = sl; c < nchunk; c += 8) {
         const float* o = part + (((long)b * nchunk + c) * 32 + g) * 2;
         a += o[0];
         q += o[1];
     }
-    const float n = (float)HW * (float)(C / 32);
-    const float mean = a / n;
-    float var = q / n - mean * mean;
-    if (var < 0.f) var = 0.f;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    const float sc = rstd * gamma[ch];
-    gn[(long)gid * 2] = sc;
-    gn[(long)gid * 2 + 1] = beta[ch] - mean * sc;
+    sa[sl][g] = a;
+    sq[sl][g] = q;
+    rq_syncthreads();
+    if (tid < 32) {
+        float ta = 0.f, tq = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ta += sa[k][tid]; tq += sq[k][tid]; }
+        const float n = (float)HW * (float)(C / 32);
+        const float mean = ta / n;
+        float var = tq / n - mean * mean;
+        if (var < 0.f) var = 0.f;
+        smean[tid] = mean;
+        srstd[tid] = 1.0f / sqrtf(var + eps);
+    }
+    rq_syncthreads();
+    const int cpg = C / 32;
+    for (int ch = tid; ch < C; ch += 256) {
+        const int gg = ch / cpg;
+        const float sc = srstd[gg] * gamma[ch];
+        gn[((long)b * C + ch) * 2] = sc;
+        gn[((long)b * C + ch) * 2 + 1] = beta[ch] - smean[gg] * sc;
+    }
 }
 
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
@@ -708,8 +724,7 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
                         int nchunk_have, hipStream_t s) {
     int nchunk = nchunk_have;
     if (nchunk <= 0) RQ_TRY(rq_launch_gn_stats(x, part, B, HW, C, &nchunk, s));
-    const int n = B * C;
-    RQ_LAUNCH(gn_params_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, gamma, beta, gn, B, HW, C, nchunk, 1e-6f);
+    RQ_LAUNCH(gn_params_kernel, dim3(B), dim3(256), 0, s, part, gamma, beta, gn, B, HW, C, nchunk, 1e-6f);
     return rq_check_launch("gn_params_kernel");
 }
 

@@ -156,6 +156,11 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
             if (M >= 4096) { *bm = 257; *glds = 2; }        // register-blocked kernel: 267 vs 281 us at M = 4096
             return;
         }
+        if (M >= 8192) {                                    // M = 8192 sweep: rb kernel for the widest N, 128x128 otherwise
+            *splitk = 1;
+            if (N >= 6144) { *bm = 257; *bn = 128; } else { *bm = 128; *bn = 128; }
+            return;
+        }
         if (M >= 4096 && N >= 4096) { *bm = 128; *bn = 128; *splitk = 1; return; }                       // qkv, fc1
         if (M >= 2048 && allow_splitk && K >= 4096 && N <= 2048) {                                       // fc2
             *bm = 256; *bn = 128; *splitk = M >= 4096 ? 1 : 2; *glds = 3;

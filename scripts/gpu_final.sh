@@ -23,4 +23,4 @@ for f in glob.glob('gpurun_out/prof/**/*.db', recursive=True) + glob.glob('gpuru
     break
 PY
 rm -rf gpurun_out/prof
-RQ_M=4096 bash scripts/gpu_pmc2.sh > /dev/null 2>&1; cp gpurun_out/gemm_traffic.json gpurun_out/gemm_traffic_m4096.json
+RQ_M=8192 bash scripts/gpu_pmc2.sh > /dev/null 2>&1; cp gpurun_out/gemm_traffic.json gpurun_out/gemm_traffic_m8192.json
