@@ -9,11 +9,7 @@ src = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/gemm_traffic.json'
 t = json.load(open(src))
 shapes = [('qkv', 4608, 1536, 2, 4224), ('proj (split-K slabs)', 1536, 1536, 4, 4224), ('fc1', 6144, 1536, 2, 4224),
           ('fc2 (split-K slabs)', 1536, 6144, 4, 4224), ('classifier', 16384, 1536, 4, 256)]
-if len(t) == 4:      # proj and fc2 ran the same kernel instantiation with the same grid: one merged PMC row (mean of both)
-    t = [t[0], t[1], t[2], t[1], t[3]]
-    merged = True
-else:
-    merged = False
+merged = False
 assert len(t) == len(shapes), (len(t), 'PMC rows; expected one per GEMM shape in launch order')
 out = {'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over scripts/gemm_traffic.py on MI355X; '
                  'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads, '
