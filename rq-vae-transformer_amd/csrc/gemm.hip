@@ -15,9 +15,10 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
     GemmArgs g = a;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     int nblocks;
-    if (getenv("RQAMD_GEMM_SCHED0")) {
+    static const bool env_sched0 = getenv("RQAMD_GEMM_SCHED0") != nullptr, env_sched1 = getenv("RQAMD_GEMM_SCHED1") != nullptr;   // A/B switches
+    if (env_sched0) {
         g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
-    } else if (NT >= 8 && !a.conv && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6 && !getenv("RQAMD_GEMM_SCHED1")) {
+    } else if (NT >= 8 && !a.conv && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6 && !env_sched1) {
         // dense, weights much smaller than activations (fc2 at large batch): give every XCD a band of m-tiles instead.
         // An XCD then streams its own slice of A once and all of W (N*K bytes, 8x in total) rather than all of A
         // (M*K bytes, 8x): PMC showed 446 MB per fc2 launch at M=4096 against 94 MB algorithmic with n-ranges, 226 MB

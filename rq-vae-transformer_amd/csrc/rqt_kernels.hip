@@ -1060,7 +1060,8 @@ int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
         attr_done = true;
     }
     SampleArgs b = a;
-    if (a.top_k > 0 && a.top_k < a.V && a.V <= SMP_T * SMP_VPT && a.V % 4 == 0 && a.redo && !getenv("RQAMD_SAMPLER_LDS")) {
+    static const bool env_lds_only = getenv("RQAMD_SAMPLER_LDS") != nullptr;      // A/B switch
+    if (a.top_k > 0 && a.top_k < a.V && a.V <= SMP_T * SMP_VPT && a.V % 4 == 0 && a.redo && !env_lds_only) {
         // top-k on: register-resident kernel; rows it cannot finish (more than SMP_CAP keys tied into the top k, NaN
         // threshold) are flagged in a.redo and redone by the general kernel, whose other workgroups exit at once
         RQ_LAUNCH(sample_topk_kernel, dim3(a.rows), dim3(SMP_T), 0, s, a);
