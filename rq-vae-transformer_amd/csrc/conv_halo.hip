@@ -15,6 +15,7 @@
 // shift of the pixel index, XOR-swizzled like gemm.h's tiles (conflict-free ds_read_b128).
 // 8 wavefronts (4 x 2), wave tile 64 pixels x 64 channels, transposed accumulators and the packed-bf16
 // LDS epilogue of gemm.h.  Used when H % 8 == 0, W % 32 == 0, Cin % 64 == 0, Cout % 128 == 0.
+#include <stdlib.h>
 #include <type_traits>
 #include "gemm.h"
 #include "rq_common.h"
@@ -52,21 +53,34 @@ static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) 
 // [B][H/2][W/2][Cin], output pixel (oy, ox) tap (ky, kx) reads source pixel ((oy+ky-1) >> 1, (ox+kx-1) >> 1).  The
 // patch of an 8 x 32 output tile is then only (4+2) x (16+2) source pixels; the fragment address of a lane becomes
 // row wm + ((i+ky+1) >> 1) (still an immediate) and column (lane + kx + 1) >> 1 (one base register per kx).
-template <int FUSE_GN, int UPS>
-__global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
+// TH = tile height: 8 (eight wavefronts, 4 x 2; double-buffered patch, 119 KB of LDS, one workgroup per CU) or 4 (four
+// wavefronts, 2 x 2; single patch buffer, 58 KB, TWO workgroups per CU).  Within a workgroup the phases are serial --
+// staging, LDS reads + MFMA and the epilogue each wait for the workgroup's barriers (ablation: 85 + 95 + 50 us of a
+// 230 us launch, nearly additive) -- so two independent workgroups per CU let one's staging / epilogue run under the
+// other's MFMAs.  The price: a 6 x 34 patch per 4 x 32 tile (1.59x the interior instead of 1.33x), every weight tile
+// staged for half as many pixels, and an extra barrier per chunk (the patch buffer is refilled in place).
+template <int FUSE_GN, int UPS, int TH>
+__global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    constexpr int NTH = TH * 64;                   // threads: one wavefront per (row pair, cout half)
+    constexpr int NB_H = TH == 8 ? 2 : 1;          // patch buffers
+    constexpr int W_IT = 1024 / NTH;               // 16-byte chunks of a weight tile per thread
+    constexpr int TPX = TH * HT_W;                 // pixels per tile
+    // with two workgroups per CU the other one covers global latency: shallow prefetch, fewer registers (<= 256 needed)
+    constexpr int W_SETS = TH == 8 ? 3 : 1;        // weight tiles in flight (register sets)
+    constexpr bool RPRE = TH == 8;                 // residual tile prefetched into registers during the last taps
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
-    constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? HT_H / 2 + 2 : HT_H + 2;
+    constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
     constexpr int HP_N = PW * PH;                  // patch pixels: 340, or 108 through the upsample
     constexpr int HALO_BYTES = HP_N * 128;
-    constexpr int H_IT = (HP_N * 8 + H_NTH - 1) / H_NTH;
+    constexpr int H_IT = (HP_N * 8 + NTH - 1) / NTH;
     RQ_DYN_SMEM(smem);
     char* sH = (char*)smem;                        // [2][HALO_BYTES]
-    char* sW = sH + 2 * HALO_BYTES;                // [2][HW_BYTES]
+    char* sW = sH + NB_H * HALO_BYTES;             // [2][HW_BYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 wavefronts: rows (tile y pairs) x cout halves
+    const int wm = wave >> 1, wn = wave & 1;       // (TH/2) x 2 wavefronts: rows (tile y pairs) x cout halves
 
     // ---- tile decode: contiguous band of tiles per XCD (neighbouring tiles share halo rows in that L2)
-    const int tiles_x = p.W / HT_W, tiles_y = p.H / HT_H, NT = p.Cout / H_BN;
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
     const int n_mt = p.B * tiles_y * tiles_x;
     const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
     const int per = (n_mt + 7) >> 3;
@@ -75,7 +89,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     if (slot >= per * NT || mtile >= n_mt) return;
     const int img = mtile / (tiles_y * tiles_x);
     const int trem = mtile - img * (tiles_y * tiles_x);
-    const int ty0 = (trem / tiles_x) * HT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
     const int n0 = nt * H_BN;
 
     // ---- halo staging bookkeeping (loop-invariant): byte offsets from x, validity, LDS offsets
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     bool h_in[H_IT], h_ok[H_IT];
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
-        const int q = tid + H_NTH * it;
+        const int q = tid + NTH * it;
         const int hp = q >> 3, c8 = q & 7;
         h_in[it] = hp < HP_N;
         const int hy = hp / PW, hx = hp - hy * PW;
@@ -94,12 +108,12 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         h_goff[it] = (unsigned)((((long)img * Hs + cy) * Ws + cx) * p.Cin + c8 * 8) * 2u;     // clamped: always readable
         h_loff[it] = h_in[it] ? halo_lds_off<PW>(hy, hx, c8) : 0u;
     }
-    // weight staging: 128 rows x 8 chunks = 1024 chunks, 2 per thread
-    const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row and w_row + 64
-    unsigned w_goff[2], w_loff[2];
+    // weight staging: 128 rows x 8 chunks = 1024 chunks, W_IT per thread
+    const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row + (NTH / 8) i
+    unsigned w_goff[W_IT], w_loff[W_IT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = w_row + 64 * i;
+    for (int i = 0; i < W_IT; ++i) {
+        const int r = w_row + (NTH / 8) * i;
         w_goff[i] = (unsigned)(((long)(n0 + r) * 9 * p.Cin + w_c8 * 8) * 2);
         w_loff[i] = (unsigned)(r * 128 + ((w_c8 ^ ((r >> 1) & 7)) << 4));
     }
@@ -154,12 +168,12 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     };
     auto load_w = [&](int c, int tap, rq_u128* rw) {
         const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
-        rw[0] = ld128(gWt + (w_goff[0] + kb));
-        rw[1] = ld128(gWt + (w_goff[1] + kb));
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
     };
     auto store_w = [&](int buf, const rq_u128* rw) {
-        st128(sW + buf * HW_BYTES + w_loff[0], rw[0]);
-        st128(sW + buf * HW_BYTES + w_loff[1], rw[1]);
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) st128(sW + buf * HW_BYTES + w_loff[i], rw[i]);
     };
 
     f32x16 acc[2][2];
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // Weight tiles are prefetched THREE (chunk, tap) units ahead through a rotating set of registers (unit g lives
     // in set g % 3; 9 taps per chunk keep the rotation static under the unrolled tap loop): with a one-tap
     // distance the L2 round trip (~1 us under load) was longer than a tap's 16 MFMAs and every tap stalled.
-    rq_u128 rh[H_IT], rw[3][2];
+    rq_u128 rh[H_IT], rw[W_SETS][W_IT];
     const int last_c = NC - 1;
     auto load_unit = [&](int c, int tap, rq_u128* r) {      // (c, tap) may run past the end: clamp (harmless reload)
         if (tap >= 9) { tap -= 9; ++c; }
@@ -210,9 +224,8 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         load_w(c, tap, r);
     };
     load_halo(0, rh);
-    load_w(0, 0, rw[0]);
-    load_unit(0, 1, rw[1]);
-    load_unit(0, 2, rw[2]);
+#pragma unroll
+    for (int u = 0; u < W_SETS; ++u) load_unit(0, u, rw[u]);
     store_halo(0, 0, rh);
     store_w(0, rw[0]);
     rq_syncthreads();
@@ -221,23 +234,23 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // patch registers would otherwise reload a chunk nobody needs, so the epilogue starts with the data in hand
     // (its global round trip was exposed: one workgroup per CU, nothing else to run meanwhile)
     constexpr int CPR = H_BN / 8;
-    constexpr int R_IT = 256 * CPR / H_NTH;        // 8
-    rq_u128 rr[R_IT];
+    constexpr int R_IT = TPX * CPR / NTH;          // 8
+    rq_u128 rr[RPRE ? R_IT : 1];
     const bf16_t* rsrc = p.resid;
     // one chunk of the reduction; LAST (compile time): no next patch to stage -- fetch the residual instead
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const int hbuf = c & 1;
+        const int hbuf = NB_H == 2 ? c & 1 : 0;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             // prefetch: unit g+3 into the set unit g just left; next chunk's halo patch once, a few taps ahead
-            load_unit(c, tap + 3, rw[tap % 3]);
+            load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
             if (!LAST && tap == 0) load_halo(c + 1, rh);
-            if (LAST && tap == 2 && p.resid) {             // uniform; one conservative vmcnt drain per workgroup at worst
+            if (RPRE && LAST && tap == 2 && p.resid) {     // uniform; one conservative vmcnt drain per workgroup at worst
 #pragma unroll
                 for (int k = 0; k < R_IT; ++k) {
-                    const int cidx = tid + H_NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+                    const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
                     const int ty = ml / HT_W, tx = ml - ty * HT_W;
                     const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
                     rr[k] = ld128(rsrc + pix * p.Cout + n0 + nl);
@@ -257,10 +270,17 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
             }
-            store_w(wbuf ^ 1, rw[(tap + 1) % 3]);
-            if (piece && h_in[it]) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff[it], pv);
+            store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
+            if (NB_H == 2) { if (piece && h_in[it]) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff[it], pv); }
+            else if (piece) rh[it] = pv;                   // single buffer: the finished piece waits in its register
             rq_syncthreads();
             wbuf ^= 1;
+        }
+        if (NB_H == 1 && !LAST) {                          // every wave is past its reads of this chunk: refill the buffer
+#pragma unroll
+            for (int it = 0; it < H_IT; ++it)
+                if (h_in[it]) st128(sH + h_loff[it], rh[it]);
+            rq_syncthreads();
         }
     };
     for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 
     // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
     constexpr int LDR = H_BN * 2 + 16;
-    static_assert(256 * LDR <= H_SMEM_BYTES, "epilogue tile must fit");
+    static_assert(TPX * LDR <= NB_H * (TH + 2) * HP_W * 128 + 2 * HW_BYTES, "epilogue tile must fit the launch's LDS segment");
     char* sT = (char*)smem;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
     if (p.resid) {
@@ -277,8 +297,14 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         // per-lane 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
 #pragma unroll
         for (int k = 0; k < R_IT; ++k) {
-            const int cidx = tid + H_NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-            st128(sT + ml * LDR + nl * 2, rr[k]);
+            const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+            if (RPRE) {
+                st128(sT + ml * LDR + nl * 2, rr[k]);
+            } else {
+                const int ty = ml / HT_W, tx = ml - ty * HT_W;
+                const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+                st128(sT + ml * LDR + nl * 2, ld128(p.resid + pix * p.Cout + n0 + nl));
+            }
         }
         rq_syncthreads();
     }
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
 #pragma unroll 4
-    for (int cidx = tid; cidx < 256 * CPR; cidx += H_NTH) {
+    for (int cidx = tid; cidx < TPX * CPR; cidx += NTH) {
         const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
         const int ty = ml / HT_W, tx = ml - ty * HT_W;
         const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
         }
     }
     if (p.stats) {                                  // uniform
-        __shared__ float sred[8][16][4];
+        __shared__ float sred[NTH / 64][16][4];
         const int gsz = p.Cout / 32;                // channels per group: 4, 8 or 16 (Cout = 128, 256, 512)
         float a0, q0, a1, q1;                       // pair 0 = channels 0..3 (gsz 4) or 0..7; pair 1 = channels 4..7 (gsz 4)
         if (gsz == 4) {
@@ -357,7 +383,7 @@ __global__ __launch_bounds__(H_NTH) void conv3x3_halo_kernel(ConvHaloArgs p) {
             const int chunk = (lane >> 1) & 15, pair = lane & 1;
             float a = 0.f, q = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) { a += sred[w][chunk][pair * 2]; q += sred[w][chunk][pair * 2 + 1]; }
+            for (int w = 0; w < NTH / 64; ++w) { a += sred[w][chunk][pair * 2]; q += sred[w][chunk][pair * 2 + 1]; }
             if (gsz == 16) {                        // a group spans two chunks: even chunk collects its neighbour
                 a += rq_shfl_xor(a, 2);
                 q += rq_shfl_xor(q, 2);
@@ -689,11 +715,41 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
     }
 }
 
+// tile height of the halo conv (see the kernel): 8 = one 8-wave workgroup per CU (default), 4 = two 4-wave workgroups.
+// Measured (profiles/r01_conv_halo_tile_height.txt): equal on the 128-channel 256^2 layers, the 4-row variant 10 %
+// slower on the 256-channel layers -- the expected overlap of one workgroup's staging / epilogue with the other's MFMAs
+// is eaten by the larger halo (1.59x vs 1.33x), twice the weight staging per pixel and the shallower prefetch.
+static int halo_th() {
+    static const int th = (getenv("RQAMD_HALO_TH") && atoi(getenv("RQAMD_HALO_TH")) == 4) ? 4 : 8;
+    return th;
+}
+
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
     return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64;
 }
 
-int rq_conv_halo_stat_tiles(int H, int W) { return (H / HT_H) * (W / HT_W); }
+int rq_conv_halo_stat_tiles(int H, int W) { return (H / halo_th()) * (W / HT_W); }
+static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a tile height
+
+template <int TH>
+static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
+    constexpr size_t patch = (size_t)(TH + 2) * HP_W * 128, stage = (TH == 8 ? 2 : 1) * patch + 2 * HW_BYTES;
+    constexpr size_t epi = (size_t)TH * HT_W * (H_BN * 2 + 16);
+    const size_t smem = stage > epi ? stage : epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_done = true;
+    }
+    const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
+    const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
+    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
+    return rq_check_launch("conv3x3_halo_kernel");
+}
 
 int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, const float* gn, const bf16_t* resid, bf16_t* out,
                         float* stats, int B, int H, int W, int Cin, int Cout, int ups, hipStream_t s) {
@@ -703,20 +759,8 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const size_t smem = H_SMEM_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
-    }
-    const int n_mt = B * (H / HT_H) * (W / HT_W), NT = Cout / H_BN;
-    const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1>), dim3(nblocks), dim3(H_NTH), smem, s, a);
-    else if (gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0>), dim3(nblocks), dim3(H_NTH), smem, s, a);
-    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0>), dim3(nblocks), dim3(H_NTH), smem, s, a);
-    return rq_check_launch("conv3x3_halo_kernel");
+    const int th = g_conv_halo_dbg_th ? g_conv_halo_dbg_th : halo_th();
+    return th == 8 ? launch_conv_halo_th<8>(a, ups, s) : launch_conv_halo_th<4>(a, ups, s);
 }
 
 // nchunk_have > 0: `part` already holds that many partials per image (written by the producing conv's epilogue)
@@ -732,8 +776,11 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
 extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
                                         int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
-    return rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W, Cin,
-                               Cout, ups, (hipStream_t)stream);
+    g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : 0;      // ups bit 1 / bit 2: force the 8-row / 4-row tile variant
+    const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
+                                       Cin, Cout, ups & 1, (hipStream_t)stream);
+    g_conv_halo_dbg_th = 0;
+    return rc;
 }
 
 extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,

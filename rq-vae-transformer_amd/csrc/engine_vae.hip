@@ -248,7 +248,7 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
     for (int i = 0; i < 5; ++i) h->buf[i] = (bf16_t*)((char*)h->ws.p + bytes * i);
     {   // GroupNorm partials: gn_stats uses <= RQ_GN_MAX_CHUNK per image, the conv epilogues one per 8x32 output tile
         size_t per_img_parts = RQ_GN_MAX_CHUNK;
-        const size_t tiles = (size_t)(c.resolution / 8) * ((c.resolution + 31) / 32);
+        const size_t tiles = (size_t)(c.resolution / 4) * ((c.resolution + 31) / 32);     // 4 x 32 pixel tiles at most
         if (tiles > per_img_parts) per_img_parts = tiles;
         RQ_TRY(h->part.reserve((size_t)chunk * per_img_parts * 32 * 2 * 4));
     }

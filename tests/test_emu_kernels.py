@@ -253,25 +253,27 @@ def test_emu_conv_halo(nat):
     gn = T(np.stack([1.0 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], -1).astype(np.float32))
     xf, wf = x.float().numpy(), np.transpose(w.float().numpy(), (0, 3, 1, 2))
     ref_plain = conv2d(xf, wf, bias.numpy())
-    out = nat.dbg_conv_halo(x, w, bias).float().numpy()
-    assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max()
     xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
     xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
-    stats = torch.zeros((B, (H // 8) * (W // 32), 32, 2), dtype=torch.float32)
-    out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats).float().numpy()
-    assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max()
-    # epilogue statistics: per (8x32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
-    t = out.reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32).astype(np.float64)
-    want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
-    assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max()
+    for th in (8, 4):            # 8 x 32 tiles / 8 waves / double-buffered patch, and 4 x 32 tiles / 4 waves / single buffer
+        out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float().numpy()
+        assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max(), th
+        stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), dtype=torch.float32)
+        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats, tile_h=th).float().numpy()
+        assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max(), th
+        # epilogue statistics: per (th x 32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
+        t = out.reshape(B, H // th, th, W // 32, 32, 32, Cout // 32).astype(np.float64)
+        want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
+        assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max(), th
     # Upsample.conv (layers.py:31-35): nearest 2x folded into the patch staging; 32x32 source -> 64x64 output
     xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
     xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
     ref_up = conv2d(xu, wf, bias.numpy())
-    out = nat.dbg_conv_halo(xs, w, bias, ups=True).float().numpy()
-    assert out.shape == (B, H, W, Cout)
-    assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max()
+    for th in (8, 4):
+        out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float().numpy()
+        assert out.shape == (B, H, W, Cout)
+        assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), th
 
 
 def test_emu_conv_in_mfma(nat):

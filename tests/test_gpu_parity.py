@@ -396,23 +396,25 @@ def test_conv_kernels_vs_torch(nat):
         gn = torch.stack([1.0 + 0.2 * rn(B, Cin), 0.3 * rn(B, Cin)], -1).contiguous()
         wt = w.float().permute(0, 3, 1, 2)
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1)
-        out = nat.dbg_conv_halo(x, w, bias).float()
-        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
         xn = F.silu(x.float() * gn[:, None, None, :, 0] + gn[:, None, None, :, 1]).to(torch.bfloat16).float()
-        ref = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
-        stats = torch.zeros((B, (H // 8) * (W // 32), 32, 2), device=DEV)
-        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats).float()
-        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
-        # epilogue statistics for the next GroupNorm: per (8x32 tile, group) sum / sum of squares of the bf16 output
-        t = out.double().reshape(B, H // 8, 8, W // 32, 32, 32, Cout // 32)
-        want = torch.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
-        assert float((stats.double() - want).abs().max()) < 1e-3 * float(want.abs().max())
+        ref_gn = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
+        for th in (8, 4):        # both tile variants of the kernel
+            out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float()
+            assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max()), th
+            stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), device=DEV)
+            out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats, tile_h=th).float()
+            assert float((out - ref_gn).abs().max()) < 0.02 * float(ref_gn.abs().max()), th
+            # epilogue statistics for the next GroupNorm: per (th x 32 tile, group) sum / sum of squares of the bf16 output
+            t = out.double().reshape(B, H // th, th, W // 32, 32, 32, Cout // 32)
+            want = torch.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
+            assert float((stats.double() - want).abs().max()) < 1e-3 * float(want.abs().max()), th
         # the same conv through a folded nearest 2x upsample (Upsample.forward)
         xs = rn(B, H // 2, W // 2, Cin).to(torch.bfloat16)
         xu = F.interpolate(xs.float().permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest')
         ref = F.conv2d(xu, wt, bias, padding=1).permute(0, 2, 3, 1)
-        out = nat.dbg_conv_halo(xs, w, bias, ups=True).float()
-        assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
+        for th in (8, 4):
+            out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float()
+            assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max()), th
     # MFMA Encoder.conv_in: NCHW fp32 image -> NHWC bf16
     x = rn(2, 3, 256, 256).clamp(-1, 1)
     w = rn(128, 3, 3, 3, scale=0.2)
