@@ -52,7 +52,7 @@ def build_models(device, model='huge'):
 def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=top_k, top_p=top_p)
     pixels = vae.decode_code(codes)
-    pixels = (0.5 * pixels + 0.5).clamp(0, 1)
+    pixels.mul_(0.5).add_(0.5).clamp_(0, 1)             # in place: 6.4 GB per temporary at B = 8192
     if distenv is not None and distenv.world_size > 1:
         from rqvae.utils.dist import all_gather_cat
         pixels = all_gather_cat(distenv, pixels)
@@ -142,7 +142,7 @@ def main():
         codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=args.top_k, top_p=args.top_p)
         ev[1].record()
         pixels = vae.decode_code(codes)
-        pixels = (0.5 * pixels + 0.5).clamp(0, 1)
+        pixels.mul_(0.5).add_(0.5).clamp_(0, 1)
         if distenv is not None:
             from rqvae.utils.dist import all_gather_cat
             pixels = all_gather_cat(distenv, pixels)
@@ -150,6 +150,7 @@ def main():
         ev[2].synchronize()
         t_ar += ev[0].elapsed_time(ev[1])
         t_dec += ev[1].elapsed_time(ev[2])
+        del pixels                                           # the gathered images (world x 6.4 GB) are freed before the next step
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
