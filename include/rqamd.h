@@ -170,6 +170,10 @@ int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, co
  * = (ky, kx, ci, cout), y NHWC bf16 [B][H][W][128].  Needs H % 8 == 0, W % 32 == 0. */
 int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, int B, int H, int W, void* y, void* stream);
 
+/* Kernel variants are selected by the number of rows (batch).  factor > 1 makes the selection logic see rows * factor, so
+ * that the large-batch variants run on test-sized inputs (results must not change); 1 restores normal behaviour. */
+int rqamd_dbg_set_row_scale(int factor);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,7 +145,8 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     return rq_fail(RQAMD_ERR_INVALID, "gemm: no tile %dx%d", bm, bn);
 }
 
-void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds) {
+void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds) {
+    const int M = (long)M_rows * g_rq_row_scale > 1 << 30 ? 1 << 30 : M_rows * g_rq_row_scale;      // (diagnostics factor, normally 1)
     // LDS-DMA staged operands win or tie from M = 512 up (profiles/r01_gemm_bench_lds_dma.txt, MI355X): 8-12 % at
     // M = 4096.  Tiles per shape class, from the same sweep:
     static const bool no_glds = getenv("RQAMD_NO_GLDS") != nullptr;

@@ -35,6 +35,8 @@ static inline int rq_check_launch(const char* what) {
     } while (0)
 
 // device buffer with RAII (engine-owned workspace)
+extern int g_rq_row_scale;     // diagnostics (api.hip): variant selection sees rows * this factor
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;

@@ -142,7 +142,7 @@ static int launch_resid_ln_wave(const ResidLnArgs& a, hipStream_t s) {
 }
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s) {
-    if (a.rows >= 512 && a.E % 256 == 0) {       // plenty of rows: a wavefront per row keeps every CU busy
+    if ((long)a.rows * g_rq_row_scale >= 512 && a.E % 256 == 0) {       // plenty of rows: a wavefront per row keeps every CU busy
         int rc = 1;
         switch (a.E / 256) {
             case 4: rc = launch_resid_ln_wave<4>(a, s); break;     // E = 1024 (355M)
@@ -354,7 +354,7 @@ int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     int nj = a.t_max >= 0 ? (a.t_max >> 3) + 1 : nj_cap;
     if (nj > nj_cap) nj = nj_cap;
     // two heads per wavefront while the register blocks are small (latency-bound regime) and the heads pair up
-    const int ppw = (a.nh % 2 == 0 && nj <= 4 && a.Tcap <= 64 && (long)a.rows * a.nh >= 16384) ? 2 : 1;
+    const int ppw = (a.nh % 2 == 0 && nj <= 4 && a.Tcap <= 64 && (long)a.rows * g_rq_row_scale * a.nh >= 16384) ? 2 : 1;
     if (a.Tcap <= 64) {
         switch (nj) {
             case 1: launch_attn<1, false>(a, ppw, s); break;

@@ -61,6 +61,7 @@ _SIGS = {
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_dbg_set_row_scale': (C.c_int, [C.c_int]),
     'rqamd_dbg_conv_in_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_conv_out_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]),
@@ -213,6 +214,11 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
                                          B, H, W, Cin, Cout, (1 if ups else 0) | (2 if tile_h == 8 else 4 if tile_h == 4 else 0),
                                          ptr(out), ptr(stats), stream_of(x)))
     return out
+
+
+def dbg_set_row_scale(factor):
+    """diagnostics: variant selection sees rows * factor (1 = normal)."""
+    check(lib().rqamd_dbg_set_row_scale(int(factor)))
 
 
 def dbg_conv_in(x, w, bias):

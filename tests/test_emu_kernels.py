@@ -152,6 +152,18 @@ def test_emu_rqt_tiny_logits(nat, golden):
     err = np.abs(logits - g['logits'])
     print('emu rqt tiny logits: max err %.4f mean err %.5f' % (err.max(), err.mean()))
     assert err.max() < 0.06 and err.mean() < 0.01          # bf16 weights/activations vs fp32 reference, |logits| <= 2.4
+    # the large-batch kernel variants (LDS-DMA and register-blocked GEMM tiles, two heads per attention wavefront) are
+    # selected by the row count; with the diagnostics factor they run on these 3 rows and must reproduce the result
+    nat.dbg_set_row_scale(4096)
+    try:
+        logits_big = eng.logits(codes, cond, [T(cb)] * 4).numpy()
+    finally:
+        nat.dbg_set_row_scale(1)
+    err2 = np.abs(logits_big - g['logits'])
+    print('emu rqt tiny logits, large-batch variants: max err %.4f, max diff to the small-batch kernels %.5f'
+          % (err2.max(), np.abs(logits_big - logits).max()))
+    assert err2.max() < 0.06 and err2.mean() < 0.01
+    assert np.abs(logits_big - logits).max() < 0.02
 
 
 def test_emu_rqt_text_conditioned_logits(nat, golden):
