@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
     args = ap.parse_args()
     if args.top_k is not None and args.top_k <= 0:
         args.top_k = None
@@ -137,7 +138,31 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     t_ar = t_dec = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if args.overlap:
+        # experiment (not the default): batch i is decoded on a second stream while batch i+1 is being sampled
+        s_ar, s_dec = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        prev = None
+        for i in range(args.steps + 1):
+            cur = None
+            if i < args.steps:
+                with torch.cuda.stream(s_ar):
+                    codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=args.top_k, top_p=args.top_p)
+                    e = torch.cuda.Event()
+                    e.record(s_ar)
+                cur = (codes, e)
+            if prev is not None:
+                with torch.cuda.stream(s_dec):
+                    s_dec.wait_event(prev[1])
+                    pixels = vae.decode_code(prev[0])
+                    pixels.mul_(0.5).add_(0.5).clamp_(0, 1)
+                    if distenv is not None:
+                        from rqvae.utils.dist import all_gather_cat
+                        pixels = all_gather_cat(distenv, pixels)
+                    pixels.record_stream(s_dec)
+                    del pixels
+            prev = cur
+        torch.cuda.synchronize(device)
+    for _ in range(0 if args.overlap else args.steps):
         ev[0].record()
         codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=args.top_k, top_p=args.top_p)
         ev[1].record()
@@ -229,7 +254,7 @@ def main():
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'ImageNet-256 class-conditional RQ-Transformer {args.model} sampling 8x8x4 codes + RQ-VAE decode '
                                    f'(BASELINE configs[2]); random-init weights, zero class condition',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'top_k': args.top_k, 'top_p': args.top_p,
+                       'batch_per_gpu': B, 'global_batch': B * world, 'top_k': args.top_k, 'top_p': args.top_p, 'overlap_decode_with_next_sampling': bool(args.overlap),
                        'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather per step' if world > 1 else 'single GPU',
                        'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU'},
             'ar_ms_per_image': t_ar / (args.steps * B), 'decode_ms_per_image': t_dec / (args.steps * B),
