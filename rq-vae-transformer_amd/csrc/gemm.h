@@ -660,9 +660,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
 // one's barrier / LDS latency is covered by the other.  Tile rows are 64 bytes: 16-byte chunk c of row r sits at
 // slot c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 over 16 consecutive rows); the DMA writes lane-linear, so the
 // permutation is applied to each lane's source address.
-template <int TR, int NS>
-__global__ __launch_bounds__(256, 2) void gemm_rb_kernel(GemmArgs p) {
-    constexpr int BM = 256, BN = 128, BK = 32, WGM = 2, WGN = 2, NW = 4;
+// BM = 256: wave tiles 128 x 64 (the register-blocked form described above).  BM = 128: wave tiles 64 x 64 with the same
+// half-depth stages -- 16 KB per stage, three stages = 48 KB, so THREE workgroups (12 wavefronts) share a CU where the
+// BK = 64 kernel above fits two.
+template <int BM, int TR, int NS>
+__global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void gemm_rb_kernel(GemmArgs p) {
+    constexpr int BN = 128, BK = 32, WGM = 2, WGN = 2, NW = 4;
     constexpr int WM = BM / WGM, WN = BN / WGN, MI = WM / 32, NI = WN / 32;
     constexpr int STAGE_BYTES = (BM + BN) * BK * 2;                      // 24 KB
     constexpr int SMEM_BYTES = NS * STAGE_BYTES > BM * (BN * 2 + 16) ? NS * STAGE_BYTES : BM * (BN * 2 + 16);

@@ -42,14 +42,14 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
     return rq_check_launch("gemm_bf16_kernel");
 }
 // register-blocked 256x128 / 4-wave / BK 32 kernel (gemm.h): dense operands, K % 32 == 0
-template <int TR, int NS>
+template <int BM, int TR, int NS>
 static int launch_rb(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BM = 256, BN = 128;
+    constexpr int BN = 128;
     constexpr size_t stage = (size_t)(BM + BN) * 32 * 2, epi = (size_t)BM * (BN * 2 + 16);
     const size_t smem = NS * stage > epi ? NS * stage : epi;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_rb_kernel<TR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_rb_kernel<BM, TR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_done = true;
     }
     GemmArgs g = a;
@@ -70,7 +70,7 @@ static int launch_rb(const GemmArgs& a, hipStream_t stream) {
         g.sched = 2; g.sched_gm = 1;
         nblocks = 8 * ((MT + 7) / 8) * NT;
     }
-    RQ_LAUNCH((gemm_rb_kernel<TR, NS>), dim3(nblocks, 1, a.splitk), dim3(256), smem, stream, g);
+    RQ_LAUNCH((gemm_rb_kernel<BM, TR, NS>), dim3(nblocks, 1, a.splitk), dim3(256), smem, stream, g);
     return rq_check_launch("gemm_rb_kernel");
 }
 
@@ -118,8 +118,12 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
             RQ_GL_CASE(128, 128, 2, 2)
             RQ_GL_CASE(256, 128, 4, 2)
             if (bm == 257 && bn == 128) {     // tile code 257x128: the register-blocked kernel (4 waves, 128x64 wave tiles, BK 32)
-                if (gl == 2) return tr ? launch_rb<1, 2>(a, stream) : launch_rb<0, 2>(a, stream);
-                return tr ? launch_rb<1, 3>(a, stream) : launch_rb<0, 3>(a, stream);
+                if (gl == 2) return tr ? launch_rb<256, 1, 2>(a, stream) : launch_rb<256, 0, 2>(a, stream);
+                return tr ? launch_rb<256, 1, 3>(a, stream) : launch_rb<256, 0, 3>(a, stream);
+            }
+            if (bm == 129 && bn == 128) {     // tile code 129x128: 128x128 tile on half-depth stages (three workgroups per CU)
+                if (gl == 2) return tr ? launch_rb<128, 1, 2>(a, stream) : launch_rb<128, 0, 2>(a, stream);
+                return tr ? launch_rb<128, 1, 3>(a, stream) : launch_rb<128, 0, 3>(a, stream);
             }
 #undef RQ_GL_CASE
         }
@@ -133,14 +137,6 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         if (!a.conv) return tr ? launch_c<256, 128, 0, 1, 4, 2>(a, stream) : launch_c<256, 128, 0, 0, 4, 2>(a, stream);
         if (a.ups) return tr ? launch_c<256, 128, 2, 1, 4, 2>(a, stream) : launch_c<256, 128, 2, 0, 4, 2>(a, stream);
         return tr ? launch_c<256, 128, 1, 1, 4, 2>(a, stream) : launch_c<256, 128, 1, 0, 4, 2>(a, stream);
-    }
-    // register-blocked variants (dense operands only): wave tile 128x64 -> 0.75 KB of LDS fragment reads per
-    // MFMA instead of 1 KB (the 64x64 wave tile saturates the LDS read port at ~50 % MFMA rate)
-    if (bm == 257 && bn == 128 && !a.conv) {   // 256x128, 4 wavefronts (2x2)
-        return a.epi != EPI_F32 ? launch_c<256, 128, 0, 1, 2, 2>(a, stream) : launch_c<256, 128, 0, 0, 2, 2>(a, stream);
-    }
-    if (bm == 129 && bn == 128 && !a.conv) {   // 128x128, 2 wavefronts (1x2)
-        return a.epi != EPI_F32 ? launch_c<128, 128, 0, 1, 1, 2>(a, stream) : launch_c<128, 128, 0, 0, 1, 2>(a, stream);
     }
     return rq_fail(RQAMD_ERR_INVALID, "gemm: no tile %dx%d", bm, bn);
 }

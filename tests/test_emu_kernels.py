@@ -237,11 +237,11 @@ def test_emu_gemm_tiles_and_lds_dma(nat):
         bias = T(rng.standard_normal(N).astype(np.float32))
         ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
         for gl in (0, 64, 96):
-            # tile code 257x128 = the register-blocked kernel (4 waves of 128x64, K-steps of 32; LDS-DMA only)
-            for (bm, bn) in ((128, 64), (128, 128), (256, 128)) + (((257, 128),) if gl else ()):
+            # tile codes 257x128 / 129x128 = the half-depth-stage kernel (K-steps of 32; LDS-DMA only): 4 waves of 128x64 / 64x64
+            for (bm, bn) in ((128, 64), (128, 128), (256, 128)) + (((257, 128), (129, 128)) if gl else ()):
                 out = nat.dbg_gemm(a, w, bias, epi=3 + gl, bm=bm, bn=bn, splitk=1).numpy()
                 assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max(), (M, N, K, gl, bm, bn)
-            for (bm, bn) in ((128, 64),) + (((257, 128),) if gl else ()):
+            for (bm, bn) in ((128, 64),) + (((257, 128), (129, 128)) if gl else ()):
                 out = nat.dbg_gemm(a, w, bias, epi=0 + gl, bm=bm, bn=bn, splitk=1).float().numpy()
                 assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max(), (M, N, K, gl, bm, bn)
                 if K >= 128:
