@@ -109,6 +109,12 @@ static __device__ __forceinline__ float rq_dpp_ror8(float v) { return rq_dpp<0x1
 static __device__ __forceinline__ float rq_readlane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+template <int CTRL> static __device__ __forceinline__ int rq_dpp_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+static __device__ __forceinline__ int rq_dpp_xor1_i(int v) { return rq_dpp_int<0xB1>(v); }
+static __device__ __forceinline__ int rq_dpp_xor2_i(int v) { return rq_dpp_int<0x4E>(v); }
+static __device__ __forceinline__ int rq_dpp_half_mirror_i(int v) { return rq_dpp_int<0x141>(v); }
+static __device__ __forceinline__ int rq_dpp_ror8_i(int v) { return rq_dpp_int<0x128>(v); }
+static __device__ __forceinline__ int rq_readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 // makes `x` opaque to the optimiser at this point (keeps loop-invariant address arithmetic from being hoisted out of a
 // persistent tile loop, where it would hold dozens of registers across the whole main loop)
 static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v"(x)); }
@@ -122,20 +128,20 @@ static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin
 
 // ---------------------------------------------------------------------------------------------
 // wave reductions
+// Full wavefronts only (every kernel here exits whole wavefronts).  Four DPP steps make the 16 lanes of a row agree, four
+// scalar lane reads combine the rows: no ds_bpermute round trips (~100 cycles each, six in a row, in the xor-shuffle form
+// this replaces -- the sampler's top-k / top-p searches run one such reduction per iteration).
 static __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += rq_shfl_xor(v, m);
-    return v;
+    v += rq_dpp_xor1(v); v += rq_dpp_xor2(v); v += rq_dpp_half_mirror(v); v += rq_dpp_ror8(v);
+    return (rq_readlane(v, 0) + rq_readlane(v, 16)) + (rq_readlane(v, 32) + rq_readlane(v, 48));
 }
 static __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, rq_shfl_xor(v, m));
-    return v;
+    v = fmaxf(v, rq_dpp_xor1(v)); v = fmaxf(v, rq_dpp_xor2(v)); v = fmaxf(v, rq_dpp_half_mirror(v)); v = fmaxf(v, rq_dpp_ror8(v));
+    return fmaxf(fmaxf(rq_readlane(v, 0), rq_readlane(v, 16)), fmaxf(rq_readlane(v, 32), rq_readlane(v, 48)));
 }
 static __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += rq_shfl_xor_i(v, m);
-    return v;
+    v += rq_dpp_xor1_i(v); v += rq_dpp_xor2_i(v); v += rq_dpp_half_mirror_i(v); v += rq_dpp_ror8_i(v);
+    return (rq_readlane_i(v, 0) + rq_readlane_i(v, 16)) + (rq_readlane_i(v, 32) + rq_readlane_i(v, 48));
 }
 
 // 16-byte global/LDS access helpers

@@ -171,6 +171,11 @@ static inline float rq_dpp_xor2(float v) { return rq_emu_shfl(v, rqemu::g_cur->l
 static inline float rq_dpp_half_mirror(float v) { const int l = rqemu::g_cur->lane; return rq_emu_shfl(v, (l & ~7) | (7 - (l & 7))); }
 static inline float rq_dpp_ror8(float v) { const int l = rqemu::g_cur->lane; return rq_emu_shfl(v, (l & ~15) | ((l + 8) & 15)); }
 static inline float rq_readlane(float v, int lane) { return rq_emu_shfl(v, lane); }
+static inline int rq_dpp_xor1_i(int v) { return rq_emu_shfl(v, rqemu::g_cur->lane ^ 1); }
+static inline int rq_dpp_xor2_i(int v) { return rq_emu_shfl(v, rqemu::g_cur->lane ^ 2); }
+static inline int rq_dpp_half_mirror_i(int v) { const int l = rqemu::g_cur->lane; return rq_emu_shfl(v, (l & ~7) | (7 - (l & 7))); }
+static inline int rq_dpp_ror8_i(int v) { const int l = rqemu::g_cur->lane; return rq_emu_shfl(v, (l & ~15) | ((l + 8) & 15)); }
+static inline int rq_readlane_i(int v, int lane) { return rq_emu_shfl(v, lane); }
 
 // v_mfma_f32_32x32x16_bf16: A lane l holds A[i=l&31][k=8*(l>>5)+j], B lane l holds B[k=8*(l>>5)+j][n=l&31],
 // C/D reg r of lane l is (row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31).   (cdna_hip_programming.md §3)
