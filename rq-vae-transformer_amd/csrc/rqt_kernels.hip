@@ -337,6 +337,91 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     attn_run<NJ, DYN, P>(p, lane, (int)blockIdx.y, h0, t);
 }
 
+// Contexts of at most 8 keys (t <= 7: every step of the depth transformer and the first 8 spatial positions -- 44 % of all
+// attention launches): EIGHT (row, head) pairs per wavefront, one per 8-lane group, lane = (pair slot, 16-byte chunk).
+// In the kernel above a wavefront serves one or two pairs and most of a 64-lane load instruction fetches nothing new;
+// its launch time at t = 0 was the texture-address path's instruction rate (7+ wavefront loads / stores per pair), not
+// bytes.  Here a wavefront instruction moves 1 KB of useful data for 8 pairs, the softmax over <= 8 keys stays inside
+// the lanes of a group (three DPP steps per dot product), and nothing crosses groups.
+template <int T>      // number of cached keys (t), 0..7
+static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, long pair, bool valid, int cc) {
+    const int E = p.E, Tcap = p.Tcap;
+    const int b = (int)(pair / p.nh), h = (int)(pair - (long)b * p.nh);
+    const bf16_t* qrow = p.qkv + (long)b * 3 * E + h * 64 + cc * 8;
+    bf16_t* kc = p.kc + pair * Tcap * 64 + cc * 8;
+    bf16_t* vc = p.vc + pair * Tcap * 64 + cc * 8;
+    const rq_u128 qv = ld128(qrow), kn = ld128(qrow + E), vn = ld128(qrow + 2 * E);
+    rq_u128 kr[T > 0 ? T : 1], vr[T > 0 ? T : 1];
+#pragma unroll
+    for (int j = 0; j < T; ++j) kr[j] = ld128(kc + j * 64);
+#pragma unroll
+    for (int j = 0; j < T; ++j) vr[j] = ld128(vc + j * 64);
+    if (valid) {                                   // append this token's k / v
+        st128(kc + T * 64, kn);
+        st128(vc + T * 64, vn);
+    }
+    float qf[8], sc[T + 1];
+    unpack8(qv, qf);
+    float mx = -__int_as_float(0x7f800000);
+#pragma unroll
+    for (int j = 0; j <= T; ++j) {
+        float kf[8];
+        unpack8(j < T ? kr[j < T ? j : 0] : kn, kf);
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+        dot += rq_dpp_xor1(dot);
+        dot += rq_dpp_xor2(dot);
+        dot += rq_dpp_half_mirror(dot);
+        sc[j] = dot * 0.125f;                      // 1/sqrt(64), attentions.py:87
+        mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j <= T; ++j) {
+        sc[j] = rq_fast_exp2((sc[j] - mx) * 1.4426950408889634f);
+        sum += sc[j];
+    }
+    const float inv = 1.0f / sum;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j <= T; ++j) {
+        float vf[8];
+        unpack8(j < T ? vr[j < T ? j : 0] : vn, vf);
+        const float pj = sc[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+    }
+    if (valid) {
+        rq_u128 o;
+        o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+        o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+        st128(p.y + (long)b * E + h * 64 + cc * 8, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long total = (long)p.rows * p.nh;
+    long pair = ((long)blockIdx.x * 4 + wave) * 8 + (lane >> 3);
+    const bool valid = pair < total;
+    if (!valid) pair = total - 1;                  // clamped loads, masked stores
+    const int t = (p.step ? *p.step : 0) + p.step_off;
+    switch (t) {
+        case 0: attn_small_run<0>(p, pair, valid, lane & 7); break;
+        case 1: attn_small_run<1>(p, pair, valid, lane & 7); break;
+        case 2: attn_small_run<2>(p, pair, valid, lane & 7); break;
+        case 3: attn_small_run<3>(p, pair, valid, lane & 7); break;
+        case 4: attn_small_run<4>(p, pair, valid, lane & 7); break;
+        case 5: attn_small_run<5>(p, pair, valid, lane & 7); break;
+        case 6: attn_small_run<6>(p, pair, valid, lane & 7); break;
+        case 7: attn_small_run<7>(p, pair, valid, lane & 7); break;
+        default: rq_trap();                        // host bound violated
+    }
+}
+
 template <int NJ, bool DYN>
 static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t s) {
     const dim3 blk(256);
@@ -355,6 +440,12 @@ int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (nj > nj_cap) nj = nj_cap;
     // two heads per wavefront while the register blocks are small (latency-bound regime) and the heads pair up
     const int ppw = (a.nh % 2 == 0 && nj <= 4 && a.Tcap <= 64 && (long)a.rows * g_rq_row_scale * a.nh >= 16384) ? 2 : 1;
+    static const bool no_small = getenv("RQAMD_NO_ATTN_SMALL") != nullptr;      // A/B switch
+    if (nj == 1 && !no_small) {                   // at most 8 keys: eight pairs per wavefront
+        const long pairs = (long)a.rows * a.nh;
+        RQ_LAUNCH(attn_small_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
+        return rq_check_launch("attn_small_kernel");
+    }
     if (a.Tcap <= 64) {
         switch (nj) {
             case 1: launch_attn<1, false>(a, ppw, s); break;
