@@ -52,6 +52,13 @@ RQT_TINY = rqt(128, 2, 2, 2, 500, vocab_cond=10, block_size=(4, 4, 4), input_emb
 RQT_TINY_TXT = rqt(128, 2, 2, 2, 500, vocab_cond=20, block_cond=4, block_size=(4, 4, 4), input_embed_dim=64)
 # one real-width layer of each stack (E=1536, 24 heads, V=16384) -- layer-count-independent parity
 RQT_WIDE = rqt(1536, 24, 2, 1, 16384)
+# 3.8B layer shapes (E=2560, 40 heads), 2 body + 1 head layers -- width-dependent kernel variants (BASELINE configs[3])
+RQT_XWIDE = rqt(2560, 40, 2, 1, 16384)
+# text-to-image widths with real conditioning lengths: cc3m shape (E=1280, 20 heads, 32 text tokens -> body context 95,
+# the 16-block DYN attention kernel) and the 64-token variant of the 3.9B text model (context 127, 32-block kernel),
+# 3 body + 2 head layers each (configs/cc3m/stage2/*.yaml; BASELINE configs[4])
+RQT_TXT32 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=32)
+RQT_TXT64 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=64)
 
 PARAM_COUNTS_M = {  # BASELINE.md §2 / reference README.md:38-47
     'RQT_FFHQ_355M': 355.4, 'RQT_IN_480M': 480.9, 'RQT_IN_821M': 820.9,

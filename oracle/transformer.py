@@ -113,8 +113,9 @@ class RQTransformerOracle:
         return linear(h, p['classifier.linear.weight'], p['classifier.linear.bias'])
 
     # ------------------------------------------------------------------ forward
-    def forward(self, xs, codebooks, cond=None):
-        """transformers.py:113-188 (cond_len == 1 path; cond_classifier not restated)."""
+    def forward(self, xs, codebooks, cond=None, return_cond_logits=False):
+        """transformers.py:113-188.  return_cond_logits: for cond_len > 1 return (seq_logits, cond_logits) as the
+        reference does (:150-153,:185-186): cond_classifier over the body outputs of the first cond_len-1 positions."""
         p = self.p
         xs = np.asarray(xs)
         B, H, W, D = xs.shape
@@ -135,7 +136,11 @@ class RQTransformerOracle:
         full = np.concatenate([spatial_ctx.reshape(B, seq_len, 1, -1), depth_ctx[:, :, :-1]], -2)
         full = full.reshape(B * seq_len, D, -1) + p['pos_emb_d'][:, :D]
         out = self._stack('head_transformer', full, self.nh_layers, self.n_head_head)
-        return self._classifier(out.reshape(B, H, W, D, -1))
+        seq_logits = self._classifier(out.reshape(B, H, W, D, -1))
+        if return_cond_logits and cond_len > 1:
+            h = layer_norm(latents[:, :cond_len - 1], p['cond_classifier.layer_norm.weight'], p['cond_classifier.layer_norm.bias'])
+            return seq_logits, linear(h, p['cond_classifier.linear.weight'], p['cond_classifier.linear.bias'])
+        return seq_logits
 
     # ------------------------------------------------------------------ cached path
     def init_cache(self):

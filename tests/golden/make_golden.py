@@ -212,6 +212,64 @@ def gen_rqt():
              logits=logits)
 
 
+# ------------------------------------------------------------------ 5. RQ-Transformer at the benchmarked / released shapes
+class CodebookAux:
+    """minimal model_aux: the reference only calls get_code_emb_with_depth on it (transformers.py:109-111)"""
+
+    def __init__(self, cb):
+        self.cb = torch.from_numpy(cb)
+
+    def get_code_emb_with_depth(self, xs):
+        return F.embedding(xs, self.cb), None
+
+
+BIG_POS = [(0, 0), (0, 1), (3, 5), (7, 7)]          # spatial positions whose logits are stored (all depths)
+
+
+def big_codebook(K, seed):
+    return np.random.default_rng(seed).standard_normal((K, 256), dtype=np.float32)
+
+
+def gen_rqt_big(only=None):
+    """Reference logits (teacher-forced forward(), fp32, CPU) for the configurations bench.py times and the
+    other released widths: full 1.4B (42+6 layers), full FFHQ-355M (24+4, V=2048, unconditional), E=2560/40 heads
+    (2+1 layers), and the text-to-image width E=1280/20 heads with 32 and 64 conditioning tokens (3+2 layers; also
+    the cond_classifier logits).  Stored: fp16 logits at BIG_POS x all depths; inputs/weights regenerate from seeds."""
+    cases = [('in1400m', C.RQT_IN_1400M, 2, 61), ('ffhq355m', C.RQT_FFHQ_355M, 2, 62), ('xwide', C.RQT_XWIDE, 2, 63),
+             ('txt32', C.RQT_TXT32, 2, 64), ('txt64', C.RQT_TXT64, 2, 65)]
+    for tag, cfg, B, seed in cases:
+        if only and tag not in only:
+            continue
+        m, params = ref_rqt(cfg, seed=seed)
+        H, W, D = cfg['block_size']
+        V = cfg['vocab_size']
+        cb = big_codebook(V, seed + 100)
+        rng = np.random.default_rng(seed + 200)
+        codes = rng.integers(0, V, (B, H, W, D))
+        cond = rng.integers(0, max(cfg['vocab_size_cond'], 1), (B, max(cfg['block_size_cond'], 1)))
+        out = m(torch.from_numpy(codes), CodebookAux(cb), cond=torch.from_numpy(cond))
+        extra = {}
+        if isinstance(out, tuple):
+            out, cond_logits = out
+            cl = cond_logits.numpy()                                           # (B, cond_len-1, vocab_cond)
+            cpos = sorted({0, 1, cl.shape[1] // 2, cl.shape[1] - 1})
+            extra['cond_pos'] = np.array(cpos, np.int32)
+            extra['cond_logits'] = cl[:, cpos].astype(np.float16)
+        logits = out.numpy()
+        sel = np.stack([logits[:, h, w] for h, w in BIG_POS], 1)          # (B, npos, D, V)
+        print(f'  rqt[{tag}] |logits| max {np.abs(logits).max():.3f} std {logits.std():.3f}')
+        if cfg['body']['n_layer'] + cfg['head']['n_layer'] <= 6:
+            ol = oracle.RQTransformerOracle(cfg, params).forward(codes, [cb] * D, cond, return_cond_logits=True)
+            if isinstance(ol, tuple):
+                print(f'  rqt[{tag}] oracle cond_logits vs ref: {np.abs(ol[1] - cond_logits.numpy()).max():.2e}')
+                ol = ol[0]
+            print(f'  rqt[{tag}] oracle forward vs ref: {np.abs(ol - logits).max():.2e}')
+        save(f'rqt_{tag}.npz', seed=seed, cb_seed=seed + 100, codes=codes.astype(np.int32), cond=cond.astype(np.int32),
+             pos=np.array(BIG_POS, np.int32), logits=sel.astype(np.float16), logits_absmax=np.float32(np.abs(logits).max()),
+             logits_std=np.float32(logits.std()), **extra)
+        del m, params
+
+
 def gen_param_counts():
     counts = {}
     for name in C.PARAM_COUNTS_M:
@@ -228,7 +286,11 @@ def gen_param_counts():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'counts']
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'counts']
     for w in which:
         print(f'[{w}]')
-        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'counts': gen_param_counts}[w]()
+        if w.startswith('rqt_big:'):                      # e.g. rqt_big:txt32,txt64
+            gen_rqt_big(w.split(':', 1)[1].split(','))
+            continue
+        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big,
+         'counts': gen_param_counts}[w]()

@@ -113,6 +113,22 @@ def test_rqt_tiny_text_conditioned(golden):
             np.testing.assert_allclose(lg, g['logits'][:, h, w, 0], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize('tag', ['xwide', 'txt32', 'txt64'])
+def test_oracle_vs_reference_real_widths(golden, tag):
+    """E=2560/40 heads and E=1280/20 heads with 32 / 64 text tokens (few layers): the oracle against the reference's
+    own logits (seq logits at the stored positions; cond_classifier logits for the text shapes)."""
+    g = golden(f'rqt_{tag}.npz')
+    cfg = {'xwide': C.RQT_XWIDE, 'txt32': C.RQT_TXT32, 'txt64': C.RQT_TXT64}[tag]
+    cb = np.random.default_rng(int(g['cb_seed'])).standard_normal((cfg['vocab_size'], 256), dtype=np.float32)
+    orc = oracle.RQTransformerOracle(cfg, oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed'])))
+    out = orc.forward(g['codes'].astype(np.int64), [cb] * 4, g['cond'].astype(np.int64), return_cond_logits=True)
+    seq = out[0] if isinstance(out, tuple) else out
+    got = np.stack([seq[:, h, w] for h, w in g['pos']], 1)
+    assert np.abs(got - g['logits'].astype(np.float32)).max() < 2e-3          # fp16 storage of |logits| <= 3.2
+    if isinstance(out, tuple):
+        assert np.abs(out[1][:, g['cond_pos']] - g['cond_logits'].astype(np.float32)).max() < 2e-3
+
+
 def test_param_counts():
     """README.md:38-47 of the reference: structural known answers."""
     with open(os.path.join(GOLDEN, 'param_counts.json')) as f:
