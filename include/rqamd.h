@@ -127,6 +127,12 @@ int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, 
  * This is the parity hook against RQTransformer.forward (transformers.py:113-188). */
 int rqamd_rqt_logits(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
                      const float* const* codebooks, float* logits_out, void* stream);
+/* rqamd_rqt_forward <- RQTransformer.forward (transformers.py:113-188) including the text-conditioned return value
+ * (seq_logits, cond_logits) (:150-153,:185-186): as rqamd_rqt_logits, plus cond_logits_out (batch, block_size_cond-1,
+ * vocab_size_cond) fp32 = cond_classifier over the body outputs of the conditioning prefix (NULL to skip; must be NULL
+ * when block_size_cond <= 1). */
+int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
+                      const float* const* codebooks, float* logits_out, float* cond_logits_out, void* stream);
 /* timing hook for bench.py: average device time (ms) of the engine's weight-streaming GEMM launches
  * during the last rqamd_rqt_sample call is not observable from outside the stream, so the engine can
  * bracket every GEMM launch of one call with HIP events (profile != 0 disables graphs for that call). */

@@ -44,6 +44,9 @@ struct rqamd_rqt {
     std::vector<RqtLayer> body, head;
     bf16_t *w_in, *w_headin, *w_cls;
     float *b_in, *b_headin, *b_cls, *cls_lnw, *cls_lnb;
+    bf16_t* w_ccls = nullptr;                      // cond_classifier (transformers.py:100-104), text-conditioned models only
+    float *b_ccls = nullptr, *ccls_lnw = nullptr, *ccls_lnb = nullptr;
+    int n_ccls_seen = 0;
     float *cond_emb, *pos_cond, *pos_hw, *pos_d;
     float *body_in_bias, *head_in_bias;   // [HW][E], [D][E] derived tables
     bool tables_dirty = true;
@@ -104,6 +107,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     const size_t per_layer = al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2) + al(3 * E * 4) + al(4 * E * 4) + 6 * al(E * 4);
     size_t total = per_layer * (c->n_layer_body + c->n_layer_head) + 2 * al(E * Din * 2) + al(V * E * 2) + 4 * al(E * 4) + al(V * 4)
                    + al(vc * E * 4) + al(h->cond_len * E * 4) + 2 * al(h->HW * E * 4) + 2 * al(h->D * E * 4);
+    if (h->cond_len > 1) total += al((size_t)vc * E * 2) + al((size_t)vc * 4) + 2 * al(E * 4);
     if (h->arena.reserve(total) != RQAMD_OK) { delete h; return RQAMD_ERR_HIP; }
     char* p = (char*)h->arena.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
@@ -126,6 +130,10 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     h->cond_emb = (float*)take(vc * E * 4); h->pos_cond = (float*)take(h->cond_len * E * 4);
     h->pos_hw = (float*)take(h->HW * E * 4); h->body_in_bias = (float*)take(h->HW * E * 4);
     h->pos_d = (float*)take(h->D * E * 4); h->head_in_bias = (float*)take(h->D * E * 4);
+    if (h->cond_len > 1) {
+        h->w_ccls = (bf16_t*)take((size_t)vc * E * 2); h->b_ccls = (float*)take((size_t)vc * 4);
+        h->ccls_lnw = (float*)take(E * 4); h->ccls_lnb = (float*)take(E * 4);
+    }
     h->n_required = 4 + 4 + 4 + 12 * 2 * 0;   // filled below
     h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + 4 /*mlps*/ + 4 /*classifier*/ + (size_t)16 * (c->n_layer_body + c->n_layer_head);
     *out = h;
@@ -180,7 +188,19 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
     else if (s == "classifier.layer_norm.bias") rc = f32copy(h->cls_lnb, E);
     else if (s == "classifier.linear.weight") rc = bf16copy(h->w_cls, (long)h->V * E);
     else if (s == "classifier.linear.bias") rc = f32copy(h->b_cls, h->V);
-    else if (s.rfind("cond_classifier.", 0) == 0) return RQAMD_OK;     // forward()-only head (transformers.py:150-153)
+    else if (s.rfind("cond_classifier.", 0) == 0) {                    // forward()-only head (transformers.py:150-153)
+        if (h->cond_len <= 1) return RQAMD_OK;
+        if (s == "cond_classifier.layer_norm.weight") rc = f32copy(h->ccls_lnw, E);
+        else if (s == "cond_classifier.layer_norm.bias") rc = f32copy(h->ccls_lnb, E);
+        else if (s == "cond_classifier.linear.weight") rc = bf16copy(h->w_ccls, (long)vc * E);
+        else if (s == "cond_classifier.linear.bias") rc = f32copy(h->b_ccls, vc);
+        else return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param: unknown parameter %s", name);
+        if (rc != RQAMD_OK) return rc;
+        bool dupc = false;
+        for (auto& k : h->seen) if (k == s) { dupc = true; break; }
+        if (!dupc) { h->seen.push_back(s); h->n_ccls_seen++; }
+        return RQAMD_OK;
+    }
     else {
         std::vector<RqtLayer>* stack = nullptr;
         size_t off = 0;
@@ -223,37 +243,55 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
 }
 
 // -------------------------------------------------------------------------------------------------
+// images per prefill chunk / workspace rows for a batch of B (text-conditioned models run the cond_len-1 prefix tokens of
+// a chunk of images through the body stack at once: rows = images x (cond_len - 1))
+static int prefill_chunk(const rqamd_rqt* h, int B) {
+    const int P = h->cond_len - 1;
+    if (P < 1) return 0;
+    int pc = (B > 4096 ? B : 4096) / P;
+    if (pc < 1) pc = 1;
+    return pc < B ? pc : B;
+}
+
 static int ensure_batch(rqamd_rqt* h, int B) {
     if (B <= h->cap) return RQAMD_OK;
+    // Failure-atomic regrowth: the old capacity is dropped BEFORE anything is freed, and the new one is recorded only after
+    // every allocation succeeded -- a failed hipMalloc (the KV cache is ~135 GB at B = 8192) leaves the handle empty
+    // (cap 0, no graphs), never pointing at freed memory; the caller may retry with a smaller batch.
+    h->cap = 0;
+    h->gvalid = false;
+    for (auto& L : h->body) L.kc = L.vc = nullptr;
+    for (auto& L : h->head) L.kc = L.vc = nullptr;
     const size_t E = h->E, V = h->V;
-    const size_t rows = (size_t)B;
-    size_t total = 2 * al(rows * E * 4) + al((size_t)h->max_slabs * rows * E * 4) + al(rows * V * 4) + 2 * al(rows * E * 2) + al(rows * 3 * E * 2)
-                   + al(rows * 4 * E * 2) + al(rows * h->Din * 2) + al(rows * h->HW * h->D * 8) + al(rows * h->cond_len * 8) + al(64) + al(64) + al(rows * 4);
+    const size_t brows = (size_t)B;
+    const size_t prow = (size_t)prefill_chunk(h, B) * (h->cond_len - 1);
+    const size_t rows = brows > prow ? brows : prow;              // activation rows (decode step or prefill chunk)
+    size_t total = 2 * al(rows * E * 4) + al((size_t)h->max_slabs * rows * E * 4) + al(brows * V * 4) + 2 * al(rows * E * 2) + al(rows * 3 * E * 2)
+                   + al(rows * 4 * E * 2) + al(brows * h->Din * 2) + al(brows * h->HW * h->D * 8) + al(brows * h->cond_len * 8) + al(64) + al(64) + al(brows * 4);
     RQ_TRY(h->ws.reserve(total));
     char* p = (char*)h->ws.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
     h->x = (float*)take(rows * E * 4); h->xh = (float*)take(rows * E * 4);
     h->slabs = (float*)take((size_t)h->max_slabs * rows * E * 4);
-    h->logits = (float*)take(rows * V * 4);
+    h->logits = (float*)take(brows * V * 4);
     h->y = (bf16_t*)take(rows * E * 2); h->ya = (bf16_t*)take(rows * E * 2);
     h->qkv = (bf16_t*)take(rows * 3 * E * 2); h->hbuf = (bf16_t*)take(rows * 4 * E * 2);
-    h->ain = (bf16_t*)take(rows * h->Din * 2);
-    h->xs = (int64_t*)take(rows * h->HW * h->D * 8); h->cond = (int64_t*)take(rows * h->cond_len * 8);
-    h->st = (int*)take(64); h->rng = (uint64_t*)take(64); h->smp_redo = (int*)take(rows * 4);
+    h->ain = (bf16_t*)take(brows * h->Din * 2);
+    h->xs = (int64_t*)take(brows * h->HW * h->D * 8); h->cond = (int64_t*)take(brows * h->cond_len * 8);
+    h->st = (int*)take(64); h->rng = (uint64_t*)take(64); h->smp_redo = (int*)take(brows * 4);
     // KV caches: body [rows][nh][Tbody][64] x2 per layer, head Tcap = D
-    const size_t kvb = al(rows * E * h->Tbody * 2), kvh = al(rows * E * h->D * 2);
+    const size_t kvb = al(brows * E * h->Tbody * 2), kvh = al(brows * E * h->D * 2);
     RQ_TRY(h->kv.reserve(2 * kvb * h->body.size() + 2 * kvh * h->head.size()));
     char* q = (char*)h->kv.p;
     for (auto& L : h->body) { L.kc = (bf16_t*)q; q += kvb; L.vc = (bf16_t*)q; q += kvb; }
     for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; }
     h->cap = B;
-    h->gvalid = false;
     return RQAMD_OK;
 }
 
 static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
-    if (h->seen.size() < h->n_required)
-        return rq_fail(RQAMD_ERR_STATE, "rqt: only %zu of %zu parameters set", h->seen.size(), h->n_required);
+    if (h->seen.size() - h->n_ccls_seen < h->n_required)
+        return rq_fail(RQAMD_ERR_STATE, "rqt: only %zu of %zu parameters set", h->seen.size() - h->n_ccls_seen, h->n_required);
     if (!h->tables_dirty) return RQAMD_OK;
     long n = (long)h->HW * h->E;
     RQ_LAUNCH(bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->b_in, (float)h->D, h->pos_hw, h->body_in_bias, h->HW, h->E);
@@ -298,18 +336,28 @@ struct Pending { const float* slabs; int n; const float* bias; };   // un-reduce
 
 // one transformer block on `rows` single-token rows; x is the fp32 residual stream (updated lazily:
 // `pend` carries the previous block's fc2 partials + bias into this block's first resid_ln)
+struct PrefillCtx { int img0, n_img, P; };   // non-null: `rows` = n_img * P prefix tokens of images img0.. (multi-token causal attention)
+
 static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& pend, const float* addvec, int rows,
-                     const int* step, int step_off, int t_max, int Tcap, hipStream_t st) {
+                     const int* step, int step_off, int t_max, int Tcap, hipStream_t st, const PrefillCtx* pf = nullptr) {
     const int E = h->E;
     ResidLnArgs r{};
     r.x_in = x_in; r.x_out = x; r.slabs = pend.slabs; r.n_slabs = pend.n; r.bias = pend.bias; r.addvec = addvec;
     r.gamma = L.ln1w; r.beta = L.ln1b; r.y = h->y; r.rows = rows; r.E = E; r.eps = 1e-5f;
     RQ_TRY(rq_launch_resid_ln(r, st));
     RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
-    AttnDecodeArgs at{};
-    at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
-    at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
-    RQ_TRY(rq_launch_attn_decode(at, st));
+    if (pf) {
+        AttnPrefillArgs ap{};
+        const long img_stride = (long)h->cfg.n_head * Tcap * 64;
+        ap.qkv = h->qkv; ap.kc = L.kc + pf->img0 * img_stride; ap.vc = L.vc + pf->img0 * img_stride; ap.y = h->ya;
+        ap.n_img = pf->n_img; ap.P = pf->P; ap.nh = h->cfg.n_head; ap.E = E; ap.Tcap = Tcap;
+        RQ_TRY(rq_launch_attn_prefill(ap, st));
+    } else {
+        AttnDecodeArgs at{};
+        at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
+        at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
+        RQ_TRY(rq_launch_attn_decode(at, st));
+    }
     int ns = 1;
     RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st));
     ResidLnArgs r2{};
@@ -330,6 +378,7 @@ struct StepCtx {
     const float* top_p;
     bool sample;           // run the sampler (else teacher-forced)
     float* logits_out;     // teacher-forced: (B,HW,D,V)
+    float* cond_logits_out; // teacher-forced, text-conditioned: (B, cond_len-1, vocab_size_cond) or null
 };
 
 // body stack for the token whose input is already in h->x; leaves the last fc2 un-reduced in `pend`
@@ -411,12 +460,28 @@ static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const
     if (cond) RQ_HIP(hipMemcpyAsync(h->cond, cond, (size_t)B * h->cond_len * 8, hipMemcpyDeviceToDevice, st));
     else RQ_HIP(hipMemsetAsync(h->cond, 0, (size_t)B * h->cond_len * 8, st));
     RQ_TRY(rq_launch_set_int(h->st, 0, st));
-    // conditioning prefix (text tokens): tokens 0..cond_len-2 only fill the body KV cache (transformers.py:235-239)
-    for (int i = 0; i + 1 < h->cond_len; ++i) {
-        RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, i, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
-                                    h->pos_cond, h->x, B, h->E, st));
-        Pending pend;
-        RQ_TRY(body_stack(h, B, nullptr, i, i, pend, st));
+    // Conditioning prefix (text tokens): tokens 0..cond_len-2 only fill the body KV cache (transformers.py:235-239; in
+    // forward() their body outputs also feed cond_classifier, :150-153).  All P = cond_len-1 tokens of a chunk of images go
+    // through the body stack in ONE pass (GEMMs over images x P rows, causal attention inside the prefix), the way the
+    // reference's first cached step does -- not as P sequential single-token steps.
+    if (h->cond_len > 1) {
+        const int P = h->cond_len - 1, pc = prefill_chunk(h, B), vc = h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond;
+        for (int b0 = 0; b0 < B; b0 += pc) {
+            PrefillCtx pf{b0, B - b0 < pc ? B - b0 : pc, P};
+            const int rows = pf.n_img * P;
+            RQ_TRY(rq_launch_cond_embed_multi(h->cond + (long)b0 * h->cond_len, h->cond_len, P, h->cond_emb, vc, h->pos_cond, h->x, pf.n_img, h->E, st));
+            Pending pend{nullptr, 0, nullptr};
+            for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, nullptr, 0, 0, h->Tbody, st, &pf));
+            if (c.cond_logits_out) {
+                if (!h->w_ccls || h->n_ccls_seen < 4) return rq_fail(RQAMD_ERR_STATE, "rqt: cond_classifier parameters not set");
+                ResidLnArgs r{};
+                r.x_in = h->x; r.x_out = nullptr; r.slabs = pend.slabs; r.n_slabs = pend.n; r.bias = pend.bias;
+                r.gamma = h->ccls_lnw; r.beta = h->ccls_lnb; r.y = h->y; r.rows = rows; r.E = h->E; r.eps = 1e-5f;
+                RQ_TRY(rq_launch_resid_ln(r, st));
+                RQ_TRY(step_gemm(h, h->y, h->E, h->w_ccls, rows, vc, h->E, EPI_F32, h->b_ccls, nullptr, 0,
+                                 c.cond_logits_out + (long)b0 * P * vc, vc, nullptr, st));
+            }
+        }
     }
     for (int pos = 0; pos < h->HW; ++pos) {
         const bool do_head = pos >= start_idx;
@@ -441,7 +506,12 @@ static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const
                     (void)hipGraphDestroy(g);
                     if (e2 != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e2));
                 } else {
-                    use_graph = false;    // capture unavailable: fall through to eager launches
+                    // capture unavailable (e.g. the legacy default stream): eager launches, ~10x the launch count.
+                    // Said once, loudly -- this is a performance cliff, not an error.
+                    static bool warned = false;
+                    if (!warned) { fprintf(stderr, "librqamd: hipStreamBeginCapture failed (%s); sampling runs with eager launches\n", hipGetErrorString(e)); warned = true; }
+                    (void)hipGetLastError();
+                    use_graph = false;
                 }
             }
             if (h->gexec[bucket]) {
@@ -497,6 +567,16 @@ extern "C" int rqamd_rqt_logits(rqamd_rqt* h, const int64_t* codes, const int64_
     if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_logits: batch < 1");
     StepCtx c{};
     c.B = batch; c.codebooks = codebooks; c.temperature = 1.f; c.sample = false; c.logits_out = logits_out;
+    return run_all(h, c, codes, cond, 0, false, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
+                                 const float* const* codebooks, float* logits_out, float* cond_logits_out, void* stream) {
+    if (!h || !codes || !codebooks || !logits_out) return rq_fail(RQAMD_ERR_INVALID, "rqt_forward: null argument");
+    if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_forward: batch < 1");
+    if (cond_logits_out && h->cond_len <= 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_forward: cond_logits need block_size_cond > 1");
+    StepCtx c{};
+    c.B = batch; c.codebooks = codebooks; c.temperature = 1.f; c.sample = false; c.logits_out = logits_out; c.cond_logits_out = cond_logits_out;
     return run_all(h, c, codes, cond, 0, false, nullptr, (hipStream_t)stream);
 }
 

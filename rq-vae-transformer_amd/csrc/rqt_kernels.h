@@ -39,6 +39,16 @@ struct AttnDecodeArgs {
     int rows, nh, E, Tcap;
 };
 
+// Multi-token prefill of the conditioning prefix (transformers.py:235-239 of the reference: the first cached body step
+// runs the whole prefix through MultiSelfAttention.forward with the causal mask, attentions.py:60-104).
+struct AttnPrefillArgs {
+    const bf16_t* qkv;      // [n_img * P][3E], row = img * P + i (token i of image img)
+    bf16_t* kc;             // K cache of the FIRST image of this chunk: [n_img][nh][Tcap][64]; positions 0..P-1 are written
+    bf16_t* vc;
+    bf16_t* y;              // [n_img * P][E]
+    int n_img, P, nh, E, Tcap;
+};
+
 struct EmbedTokArgs {
     const int64_t* xs;      // [rows][HW][D] codes
     const float* cb[8];     // per-depth codebooks (K, dim), padding row excluded
@@ -68,7 +78,11 @@ struct SampleArgs {
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s);
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
+int rq_launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
 int rq_launch_embed_tokens(const EmbedTokArgs& a, hipStream_t s);
+// x[(img, i)] = cond_emb[cond[img][i]] + pos_emb_cond[i] for i < n_tok: the prefix rows of the prefill
+int rq_launch_cond_embed_multi(const int64_t* cond, int cond_stride, int n_tok, const float* cond_emb, int vocab_cond,
+                               const float* pos_emb_cond, float* x, int n_img, int E, hipStream_t s);
 int rq_launch_cond_embed(const int64_t* cond, int cond_stride, int cond_idx, const float* cond_emb, int vocab_cond,
                          const float* pos_emb_cond, float* x, int rows, int E, hipStream_t s);
 int rq_launch_sample(const SampleArgs& a, hipStream_t s);

@@ -463,6 +463,91 @@ int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     return rq_check_launch("attn_decode_kernel");
 }
 
+
+// =================================================================================================
+// Prefill attention over the conditioning prefix: P tokens per image enter the body stack at once (reference:
+// transformers.py:235-239 -> MultiSelfAttention.forward on (B, P, E) with the causal mask, attentions.py:60-104).
+// One wavefront per (image, head): K and V of the pair are staged once in LDS (and appended to the KV cache at positions
+// 0..P-1 on the way), then lane i owns query i -- scores against keys 0..i with an online softmax in fp32; every lane
+// reads the same K / V row at a time (LDS broadcast, conflict-free).  Same arithmetic as the decode kernels above: bf16
+// q / k / v, fp32 dot products, scale 1/8, fp32 softmax weights on bf16 values, one bf16 rounding of the output.
+// The prefix is processed once per sample() call (the decode kernels run 64 times), P <= 255, so this is a VALU kernel.
+__global__ __launch_bounds__(64) void attn_prefill_kernel(AttnPrefillArgs p) {
+    RQ_DYN_SMEM(smem);
+    const int lane = threadIdx.x;
+    const int pair = blockIdx.x, img = pair / p.nh, hh = pair - img * p.nh;
+    const int P = p.P, E = p.E;
+    bf16_t* sK = (bf16_t*)smem;
+    bf16_t* sV = sK + (size_t)P * 64;
+    const bf16_t* q0 = p.qkv + (long)img * P * 3 * E + hh * 64;
+    bf16_t* kc = p.kc + (long)pair * p.Tcap * 64;
+    bf16_t* vc = p.vc + (long)pair * p.Tcap * 64;
+    for (int idx = lane; idx < P * 8; idx += 64) {
+        const int j = idx >> 3, c = idx & 7;
+        const rq_u128 kv = ld128(q0 + (long)j * 3 * E + E + c * 8), vv = ld128(q0 + (long)j * 3 * E + 2 * E + c * 8);
+        st128(sK + j * 64 + c * 8, kv);
+        st128(sV + j * 64 + c * 8, vv);
+        st128(kc + j * 64 + c * 8, kv);
+        st128(vc + j * 64 + c * 8, vv);
+    }
+    rq_syncthreads();
+    const float NEG_INF = -__int_as_float(0x7f800000);
+    for (int i0 = 0; i0 < P; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < P;
+        const int iq = live ? i : P - 1;
+        float qf[64], acc[64];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) unpack8(ld128(q0 + (long)iq * 3 * E + c * 8), qf + c * 8);
+#pragma unroll
+        for (int e = 0; e < 64; ++e) acc[e] = 0.f;
+        float m = NEG_INF, l = 0.f;
+        const int jend = i0 + 63 < P - 1 ? i0 + 63 : P - 1;       // wave-uniform trip count; lanes mask keys j > i
+        for (int j = 0; j <= jend; ++j) {
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float kf[8];
+                unpack8(ld128(sK + j * 64 + c * 8), kf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot = fmaf(qf[c * 8 + e], kf[e], dot);
+            }
+            const float sc = j <= iq ? dot * 0.125f : NEG_INF;    // 1/sqrt(64), attentions.py:87; causal mask :88-91
+            const float mn = fmaxf(m, sc);
+            const float alpha = (m == NEG_INF) ? 0.f : rq_fast_exp2((m - mn) * 1.4426950408889634f);
+            const float w = (sc == NEG_INF) ? 0.f : rq_fast_exp2((sc - mn) * 1.4426950408889634f);
+            l = l * alpha + w;
+            m = mn;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float vf[8];
+                unpack8(ld128(sV + j * 64 + c * 8), vf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[c * 8 + e] = fmaf(w, vf[e], acc[c * 8 + e] * alpha);
+            }
+        }
+        if (live) {
+            const float inv = 1.0f / l;
+            bf16_t* o = p.y + ((long)img * P + i) * E + hh * 64;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                rq_u128 u;
+                u.x = pack_bf16x2(acc[c * 8 + 0] * inv, acc[c * 8 + 1] * inv); u.y = pack_bf16x2(acc[c * 8 + 2] * inv, acc[c * 8 + 3] * inv);
+                u.z = pack_bf16x2(acc[c * 8 + 4] * inv, acc[c * 8 + 5] * inv); u.w = pack_bf16x2(acc[c * 8 + 6] * inv, acc[c * 8 + 7] * inv);
+                st128(o + c * 8, u);
+            }
+        }
+    }
+}
+
+int rq_launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
+    if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
+    if (a.P < 1 || a.P > a.Tcap || a.P > 255) return rq_fail(RQAMD_ERR_UNSUPPORTED, "prefill attention: %d tokens (cache %d, max 255)", a.P, a.Tcap);
+    const size_t smem = (size_t)a.P * 64 * 2 * 2;
+    RQ_LAUNCH(attn_prefill_kernel, dim3((unsigned)(a.n_img * a.nh)), dim3(64), smem, s, a);
+    return rq_check_launch("attn_prefill_kernel");
+}
+
 // =================================================================================================
 // embedding of the newest position: sum over depths [0, n_depth) of codebook rows -> bf16 GEMM operand
 __global__ void embed_tokens_kernel(EmbedTokArgs p) {
@@ -513,6 +598,27 @@ int rq_launch_cond_embed(const int64_t* cond, int cond_stride, int cond_idx, con
     RQ_LAUNCH(cond_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cond, cond_stride, cond_idx,
               cond_emb, vocab_cond, pos_emb_cond, x, rows, E);
     return rq_check_launch("cond_embed_kernel");
+}
+
+__global__ void cond_embed_multi_kernel(const int64_t* cond, int cond_stride, int n_tok, const float* cond_emb, int vocab_cond,
+                                        const float* pos_emb_cond, float* x, int n_img, int E) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)n_img * n_tok * E) return;
+    const long row = gid / E;
+    const int e = (int)(gid - row * E);
+    const int img = (int)(row / n_tok), i = (int)(row - (long)img * n_tok);
+    long c = cond ? cond[(long)img * cond_stride + i] : 0;
+    if (c < 0) c = 0;
+    if (c >= vocab_cond) c = vocab_cond - 1;
+    x[gid] = cond_emb[c * E + e] + pos_emb_cond[(long)i * E + e];
+}
+
+int rq_launch_cond_embed_multi(const int64_t* cond, int cond_stride, int n_tok, const float* cond_emb, int vocab_cond,
+                               const float* pos_emb_cond, float* x, int n_img, int E, hipStream_t s) {
+    const long n = (long)n_img * n_tok * E;
+    RQ_LAUNCH(cond_embed_multi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, cond, cond_stride, n_tok,
+              cond_emb, vocab_cond, pos_emb_cond, x, n_img, E);
+    return rq_check_launch("cond_embed_multi_kernel");
 }
 
 // =================================================================================================

@@ -52,6 +52,7 @@ _SIGS = {
                                    C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     'rqamd_rqt_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_rqt_set_profile': (C.c_int, [C.c_void_p, C.c_int]),
     'rqamd_rqt_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double)]),
@@ -331,6 +332,16 @@ class RqtEngine(_Engine):
         check(lib().rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
                                      ptr(out), stream_of(codes)))
         return out
+
+    def forward(self, codes, cond, codebooks):
+        """(seq_logits (B,H,W,D,V), cond_logits (B, block_size_cond-1, vocab_size_cond)) -- text-conditioned models"""
+        B = codes.shape[0]
+        c = self.cfg
+        out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
+        cl = torch.empty((B, c.block_size_cond - 1, max(c.vocab_size_cond, 1)), dtype=torch.float32, device=codes.device)
+        check(lib().rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
+                                      ptr(out), ptr(cl), stream_of(codes)))
+        return out, cl
 
     def set_profile(self, on):
         check(lib().rqamd_rqt_set_profile(self._h, int(bool(on))))

@@ -109,6 +109,20 @@ class RQTransformer(Stage2Model):
             raise ValueError('model_aux must be the RQVAE whose codebook embeds the codes (input_emb_vqvae=True)')
         return model_aux.quantizer.codebook_list()
 
+    def _checked_codebooks(self, model_aux):
+        """the engine gathers rows `code` < vocab_size of width input_embed_dim from these tables: anything else would read
+        out of bounds, so the shapes are checked here (the reference would fail in F.embedding / input_mlp)"""
+        cbs = self._codebooks(model_aux)
+        D = self.block_size[2]
+        if len(cbs) < D:
+            raise ValueError(f'model_aux has {len(cbs)} codebooks, the transformer needs {D}')
+        for d in range(D):
+            cb = cbs[d]
+            if cb.dim() != 2 or cb.shape[1] != self.config.input_embed_dim or cb.shape[0] < self.vocab_size[d]:
+                raise ValueError(f'codebook {d} has shape {tuple(cb.shape)}; expected (>= {self.vocab_size[d]}, '
+                                 f'{self.config.input_embed_dim})')
+        return cbs[:D]
+
     def _cond(self, cond, B, device):
         if cond is None:
             return None                                  # engine zero-fills (transformers.py:208-209)
@@ -127,7 +141,8 @@ class RQTransformer(Stage2Model):
         with torch.cuda.stream(side):
             out = fn()
         cur.wait_stream(side)
-        out.record_stream(cur)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            t.record_stream(cur)
         return out
 
     # ------------------------------------------------------------------ reference API
@@ -145,10 +160,17 @@ class RQTransformer(Stage2Model):
         engine's cached path over the given codes (identical to the uncached pass up to rounding --
         the reference's own cached==uncached invariant, transformers.py:352-356)."""
         if self.block_size_cond > 1:
-            # the reference returns (seq_logits, cond_logits); cond_logits come from cond_classifier over the
-            # conditioning positions and only feed the training loss (transformers.py:150-153,384-392)
-            raise NotImplementedError('text-conditioned forward() also returns cond_logits (training-side); '
-                                      'use teacher_forced_logits() for the image-code logits')
+            # (seq_logits, cond_logits): cond_classifier over the body outputs of the first cond_len-1 positions
+            # (transformers.py:150-153,185-186); the engine takes them from the multi-token prefill of the prefix
+            (B, H, W, D) = xs.shape
+            assert torch.Size([H, W, D]) == self.block_size
+            eng = self._eng()
+            cbs = self._checked_codebooks(model_aux)
+            codes = xs.to(torch.long).contiguous()
+            c = self._cond(cond, B, xs.device)
+            if c is None:
+                c = torch.zeros((B, self.block_size_cond), dtype=torch.long, device=xs.device)
+            return self._on_side_stream(xs.device, lambda: eng.forward(codes, c, cbs))
         return self.teacher_forced_logits(xs, model_aux, cond)
 
     @torch.no_grad()
@@ -157,7 +179,7 @@ class RQTransformer(Stage2Model):
         (B, H, W, D) = xs.shape
         assert torch.Size([H, W, D]) == self.block_size
         eng = self._eng()
-        cbs = self._codebooks(model_aux)
+        cbs = self._checked_codebooks(model_aux)
         codes = xs.to(torch.long).contiguous()
         c = self._cond(cond, B, xs.device)
         return self._on_side_stream(xs.device, lambda: eng.logits(codes, c, cbs))
@@ -187,7 +209,7 @@ class RQTransformer(Stage2Model):
         B = partial_sample.shape[0]
         device = partial_sample.device
         eng = self._eng()
-        cbs = self._codebooks(model_aux)
+        cbs = self._checked_codebooks(model_aux)
         xs = partial_sample.to(torch.long).contiguous()
         c = self._cond(cond, B, device)
         seed, offset = self._draw_rng(device, H * W * D)

@@ -175,6 +175,28 @@ def test_emu_rqt_text_conditioned_logits(nat, golden):
     logits = eng.logits(T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64)), [T(cb)] * 4).numpy()
     err = np.abs(logits - g['logits'])
     assert err.max() < 0.06 and err.mean() < 0.01
+    # forward(): (seq_logits, cond_logits) -- cond_classifier over the prefix rows of the multi-token prefill
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    seq, cl = eng.forward(T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64)), [T(cb)] * 4)
+    assert np.array_equal(seq.numpy(), logits)
+    ref = oracle.RQTransformerOracle(cfg, params).forward(g['codes'].astype(np.int64), [cb] * 4, g['cond'].astype(np.int64), return_cond_logits=True)
+    assert np.abs(cl.numpy() - ref[1]).max() < 0.06
+
+
+def test_emu_rqt_long_prefix(nat):
+    """70 conditioning tokens: the prefill attention runs two query blocks (69 prefix tokens), the body context is
+    16 + 69 = 85 keys (the 16-block DYN decode attention kernel); vs the oracle (pinned by the reference at 32 / 64 tokens)."""
+    cfg = C.rqt(128, 2, 1, 1, 500, vocab_cond=20, block_cond=70, block_size=(4, 4, 4), input_embed_dim=64)
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), 43)
+    rng = np.random.default_rng(44)
+    cb = rng.standard_normal((500, 64), dtype=np.float32)
+    codes, cond = rng.integers(0, 500, (2, 4, 4, 4)), rng.integers(0, 20, (2, 70))
+    eng = _rqt_engine(nat, cfg, params)
+    seq, cl = eng.forward(T(codes), T(cond), [T(cb)] * 4)
+    ref = oracle.RQTransformerOracle(cfg, params).forward(codes, [cb] * 4, cond, return_cond_logits=True)
+    e1, e2 = np.abs(seq.numpy() - ref[0]).max(), np.abs(cl.numpy() - ref[1]).max()
+    print('emu rqt long prefix: seq logits err %.4f, cond logits err %.4f' % (e1, e2))
+    assert e1 < 0.06 and e2 < 0.06
 
 
 def test_emu_rqt_tiny_sample(nat, golden):

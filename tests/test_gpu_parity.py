@@ -294,8 +294,8 @@ def test_rqt_text_conditioned(nat, golden):
     err = np.abs(logits - g['logits'])
     print('rqt tiny text-cond logits: max err %.4f mean %.5f' % (err.max(), err.mean()))
     assert err.max() < 0.06 and err.mean() < 0.01
-    with pytest.raises(NotImplementedError):
-        ar(G(g['codes'], torch.long), vae, cond=cond)
+    seq, cl = ar(G(g['codes'], torch.long), vae, cond=cond)          # (seq_logits, cond_logits), transformers.py:185-186
+    assert np.abs(N(seq) - g['logits']).max() < 0.06 and cl.shape == (2, 3, 20)
     torch.cuda.manual_seed_all(1)
     a = ar.sample(torch.zeros((2, 4, 4, 4), dtype=torch.long, device=DEV), vae, cond=cond, top_k=20, top_p=0.9)
     torch.cuda.manual_seed_all(1)
