@@ -27,6 +27,9 @@ class Config(dict):
     def copy(self):
         return Config(copy.deepcopy(dict(self)))
 
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
     def to_dict(self):
         return {k: v.to_dict() if isinstance(v, Config) else copy.deepcopy(v) for k, v in self.items()}
 
@@ -37,12 +40,42 @@ def load_config(config_path):
         return Config(yaml.load(fp, Loader=yaml.FullLoader))
 
 
+def _to_plain(cfg):
+    if hasattr(cfg, 'keys'):
+        return {k: _to_plain(cfg[k]) for k in cfg.keys()}
+    if isinstance(cfg, (list, tuple)) or type(cfg).__name__ == 'ListConfig':
+        return [_to_plain(v) for v in cfg]
+    return cfg
+
+
+def _merge(base, over):
+    out = copy.deepcopy(base)
+    for k, v in over.items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = _merge(out[k], v)
+        else:
+            out[k] = copy.deepcopy(v)
+    return out
+
+
+# config.py:31-43 of the reference: the defaults merged UNDER a stage-1 arch config
+RQVAE_ARCH_DEFAULTS = {
+    'ema': None,
+    'hparams': {'loss_type': 'l1', 'restart_unused_codes': False, 'use_padding_idx': False, 'masked_dropout': 0.0},
+    'checkpointing': False,
+}
+
+
+def is_stage1_arch(arch_type):
+    """config.py:25-26"""
+    return 'transformer' not in arch_type
+
+
 def augment_arch_defaults(arch_config):
-    """config.py:29-49"""
+    """config.py:29-49: OmegaConf.merge(arch_defaults, arch_config) -- the defaults first, the given config on top.
+    Accepts this module's Config, a plain dict or an OmegaConf node."""
     if arch_config.type == 'rq-vae':
-        out = Config({'ema': None})
-        out.update(arch_config.copy())
-        return out
+        return Config(_merge(RQVAE_ARCH_DEFAULTS, _to_plain(arch_config)))
     if arch_config.type == 'rq-transformer':
         return Config(resolve(arch_config))
     raise NotImplementedError
