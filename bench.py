@@ -11,13 +11,22 @@ of the reference's throughput script (:295-301).  Random-init weights of that ar
 One "step" = one batch of B images per GPU: sample -> decode -> clamp (-> pixel all-gather when N > 1,
 main_sampling_fid.py:226).  value = N * B * K / max-over-ranks time, inputs resident in HBM.
 
-Extra objects on the JSON line (prompt section 4): "roofline" for the dominant kernel (the bf16 MFMA
-weight-streaming GEMM of the decode step, timed live with HIP events on the engine's stream in a
-separate profiled pass) and "cpu_baseline" (the numpy oracle on the host cores, bounded sample, rank 0,
-N=1 only)."""
+Launching.  `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` re-executing this
+file, one process per GPU, RCCL); under an external torchrun (RANK / WORLD_SIZE in the environment) it joins
+that job.  The world size actually joined is what `n_gpus` reports.
+
+Extra objects on the JSON line: "roofline" for the dominant kernel (the bf16 MFMA weight-streaming GEMM of the
+decode step, timed live with HIP events on the engine's stream in a separate profiled pass), "batch_sweep" (the same
+measurement at the per-GPU batches of BASELINE configs[3] = 64 and of the reference's Fig. 4 = 500, each with its own
+roofline), "per_image_decode" (decode_code on ONE image per call, as the unchanged drivers call it), "roofline_rq"
+(the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the numpy oracle on the host cores, bounded
+sample, rank 0, N=1 only)."""
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,24 +38,48 @@ for _p in (ROOT, os.path.join(ROOT, 'rq-vae-transformer_amd')):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3    # fp32-input MFMA = fp32 vector rate
 A100_FIG4_IMG_S = 52.6          # reference Fig. 4, 1.4B 8x8x4, batch 500, 1x A100 (fp32)
+WORKLOADS = {'huge': 'BASELINE configs[2]', 'medium': 'BASELINE configs[1]', 'xhuge': 'BASELINE configs[3] dims',
+             'txt3900m': 'BASELINE configs[4] dims', 'cc3m': 'CC-3M 654M'}
 
 
-def build_models(device, model='huge'):
-    from oracle import configs as C
-    from rqvae.models.rqvae import RQVAE
-    from rqvae.models.rqtransformer import RQTransformer
-    cfg = {'huge': C.RQT_IN_1400M, 'large': C.RQT_IN_821M, 'medium': C.RQT_FFHQ_355M, 'xhuge': C.RQT_IN_3800M,
-           'tiny': C.RQT_TINY}[model]
-    vcfg = C.VAE_TINY if model == 'tiny' else (C.VAE_FFHQ if model == 'medium' else C.VAE_IMAGENET)
-    torch.manual_seed(0)
-    with torch.device(device):
-        hps, dd = vcfg
-        vae = RQVAE(**hps, ddconfig=dd, checkpointing=False).eval()
-        ar = RQTransformer(cfg).eval()
-    return vae, ar, cfg, vcfg
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 8192)), help='images per GPU per step')
+    ap.add_argument('--model', default='huge')
+    # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
+    ap.add_argument('--top-k', type=int, default=1024)
+    ap.add_argument('--top-p', type=float, default=0.95)
+    ap.add_argument('--sweep', type=str, default='64,500', help='extra per-GPU batches measured after the timed region ("" = none)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU/gloo rehearsal of the launcher, sharding, gather and timing logic with synthetic pixels (no kernels run; tests only)')
+    args = ap.parse_args(argv)
+    if args.top_k is not None and args.top_k <= 0:
+        args.top_k = None
+    if args.top_p is not None and args.top_p >= 1.0:
+        args.top_p = None
+    return args
+
+
+def self_launch(args, argv):
+    """No torchrun environment and --gpus N > 1: start the N ranks (one process per GPU) and relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
@@ -67,14 +100,14 @@ def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=2):
     import threadpoolctl
     aparams = {k: v.detach().float().cpu().numpy() for k, v in ar.state_dict().items()}
     vparams = {k: v.detach().float().cpu().numpy() for k, v in vae.state_dict().items()}
-    hps, dd = vcfg
     orc = oracle.RQTransformerOracle(cfg, aparams)
-    ov = oracle.RQVAEOracle(hps, dd, vparams)
+    ov = oracle.RQVAEOracle(vcfg['hparams'], vcfg['ddconfig'], vparams)
     H, W, D = cfg['block_size']
     cores = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
     part = np.zeros((batch, H, W, D), np.int64)
+    cl = max(cfg.get('block_size_cond', 1), 1)
     t0 = time.time()
-    xs = orc.sample(part, ov.codebooks, cond=np.zeros((batch, 1), np.int64), max_steps=n_pos * D)
+    xs = orc.sample(part, ov.codebooks, cond=np.zeros((batch, cl), np.int64), max_steps=n_pos * D)
     t_ar = (time.time() - t0) * (H * W / n_pos) / batch            # seconds per image
     t0 = time.time()
     ov.decode_code(xs[:1])
@@ -84,28 +117,174 @@ def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=2):
                       f'= {t_ar:.1f} s/img AR + one full 256x256 decode_code = {t_dec:.1f} s/img'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 8192)), help='images per GPU per step')
-    ap.add_argument('--model', default='huge')
-    # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
-    ap.add_argument('--top-k', type=int, default=1024)
-    ap.add_argument('--top-p', type=float, default=0.95)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
-    args = ap.parse_args()
-    if args.top_k is not None and args.top_k <= 0:
-        args.top_k = None
-    if args.top_p is not None and args.top_p >= 1.0:
-        args.top_p = None
+def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model, B):
+    """Profiled pass: every decode-step GEMM launch bracketed by HIP events on the engine's stream (graphs off for this pass)."""
+    eng = ar._eng()
+    eng.set_profile(True)
+    ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=top_k, top_p=top_p)
+    torch.cuda.synchronize(device)
+    pf = eng.get_profile()
+    eng.set_profile(False)
+    if not (pf['gemm_launches'] > 0 and pf['gemm_ms_total'] > 0):
+        return None
+    sec = pf['gemm_ms_total'] * 1e-3
+    gbs = pf['gemm_bytes'] / sec / 1e9
+    tfl = pf['gemm_flops'] / sec / 1e12
+    ridge = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    intensity = pf['gemm_flops'] / pf['gemm_bytes']
+    if intensity < ridge:
+        roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
+    else:
+        roofline = {'bound': 'mfma', 'achieved': tfl, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
+    traffic, traffic_src = None, None
+    for rnd in ('r02', 'r01'):
+        tp = os.path.join(ROOT, 'profiles', f'{rnd}_gemm_traffic_m{B}.json')
+        if model == 'huge' and os.path.exists(tp):
+            # PMC counters cannot be collected from inside the timed run; this is the committed result of
+            # scripts/gpu_pmc2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM
+            # shapes at the same batch rows, launch-weighted like `achieved`
+            with open(tp) as f:
+                tj = json.load(f)
+            traffic, traffic_src = tj['hbm_bytes_per_launch_weighted'], os.path.relpath(tp, ROOT)
+            break
+    roofline.update({'traffic': traffic, 'traffic_source': traffic_src, 'traffic_measured_in_run': False,
+                     'algorithmic_bytes_per_launch': pf['gemm_bytes'] / pf['gemm_launches'], 'kernel': 'decode-step bf16 MFMA GEMMs (gemm_* kernels)',
+                     'launches_per_batch': pf['gemm_launches'], 'avg_launch_us': pf['gemm_ms_total'] * 1e3 / pf['gemm_launches'],
+                     'algorithmic_GB_per_batch': pf['gemm_bytes'] / 1e9, 'algorithmic_TFLOP_per_batch': pf['gemm_flops'] / 1e12,
+                     'achieved_GBps': gbs, 'achieved_TFLOPs': tfl, 'flop_per_byte': intensity})
+    return roofline
+
+
+def timed_batch(vae, ar, B, device, top_k, top_p, steps, warmup):
+    """sample -> decode -> clamp at per-GPU batch B; returns (img/s, AR ms/img, decode ms/img)."""
+    es = torch.zeros((B,) + tuple(ar.block_size), device=device, dtype=torch.long)
+    ec = torch.zeros((B, ar.block_size_cond), device=device, dtype=torch.long)
+    for _ in range(warmup):
+        one_step(vae, ar, es, ec, None, top_k, top_p)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_ar = t_dec = 0.0
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev[0].record()
+        codes = ar.sample(es, model_aux=vae, cond=ec, top_k=top_k, top_p=top_p)
+        ev[1].record()
+        pixels = vae.decode_code(codes)
+        pixels.mul_(0.5).add_(0.5).clamp_(0, 1)
+        ev[2].record()
+        ev[2].synchronize()
+        t_ar += ev[0].elapsed_time(ev[1])
+        t_dec += ev[1].elapsed_time(ev[2])
+        del pixels
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    return B * steps / el, t_ar / (steps * B), t_dec / (steps * B), es, ec
+
+
+def per_image_decode(vae, ar, device, n=64):
+    """The unchanged drivers decode ONE image per call (measure_throughput/__main__.py:297-299,
+    main_sampling_fid.py:223): torch.cat([decode_code(codes[i:i+1]) for i in range(B)])."""
+    V = ar.vocab_size[0]
+    codes = torch.randint(0, V, (n,) + tuple(ar.block_size), device=device)
+    for i in range(4):
+        vae.decode_code(codes[i:i + 1])
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    pixels = torch.cat([vae.decode_code(codes[i:i + 1]) for i in range(n)], dim=0)
+    pixels = (0.5 * pixels + 0.5).clamp(0, 1)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return {'ms_per_image': ms, 'images_per_sec': 1e3 / ms, 'images': n,
+            'what': 'decode_code(codes[i:i+1]) one image per call + cat + clamp, as measure_throughput/__main__.py:297-299 does'}
+
+
+def rq_roofline(vae, device, n_img=256):
+    """Residual quantiser alone (RQBottleneck.quantize on encoder-shaped latents): FLOPs 2*K*D per vector-depth, bytes =
+    z read + quants/codes written + codebook once."""
+    q = vae.quantizer
+    cbs = q.codebook_list()
+    K, Dm = cbs[0].shape
+    depth = len(cbs)
+    z = torch.randn((n_img, 8, 8, Dm), device=device)
+    q.quantize(z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        q.quantize(z)
+    e1.record()
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    nvec = n_img * 64
+    flops = 2.0 * K * Dm * nvec * depth
+    byts = nvec * Dm * 4 * (1 + depth) + nvec * depth * 8 + K * Dm * 4
+    return {'bound': 'fp32-mfma', 'achieved': flops / sec / 1e12, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': flops / sec / 1e12 / MFMA_F32_PEAK_TFLOPS, 'achieved_GBps': byts / sec / 1e9, 'hbm_frac': byts / sec / 1e9 / HBM_PEAK_GBS,
+            'images': n_img, 'K': int(K), 'dim': int(Dm), 'depth': depth, 'us_per_launch': sec * 1e6,
+            'images_per_sec': n_img / sec, 'codes_per_sec': n_img * 64 * depth / sec,
+            'what': 'RQBottleneck.quantize (all depths, one launch) incl. the cumulative quant_list outputs'}
+
+
+def dry_run(args, rank, world, local_rank):
+    """CPU / gloo rehearsal (tests/test_dist_gloo.py): everything around the kernels -- rank environment, per-rank seeds,
+    label sharding, the pixel all-gather in rank order, barrier-bracketed timing with the max over ranks, the JSON line."""
+    import torch.distributed as dist
+    from rqvae.utils.dist import DistEnv, all_gather_cat
+    from rqvae.utils.utils import set_seed
+    distenv = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', init_method='env://', world_size=world, rank=rank)
+        distenv = DistEnv(world, rank, local_rank, 1, rank == 0, 'cpu')
+    set_seed(0 + rank)
+    B = args.batch
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        pass
+    sync()
+    t0 = time.perf_counter()
+    checks = []
+    for step in range(args.steps):
+        pixels = torch.full((B, 3, 4, 4), float(rank)) + torch.arange(B, dtype=torch.float32).view(B, 1, 1, 1) / 1000.0
+        if distenv is not None:
+            pixels = all_gather_cat(distenv, pixels)
+        checks.append(bool(pixels.shape[0] == world * B and all(float(pixels[r * B, 0, 0, 0]) == float(r) for r in range(world))))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-run (no kernels): launcher / sharding / gather / timing rehearsal', 'value': world * B * args.steps / elapsed,
+                          'unit': 'images/sec', 'n_gpus': world, 'world_size': world, 'requested_gpus': args.gpus, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'none', 'data': 'dry-run', 'gather_rank_major_ok': all(checks),
+                          'config': {'workload': 'dry-run', 'batch_per_gpu': B, 'global_batch': B * world}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return self_launch(args, argv)
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}', file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, rank, world, local_rank)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback exists)'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -115,11 +294,14 @@ def main():
         from rqvae.utils.dist import DistEnv
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+        assert dist.get_world_size() == world
         distenv = DistEnv(world, rank, local_rank, 1, rank == 0, torch.cuda.get_device_name())
     torch.set_grad_enabled(False)
 
+    from rqvae import presets
     from rqvae.utils.utils import set_seed
-    vae, ar, cfg, vcfg = build_models(device, args.model)
+    vae, ar, cfg = presets.build(args.model, device=device, seed=0)
+    vcfg = presets.RQVAE[presets.RQTRANSFORMER[args.model][1]]
     set_seed(0 + rank)                                   # main_sampling_fid.py:166-169
     B = args.batch
     empty_sample = torch.zeros((B,) + tuple(ar.block_size), device=device, dtype=torch.long)
@@ -178,51 +360,38 @@ def main():
         del pixels                                           # the gathered images (world x 6.4 GB) are freed before the next step
     sync()
     elapsed = time.perf_counter() - t0
+    rank_times = [elapsed]
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_times = [float(x.item()) for x in allt]
+        elapsed = max(rank_times)
 
-    # ---- roofline of the dominant kernel (profiled pass: every GEMM launch bracketed by HIP events on
-    # the engine's stream; graphs off for this pass only)
+    # ---- roofline of the dominant kernel at the timed batch
     roofline = None
     if rank == 0 and not args.no_profile:
-        eng = ar._eng()
-        eng.set_profile(True)
-        ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=args.top_k, top_p=args.top_p)
-        torch.cuda.synchronize(device)
-        pf = eng.get_profile()
-        eng.set_profile(False)
-        if pf['gemm_launches'] > 0 and pf['gemm_ms_total'] > 0:
-            sec = pf['gemm_ms_total'] * 1e-3
-            gbs = pf['gemm_bytes'] / sec / 1e9
-            tfl = pf['gemm_flops'] / sec / 1e12
-            ridge = MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-            intensity = pf['gemm_flops'] / pf['gemm_bytes']
-            if intensity < ridge:
-                roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
-            else:
-                roofline = {'bound': 'mfma', 'achieved': tfl, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
-            traffic, traffic_src = None, None
-            tp = os.path.join(ROOT, 'profiles', f'r01_gemm_traffic_m{B}.json')
-            if args.model == 'huge' and os.path.exists(tp):
-                # PMC counters cannot be collected from inside the timed run; this is the committed result of
-                # scripts/gpu_pmc2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM
-                # shapes at the same batch rows, launch-weighted like `achieved`
-                with open(tp) as f:
-                    tj = json.load(f)
-                traffic, traffic_src = tj['hbm_bytes_per_launch_weighted'], os.path.relpath(tp, ROOT)
-            roofline.update({'traffic': traffic, 'traffic_source': traffic_src,
-                             'algorithmic_bytes_per_launch': pf['gemm_bytes'] / pf['gemm_launches'], 'kernel': 'gemm_bf16_kernel', 'launches_per_batch': pf['gemm_launches'],
-                             'avg_launch_us': pf['gemm_ms_total'] * 1e3 / pf['gemm_launches'],
-                             'algorithmic_GB_per_batch': pf['gemm_bytes'] / 1e9, 'algorithmic_TFLOP_per_batch': pf['gemm_flops'] / 1e12,
-                             'achieved_GBps': gbs, 'achieved_TFLOPs': tfl, 'flop_per_byte': intensity})
+        roofline = gemm_roofline(ar, vae, empty_sample, empty_cond, args.top_k, args.top_p, device, args.model, B)
 
-    # ---- BASELINE.json's second metric, codes/sec of the RQ-VAE (encode + residual quantisation), outside the timed region
-    enc = None
+    # ---- the same measurement at smaller per-GPU batches (BASELINE configs[3] per-GPU share, reference Fig. 4 batch)
+    sweep = []
+    if rank == 0 and world == 1 and args.sweep:
+        for b in [int(x) for x in args.sweep.split(',') if x]:
+            if b == B:
+                continue
+            ips, a_ms, d_ms, es, ec = timed_batch(vae, ar, b, device, args.top_k, args.top_p, steps=3 if b >= 256 else 5, warmup=1)
+            entry = {'batch_per_gpu': b, 'images_per_sec': ips, 'ar_ms_per_image': a_ms, 'decode_ms_per_image': d_ms,
+                     'ar_ms_per_batch': a_ms * b}
+            if not args.no_profile:
+                entry['roofline'] = gemm_roofline(ar, vae, es, ec, args.top_k, args.top_p, device, args.model, b)
+            sweep.append(entry)
+            del es, ec
+
+    # ---- per-image decode (the drivers' call pattern), BASELINE's second metric (codes/sec) and the quantiser roofline
+    pid = enc = rqr = None
     if rank == 0 and not args.no_profile:
+        pid = per_image_decode(vae, ar, device)
         xb = torch.randn((256, 3, 256, 256), device=device).clamp(-1, 1)
         vae.get_codes(xb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -233,8 +402,9 @@ def main():
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 3
         enc = {'codes_per_sec': 256 * 256 / ms * 1e3, 'images_per_sec': 256 / ms * 1e3, 'batch': 256,
-               'what': 'RQVAE.get_codes: 256x256 encode + depth-4 residual quantisation (K=16384), 256 codes per image'}
+               'what': 'RQVAE.get_codes: 256x256 encode + depth-4 residual quantisation, 256 codes per image'}
         del xb
+        rqr = rq_roofline(vae, device)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -247,25 +417,32 @@ def main():
         n_img = world * B * args.steps
         value = n_img / elapsed
         out = {
-            'metric': '256x256 images/sec, AR sampling + decode (ImageNet RQ-Transformer 1.4B, 8x8x4 codes)',
+            'metric': f'256x256 images/sec, AR sampling + decode (RQ-Transformer {args.model}, 8x8x4 codes)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            # context only: a B = 8192 bf16 MI355X number over the reference's B = 500 fp32 A100 number;
+            # the like-for-like batch is batch_sweep's 500 entry
             'vs_baseline': value / (A100_FIG4_IMG_S * world) if args.model == 'huge' else None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'ImageNet-256 class-conditional RQ-Transformer {args.model} sampling 8x8x4 codes + RQ-VAE decode '
-                                   f'(BASELINE configs[2]); random-init weights, zero class condition',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'top_k': args.top_k, 'top_p': args.top_p, 'overlap_decode_with_next_sampling': bool(args.overlap),
-                       'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather per step' if world > 1 else 'single GPU',
-                       'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU'},
-            'ar_ms_per_image': t_ar / (args.steps * B), 'decode_ms_per_image': t_dec / (args.steps * B),
-            'roofline': roofline, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'config': {'workload': f'RQ-Transformer {args.model} ({WORKLOADS.get(args.model, args.model)}) sampling 8x8x4 codes + RQ-VAE decode; '
+                                   f'random-init weights, zero condition',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'top_k': args.top_k, 'top_p': args.top_p,
+                       'overlap_decode_with_next_sampling': bool(args.overlap), 'world_size': world, 'requested_gpus': args.gpus,
+                       'per_rank_seconds': rank_times,
+                       'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather (RCCL) per step' if world > 1 else 'single GPU',
+                       'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU; '
+                                          'different batch / precision / hardware -- context, not a like-for-like ratio'},
+            'ar_ms_per_image': t_ar / (args.steps * B) if not args.overlap else None,
+            'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
+            'roofline': roofline, 'batch_sweep': sweep, 'per_image_decode': pid, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 1
+#define RQAMD_ABI_VERSION 2
 
 typedef enum {
     RQAMD_OK = 0,
@@ -40,16 +40,20 @@ const char* rqamd_last_error(void);
  * all depths.  x (n_vec, dim) fp32; codebooks[d] (n_embed[d], dim) fp32 WITHOUT the padding row
  * (pass weight[:-1]); the same pointer repeated = shared codebook.  codes (n_vec, depth) int64;
  * quant_cum (depth, n_vec, dim) fp32 cumulative quants (quant_list) or NULL.
+ * code_norms[d] (n_embed[d]) fp32 = ||c||^2 per code from rqamd_rq_code_norms, owned and cached by the caller per codebook
+ * version (no library-side scratch: calls on different streams / threads never share state).
  * Distances use the reference's expanded form ||x||^2+||c||^2-2x.c in fp32; ties -> lowest index. */
-int rqamd_rq_quantize(const float* x, const float* const* codebooks, const int* n_embed, int depth,
-                      int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream);
+int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
+                      int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream);
+/* rqamd_rq_code_norms <- the codebook_t.pow(2).sum(0) term of compute_distances (quantizations.py:51-52). */
+int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream);
 
 /* rqamd_rq_embed <- RQBottleneck.embed_code :297-311 (mode 0: sum over depth),
  * embed_code_with_depth :313-334 (mode 1: (n_vec, depth, dim)), and the depth-cumsum the sampler
  * feeds to head_mlp (transformers.py:157-160; mode 2).  codes (n_vec, depth) int64; out fp32.
- * Out-of-range codes are an error in the reference (index error); here they clamp to the zero
- * padding row semantics: code == n_embed selects zeros, anything else out of range -> RQAMD_ERR_INVALID
- * is NOT detectable asynchronously, so callers validate (the Python mirror asserts). */
+ * code == n_embed selects the zero padding row (quantizations.py:28).  Any other out-of-range code is an index error in
+ * the reference (F.embedding's device-side assert); here the kernel traps, which surfaces as a HIP error at the next
+ * synchronisation -- it cannot be reported asynchronously through the return value, and it is never silent zeros. */
 int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,
                    int64_t n_vec, int dim, int mode, float* out, void* stream);
 
@@ -61,10 +65,11 @@ int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const in
  * on Philox4x32-10 keyed by (seed, offset).  No host synchronisation.  top_k <= 0 or >= vocab: no
  * top-k; top_p < 0: no nucleus step (top_p = 1.0 still runs it, as the reference does,
  * transformers.py:323-324).  probs_out (rows, vocab) fp32 receives the filtered distribution
- * (parity hook) or NULL; samples_out (rows) int64 or NULL. */
+ * (parity hook) or NULL; samples_out (rows) int64 or NULL.  row_flags: caller-owned scratch of `rows` ints (lets rows
+ * whose top-k survivors fit in registers skip the general kernel) or NULL. */
 int rqamd_sample_logits(const float* logits, int rows, int vocab, float temperature, int top_k,
                         float top_p, uint64_t seed, uint64_t offset, int64_t* samples_out,
-                        float* probs_out, void* stream);
+                        float* probs_out, int* row_flags, void* stream);
 
 /* ---- RQ-VAE encoder / decoder engine -------------------------------------------------------
  * Handle = packed bf16 weights + activation workspace for Encoder/Decoder (modules.py:10-202),

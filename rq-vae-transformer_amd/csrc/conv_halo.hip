@@ -542,11 +542,10 @@ int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, 
     ConvOutArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.y = y; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const size_t smem = (size_t)(Cin / 64) * O_PLANE + 8 * (size_t)(9 * Cin * 2 + 32);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)conv_out_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_out_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     const int n_mt = B * (H / OT_H) * (W / HT_W);
     const int nblocks = 8 * ((n_mt + 7) / 8);
@@ -668,10 +667,9 @@ int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf
     ConvInArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W;
     const size_t smem = 4096 + 128 + (size_t)CI_COUT * CI_WROW + 4 * (size_t)CI_STG;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)conv_in_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
     }
     RQ_LAUNCH(conv_in_mfma_kernel, dim3((unsigned)(B * (H / HT_H) * (W / HT_W))), dim3(256), smem, s, a);
     return rq_check_launch("conv_in_mfma_kernel");
@@ -736,12 +734,11 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     constexpr size_t patch = (size_t)(TH + 2) * HP_W * 128, stage = (TH == 8 ? 2 : 1) * patch + 2 * HW_BYTES;
     constexpr size_t epi = (size_t)TH * HT_W * (H_BN * 2 + 16);
     const size_t smem = stage > epi ? stage : epi;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;

@@ -93,8 +93,8 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: head_dim must be 64 (embed_dim=%d n_head=%d)", c->embed_dim, c->n_head);
     if (c->embed_dim % 64 || c->input_embed_dim % 64 || c->embed_dim > 4096)
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: embed_dim / input_embed_dim must be multiples of 64, embed_dim <= 4096");
-    if (c->n_layer_body < 1 || c->n_layer_head < 1)
-        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: needs >= 1 body and head layer (depth-1 'vqgan' variants unsupported)");
+    if (c->n_layer_body < 1 || c->n_layer_head < 0)      // head.n_layer = 0: the depth-1 "VQ-GAN" shapes (measure_throughput/__main__.py:166-210)
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: needs >= 1 body layer and >= 0 head layers");
     if (c->D < 1 || c->D > 8 || c->H < 1 || c->W < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: bad block_size");
     rqamd_rqt* h = new rqamd_rqt();
     h->cfg = *c;
@@ -434,6 +434,7 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         }
         ResidLnArgs r{};
         r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
+        if (h->head.empty()) { r.x_in = x_in; r.addvec = addvec; }     // no head stack: the classifier sees the head token itself
         r.gamma = h->cls_lnw; r.beta = h->cls_lnb; r.y = h->y; r.rows = B; r.E = E; r.eps = 1e-5f;
         RQ_TRY(rq_launch_resid_ln(r, st));
         RQ_TRY(step_gemm(h, h->y, E, h->w_cls, B, h->V, E, EPI_F32, h->b_cls, nullptr, 0, h->logits, h->V, nullptr, st));

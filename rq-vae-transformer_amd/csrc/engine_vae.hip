@@ -242,6 +242,11 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
     size_t mid = (size_t)lowres * lowres * c.ch * c.ch_mult[c.n_levels - 1] * 3;
     if (mid > per_img) per_img = mid;
     if (chunk <= h->chunk && h->buf[0]) return RQAMD_OK;
+    // failure-atomic regrowth: forget the old capacity before anything is freed, record the new one only after every
+    // allocation succeeded (a failed hipMalloc leaves the handle empty -- chunk 0, no buffers -- never dangling)
+    h->chunk = 0;
+    h->cap_elems = 0;
+    for (int i = 0; i < 5; ++i) h->buf[i] = nullptr;
     const size_t elems = per_img * chunk;
     const size_t bytes = (elems * 2 + 255) & ~(size_t)255;
     RQ_TRY(h->ws.reserve(bytes * 5));

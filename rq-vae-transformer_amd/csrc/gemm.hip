@@ -6,10 +6,9 @@
 template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * (GL ? GL : 2);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
     }
     // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
     GemmArgs g = a;
@@ -47,10 +46,9 @@ static int launch_rb(const GemmArgs& a, hipStream_t stream) {
     constexpr int BN = 128;
     constexpr size_t stage = (size_t)(BM + BN) * 32 * 2, epi = (size_t)BM * (BN * 2 + 16);
     const size_t smem = NS * stage > epi ? NS * stage : epi;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_rb_kernel<BM, TR, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_done = true;
     }
     GemmArgs g = a;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;

@@ -246,7 +246,10 @@ __global__ void rq_embed_kernel(RqEmbedArgs p) {
     for (int d = 0; d < p.depth; ++d) {
         long code = p.codes[v * p.depth + d];
         f32x4 e = {0.f, 0.f, 0.f, 0.f};
-        if (code >= 0 && code < p.K[d]) e = *(const f32x4*)(p.cb[d] + code * p.dim + f * 4);   // row K = zero padding
+        // row K is the zero padding row of VQEmbedding (quantizations.py:28); anything else outside [0, K] is an index
+        // error in the reference (F.embedding's device-side assert) and a trap here -- never silent zeros
+        if (code < 0 || code > p.K[d]) rq_trap();
+        if (code < p.K[d]) e = *(const f32x4*)(p.cb[d] + code * p.dim + f * 4);
         if (p.mode == 1) {
             *(f32x4*)(p.out + ((v * p.depth + d) * p.dim) + f * 4) = e;
         } else {
@@ -258,45 +261,38 @@ __global__ void rq_embed_kernel(RqEmbedArgs p) {
 }
 
 // -------------------------------------------------------------------------------------------------
-static DevBuf g_cn_buf;   // ||c||^2 scratch (per process; calls on one stream at a time)
+// ||c||^2 of every code of one codebook (the ||e||^2 term of VQEmbedding.compute_distances, quantizations.py:51-52), computed
+// ONCE per codebook version by the caller and passed to every rqamd_rq_quantize on it (it used to be recomputed per call into a
+// process-global scratch buffer, which was neither stream- nor thread-safe).
+extern "C" int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream) {
+    if (!codebook || !norms_out || n_embed < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_code_norms: bad argument");
+    if (dim % 4 != 0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_code_norms: dim %d %% 4 != 0", dim);
+    RQ_LAUNCH(rq_code_norm_kernel, dim3((n_embed + 255) / 256), dim3(256), 0, (hipStream_t)stream, codebook, n_embed, dim, norms_out);
+    return rq_check_launch("rq_code_norm_kernel");
+}
 
-extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, const int* n_embed, int depth,
-                                 int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream) {
+extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
+                                 int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream) {
     if (n_vec == 0) return RQAMD_OK;
-    if (!x || !codebooks || !n_embed || !codes) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: null argument");
+    if (!x || !codebooks || !code_norms || !n_embed || !codes) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: null argument");
     if (depth < 1 || depth > RQ_MAX_DEPTH) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: depth %d not in 1..%d", depth, RQ_MAX_DEPTH);
     if (dim % 64 != 0 || dim < 64 || dim > 256)
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: dim %d must be 64, 128, 192 or 256", dim);
-    if (n_vec == 0) return RQAMD_OK;
     if (n_vec < 0) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: n_vec < 0");
     hipStream_t st = (hipStream_t)stream;
     RqQuantArgs a{};
-    size_t total = 0;
     for (int d = 0; d < depth; ++d) {
-        if (n_embed[d] < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: empty codebook");
-        total += (size_t)n_embed[d];
-    }
-    RQ_TRY(g_cn_buf.reserve(total * sizeof(float)));
-    size_t off = 0;
-    for (int d = 0; d < depth; ++d) {
+        if (n_embed[d] < 1 || !codebooks[d] || !code_norms[d]) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: empty codebook / missing norms");
         a.cb[d] = codebooks[d];
         a.K[d] = n_embed[d];
-        int shared = -1;
-        for (int e = 0; e < d; ++e)
-            if (codebooks[e] == codebooks[d] && n_embed[e] == n_embed[d]) { shared = e; break; }
-        if (shared >= 0) { a.cn[d] = a.cn[shared]; continue; }
-        float* cn = g_cn_buf.as<float>() + off;
-        off += n_embed[d];
-        RQ_LAUNCH(rq_code_norm_kernel, dim3((n_embed[d] + 255) / 256), dim3(256), 0, st, codebooks[d], n_embed[d], dim, cn);
-        a.cn[d] = cn;
+        a.cn[d] = code_norms[d];
     }
     a.x = x; a.depth = depth; a.dim = dim; a.n_vec = n_vec; a.codes = codes; a.quant_cum = quant_cum;
     const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float)
                         + (4 * QT_M + QT_M) * sizeof(int);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)rq_quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     RQ_LAUNCH(rq_quantize_kernel, dim3((unsigned)((n_vec + QT_M - 1) / QT_M)), dim3(256), smem, st, a);
     return rq_check_launch("rq_quantize_kernel");

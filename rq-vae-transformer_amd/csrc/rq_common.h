@@ -2,6 +2,7 @@
 #pragma once
 #include <stdarg.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 #include "rq_hip.h"
 #include "../../include/rqamd.h"
@@ -33,6 +34,18 @@ static inline int rq_check_launch(const char* what) {
         int s_ = (call);            \
         if (s_ != RQAMD_OK) return s_; \
     } while (0)
+
+// true exactly once per (call site, device): kernel attributes such as the dynamic-LDS limit are per device, and a process
+// may drive several (model.to('cuda:1') with current device 0, one engine per device)
+struct RqDeviceOnce {
+    std::atomic<unsigned long long> seen{0};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        return !(seen.fetch_or(bit) & bit);
+    }
+};
 
 // device buffer with RAII (engine-owned workspace)
 extern int g_rq_row_scale;     // diagnostics (api.hip): variant selection sees rows * this factor

@@ -8,6 +8,11 @@
 // residual add (+ split-K slab reduce + bias) fused with LayerNorm
 // NS = number of split-K slabs (compile time: all slab loads are issued back to back, the kernel is
 // latency-bound otherwise); each thread owns float4 columns tid, tid+256, ... of its row.
+// 32 random bits -> uniform strictly inside (0,1): (2k+1) * 2^-24 for k = r >> 9 -- every value is exactly representable
+// (an odd 24-bit integer times 2^-24), the smallest is 2^-24 and the largest 1 - 2^-24.  ((r >> 8) + 0.5) * 2^-24 is NOT safe:
+// 16777215.5 rounds to 2^24, u = 1, -log(u) = -0 and the exponential race divides by it.)
+static __device__ __forceinline__ float rq_u01(uint32_t r) { return fmaf((float)(r >> 9), 1.0f / 8388608.0f, 1.0f / 16777216.0f); }
+
 template <int NS>
 __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
     __shared__ float red[8];
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs p) {
         for (int e = 0; e < 4; ++e) {
             const int i = i4 * 4 + e;
             if (i < V) {
-                const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+                const float u = rq_u01(r[e]);
                 const float sc = sx[i] / (-logf(u));
                 if (sc > best) { best = sc; besti = i; }
             }
@@ -1058,7 +1063,7 @@ static __device__ __forceinline__ void sample_tail(const SampleArgs& p, float (&
         unsigned r[4];
         philox4x32_10((unsigned)(i >> 2), (unsigned)row, (unsigned)off, (unsigned)(off >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
         const unsigned w = (i & 3) == 0 ? r[0] : (i & 3) == 1 ? r[1] : (i & 3) == 2 ? r[2] : r[3];
-        const float u = ((float)(w >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+        const float u = rq_u01(w);
         const float sc = q[k] / (-logf(u));
         if (sc > best || (sc == best && i < besti)) { best = sc; besti = i; }
     }
@@ -1219,7 +1224,7 @@ __global__ __launch_bounds__(256) void sample_gumbel_kernel(SampleArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = i4 * 4 + e;
-            const float u = ((float)(r[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+            const float u = rq_u01(r[e]);
             float x = v[e] * inv_t;
             if (x != x) x = NEG_INF;                                            // NaN scrub (utils.py:103-105)
             const float sc = x - __logf(-__logf(u));
@@ -1251,10 +1256,9 @@ int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
         return rq_check_launch("sample_gumbel_kernel");
     }
     const size_t smem = (size_t)a.V * 4 + 16 * 4 + 16 * 4 + 256 * 4 + 4 * 4 + 32 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
     }
     SampleArgs b = a;
     static const bool env_lds_only = getenv("RQAMD_SAMPLER_LDS") != nullptr;      // A/B switch
@@ -1270,20 +1274,12 @@ int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
     return rq_check_launch("sample_kernel");
 }
 extern "C" int rqamd_sample_logits(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p,
-                                   uint64_t seed, uint64_t offset, int64_t* samples_out, float* probs_out, void* stream) {
+                                   uint64_t seed, uint64_t offset, int64_t* samples_out, float* probs_out, int* row_flags, void* stream) {
     if (!logits || rows < 0) return rq_fail(RQAMD_ERR_INVALID, "sample_logits: bad argument");
     if (rows == 0) return RQAMD_OK;
     SampleArgs a{};
     a.logits = logits; a.rows = rows; a.V = vocab; a.temperature = temperature; a.top_k = top_k; a.top_p = top_p;
     a.seed = seed; a.offset = offset; a.out = samples_out; a.out_stride = 1; a.probs_out = probs_out; a.D = 1;
-    // per-row hand-back flags of the top-k kernel: a cached device buffer (this entry is the stand-alone sampler;
-    // the sampling engine passes its own workspace)
-    static std::mutex mu;
-    static DevBuf* flags = new DevBuf();     // never destroyed: no hipFree after the runtime has shut down
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        RQ_TRY(flags->reserve((size_t)rows * sizeof(int)));
-        a.redo = flags->as<int>();
-    }
+    a.redo = row_flags;     // caller-owned (rows ints) or NULL: without it every row takes the general kernel
     return rq_launch_sample(a, (hipStream_t)stream);
 }

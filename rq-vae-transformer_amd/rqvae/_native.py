@@ -3,6 +3,7 @@ reference's ``rqvae.models`` API and the gfx950 kernels.
 
 There is no CPU path: if the library (or a GPU tensor) is missing this module raises.  PyTorch is used
 for device memory and streams only; every argument crossing the ABI is a raw pointer / size."""
+import contextlib
 import ctypes as C
 import os
 
@@ -12,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
 
 _lib = None
-_allow_host_pointers = False   # flipped only by the emulator tests (tests/emu), never by product code
+ABI_VERSION = 2
 
 
 class RqamdError(RuntimeError):
@@ -34,12 +35,13 @@ class RqtConfig(C.Structure):
 _SIGS = {
     'rqamd_abi_version': (C.c_int, []),
     'rqamd_last_error': (C.c_char_p, []),
-    'rqamd_rq_quantize': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
-                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_rq_quantize': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_rq_code_norms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_sample_logits': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_vae_create': (C.c_int, [C.POINTER(VaeConfig), C.POINTER(C.c_void_p)]),
     'rqamd_vae_destroy': (C.c_int, [C.c_void_p]),
     'rqamd_vae_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
@@ -75,8 +77,8 @@ def _bind(path):
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
-    if lib.rqamd_abi_version() != 1:
-        raise RqamdError(f'{path}: ABI version {lib.rqamd_abi_version()} != 1')
+    if lib.rqamd_abi_version() != ABI_VERSION:
+        raise RqamdError(f'{path}: ABI version {lib.rqamd_abi_version()} != {ABI_VERSION} (rebuild: python rq-vae-transformer_amd/build.py)')
     return lib
 
 
@@ -88,14 +90,6 @@ def lib():
             raise RqamdError(f'{LIB_PATH} not found: build it with `python rq-vae-transformer_amd/build.py` '
                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
         _lib = _bind(LIB_PATH)
-    return _lib
-
-
-def _load_for_testing(path, allow_host_pointers):
-    """tests/emu only: bind another build of the same sources (the host emulator)."""
-    global _lib, _allow_host_pointers
-    _lib = _bind(path)
-    _allow_host_pointers = allow_host_pointers
     return _lib
 
 
@@ -113,7 +107,7 @@ def ptr(t, dtype=None):
     """Raw device pointer of a contiguous tensor (validated)."""
     if t is None:
         return None
-    if not t.is_cuda and not _allow_host_pointers:
+    if not t.is_cuda:
         raise RqamdError('librqamd needs CUDA(HIP) tensors on an MI355X; got a CPU tensor (no CPU fallback exists)')
     if not t.is_contiguous():
         raise ValueError('non-contiguous tensor passed to librqamd')
@@ -128,6 +122,14 @@ def stream_of(t):
     return C.c_void_p(0)
 
 
+def on_device_of(t):
+    """Context that makes t's device the current HIP device for the duration of a native call: the library allocates
+    (engine workspaces, graphs) and sets kernel attributes on the CURRENT device, while the stream passed in belongs to
+    the tensor's device -- model.to('cuda:1') with current device 0 must not mix the two."""
+    dev = t if isinstance(t, torch.device) else t.device
+    return torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext()
+
+
 def _ptr_array(tensors, dtype=torch.float32):
     arr = (C.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -140,15 +142,36 @@ def _int_array(vals):
 
 
 # ---------------------------------------------------------------------------------------------- free functions
-def rq_quantize(x, codebooks, want_quants=True):
-    """x (n_vec, dim) fp32; codebooks: list of (K_i, dim) fp32 (padding row excluded).
+def rq_code_norms(codebook):
+    """||c||^2 per code of a (K, dim) fp32 codebook (the codebook term of compute_distances)."""
+    K, dim = codebook.shape
+    out = torch.empty((K,), dtype=torch.float32, device=codebook.device)
+    with on_device_of(codebook):
+        check(lib().rqamd_rq_code_norms(ptr(codebook, torch.float32), K, dim, ptr(out), stream_of(codebook)))
+    return out
+
+
+def rq_quantize(x, codebooks, want_quants=True, norms=None):
+    """x (n_vec, dim) fp32; codebooks: list of (K_i, dim) fp32 (padding row excluded); norms: list of rq_code_norms(cb)
+    (computed here when not given -- callers that quantise repeatedly cache them per codebook version).
     -> codes (n_vec, depth) int64, quant_cum (depth, n_vec, dim) fp32 or None."""
     n_vec, dim = x.shape
     depth = len(codebooks)
+    for cb in codebooks:
+        if cb.dim() != 2 or cb.shape[1] != dim:
+            raise ValueError(f'codebook of shape {tuple(cb.shape)} does not match vectors of dim {dim}')
+    if norms is None:
+        norms, seen = [], {}
+        for cb in codebooks:
+            key = (cb.data_ptr(), cb.shape[0])
+            if key not in seen:
+                seen[key] = rq_code_norms(cb)
+            norms.append(seen[key])
     codes = torch.empty((n_vec, depth), dtype=torch.int64, device=x.device)
     quants = torch.empty((depth, n_vec, dim), dtype=torch.float32, device=x.device) if want_quants else None
-    check(lib().rqamd_rq_quantize(ptr(x, torch.float32), _ptr_array(codebooks), _int_array([c.shape[0] for c in codebooks]),
-                                  depth, n_vec, dim, ptr(codes), ptr(quants), stream_of(x)))
+    with on_device_of(x):
+        check(lib().rqamd_rq_quantize(ptr(x, torch.float32), _ptr_array(codebooks), _ptr_array(norms),
+                                      _int_array([c.shape[0] for c in codebooks]), depth, n_vec, dim, ptr(codes), ptr(quants), stream_of(x)))
     return codes, quants
 
 
@@ -158,8 +181,9 @@ def rq_embed(codes, codebooks, mode):
     dim = codebooks[0].shape[1]
     shape = (n_vec, dim) if mode == 0 else (n_vec, depth, dim)
     out = torch.empty(shape, dtype=torch.float32, device=codes.device)
-    check(lib().rqamd_rq_embed(ptr(codes, torch.int64), _ptr_array(codebooks), _int_array([c.shape[0] for c in codebooks]),
-                               depth, n_vec, dim, mode, ptr(out), stream_of(codes)))
+    with on_device_of(codes):
+        check(lib().rqamd_rq_embed(ptr(codes, torch.int64), _ptr_array(codebooks), _int_array([c.shape[0] for c in codebooks]),
+                                   depth, n_vec, dim, mode, ptr(out), stream_of(codes)))
     return out
 
 
@@ -167,10 +191,12 @@ def sample_logits(logits, temperature=1.0, top_k=None, top_p=None, seed=0, offse
     rows, vocab = logits.shape
     samples = torch.empty((rows,), dtype=torch.int64, device=logits.device) if want_samples else None
     probs = torch.empty((rows, vocab), dtype=torch.float32, device=logits.device) if want_probs else None
-    check(lib().rqamd_sample_logits(ptr(logits, torch.float32), rows, vocab, float(temperature),
-                                    0 if top_k is None else int(top_k), -1.0 if top_p is None else float(top_p),
-                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(samples), ptr(probs),
-                                    stream_of(logits)))
+    flags = torch.empty((max(rows, 1),), dtype=torch.int32, device=logits.device)
+    with on_device_of(logits):
+        check(lib().rqamd_sample_logits(ptr(logits, torch.float32), rows, vocab, float(temperature),
+                                        0 if top_k is None else int(top_k), -1.0 if top_p is None else float(top_p),
+                                        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(samples), ptr(probs),
+                                        ptr(flags), stream_of(logits)))
     return samples, probs
 
 
@@ -243,20 +269,45 @@ def dbg_conv_out(x, w, bias, gn=None):
 
 # ---------------------------------------------------------------------------------------------- engines
 class _Engine:
+    """Opaque native handle bound to ONE device: created, fed and run with that device current (on_device_of)."""
     _create = _destroy = _set = None
 
-    def __init__(self, cfg_struct):
+    def __init__(self, cfg_struct, device):
+        self.device = torch.device(device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self._h = C.c_void_p()
-        check(getattr(lib(), self._create)(C.byref(cfg_struct), C.byref(self._h)))
+        with on_device_of(self.device):
+            check(getattr(lib(), self._create)(C.byref(cfg_struct), C.byref(self._h)))
+
+    def _on_my_device(self, *tensors):
+        for t in tensors:
+            if t is not None and t.device != self.device:
+                raise ValueError(f'tensor on {t.device}, engine on {self.device} (move the model and its inputs to one device)')
 
     def set_param(self, name, tensor):
         t = tensor.detach()
+        self._on_my_device(t)
         if t.dtype != torch.float32 or not t.is_contiguous():
             t = t.to(torch.float32).contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
-        check(getattr(lib(), self._set)(self._h, name.encode(), ptr(t, torch.float32), shape, t.dim(), stream_of(t)))
+        with on_device_of(self.device):
+            check(getattr(lib(), self._set)(self._h, name.encode(), ptr(t, torch.float32), shape, t.dim(), stream_of(t)))
         if t.is_cuda:
             t.record_stream(torch.cuda.current_stream(t.device))
+
+    def _run(self, fn):
+        """One native call on the engine's device.  The engines allocate their workspaces with hipMalloc, outside torch's
+        caching allocator: on a HIP (out-of-memory) failure the allocator's cached blocks are released and the call is
+        retried once -- the handle is left empty, not dangling, by a failed regrowth."""
+        with on_device_of(self.device):
+            try:
+                return check(fn())
+            except RqamdError:
+                if self.device.type != 'cuda':
+                    raise
+                torch.cuda.empty_cache()
+                return check(fn())
 
     def close(self):
         if self._h is not None and self._h.value and _lib is not None:
@@ -273,7 +324,7 @@ class _Engine:
 class VaeEngine(_Engine):
     _create, _destroy, _set = 'rqamd_vae_create', 'rqamd_vae_destroy', 'rqamd_vae_set_param'
 
-    def __init__(self, ddconfig, embed_dim):
+    def __init__(self, ddconfig, embed_dim, device='cuda'):
         c = VaeConfig()
         c.ch, c.out_ch, c.in_channels = ddconfig['ch'], ddconfig['out_ch'], ddconfig['in_channels']
         c.resolution, c.z_channels, c.num_res_blocks = ddconfig['resolution'], ddconfig['z_channels'], ddconfig['num_res_blocks']
@@ -287,21 +338,31 @@ class VaeEngine(_Engine):
             c.attn_resolutions[i] = int(a)
         c.embed_dim, c.double_z = int(embed_dim), int(bool(ddconfig.get('double_z', True)))
         self.cfg = c
-        super().__init__(c)
+        super().__init__(c, device)
 
     def decode(self, z_q):
         """z_q (B,h,w,embed_dim) fp32 NHWC -> (B,out_ch,H,W) fp32"""
+        c = self.cfg
+        lr = c.resolution >> (c.n_levels - 1)
+        if z_q.dim() != 4 or tuple(z_q.shape[1:]) != (lr, lr, c.embed_dim):
+            # the engine is built for one resolution (its workspaces and tile schedules are sized from ddconfig.resolution)
+            raise ValueError(f'decode: latent of shape {tuple(z_q.shape)}; this RQVAE decodes (B, {lr}, {lr}, {c.embed_dim})')
+        self._on_my_device(z_q)
         B = z_q.shape[0]
-        out = torch.empty((B, self.cfg.out_ch, self.cfg.resolution, self.cfg.resolution), dtype=torch.float32, device=z_q.device)
-        check(lib().rqamd_vae_decode(self._h, ptr(z_q, torch.float32), B, ptr(out), stream_of(z_q)))
+        out = torch.empty((B, c.out_ch, c.resolution, c.resolution), dtype=torch.float32, device=z_q.device)
+        self._run(lambda: lib().rqamd_vae_decode(self._h, ptr(z_q, torch.float32), B, ptr(out), stream_of(z_q)))
         return out
 
     def encode(self, x):
         """x (B,in_channels,H,W) fp32 -> z_e (B,h,w,embed_dim) fp32 NHWC"""
+        c = self.cfg
+        if x.dim() != 4 or tuple(x.shape[1:]) != (c.in_channels, c.resolution, c.resolution):
+            raise ValueError(f'encode: input of shape {tuple(x.shape)}; this RQVAE encodes (B, {c.in_channels}, {c.resolution}, {c.resolution})')
+        self._on_my_device(x)
         B = x.shape[0]
-        lr = self.cfg.resolution >> (self.cfg.n_levels - 1)
-        out = torch.empty((B, lr, lr, self.cfg.embed_dim), dtype=torch.float32, device=x.device)
-        check(lib().rqamd_vae_encode(self._h, ptr(x, torch.float32), B, ptr(out), stream_of(x)))
+        lr = c.resolution >> (c.n_levels - 1)
+        out = torch.empty((B, lr, lr, c.embed_dim), dtype=torch.float32, device=x.device)
+        self._run(lambda: lib().rqamd_vae_encode(self._h, ptr(x, torch.float32), B, ptr(out), stream_of(x)))
         return out
 
 
@@ -309,38 +370,57 @@ class RqtEngine(_Engine):
     _create, _destroy, _set = 'rqamd_rqt_create', 'rqamd_rqt_destroy', 'rqamd_rqt_set_param'
 
     def __init__(self, *, embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
-                 block_size_cond, block_size, gelu_v2=False):
+                 block_size_cond, block_size, gelu_v2=False, device='cuda'):
         c = RqtConfig(embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
                       block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2))
         self.cfg = c
-        super().__init__(c)
+        super().__init__(c, device)
+
+    def _check(self, codes, cond, codebooks):
+        c = self.cfg
+        if codes.dim() != 4 or tuple(codes.shape[1:]) != (c.H, c.W, c.D):
+            raise ValueError(f'codes of shape {tuple(codes.shape)}; expected (B, {c.H}, {c.W}, {c.D})')
+        if cond is not None and tuple(cond.shape) != (codes.shape[0], max(c.block_size_cond, 1)):
+            raise ValueError(f'cond of shape {tuple(cond.shape)}; expected ({codes.shape[0]}, {max(c.block_size_cond, 1)})')
+        if len(codebooks) < c.D:
+            raise ValueError(f'{len(codebooks)} codebooks for depth {c.D}')
+        for cb in codebooks[:c.D]:
+            if cb.dim() != 2 or cb.shape[0] < c.vocab_size or cb.shape[1] != c.input_embed_dim:
+                raise ValueError(f'codebook of shape {tuple(cb.shape)}; expected (>= {c.vocab_size}, {c.input_embed_dim})')
+        self._on_my_device(codes, cond, *codebooks[:c.D])
 
     def sample(self, partial, cond, codebooks, start_loc, temperature, top_k, top_p, seed, offset, use_graph):
+        self._check(partial, cond, codebooks)
         B = partial.shape[0]
         out = torch.empty_like(partial)
         D = self.cfg.D
-        check(lib().rqamd_rqt_sample(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
-                                     int(start_loc[0]), int(start_loc[1]), float(temperature), _int_array(top_k[:D]),
-                                     (C.c_float * D)(*[float(p) for p in top_p[:D]]), int(seed) & (2 ** 64 - 1),
-                                     int(offset) & (2 ** 64 - 1), int(bool(use_graph)), ptr(out), stream_of(partial)))
+        cbs, tk, tp = _ptr_array(codebooks[:D]), _int_array(top_k[:D]), (C.c_float * D)(*[float(p) for p in top_p[:D]])
+        self._run(lambda: lib().rqamd_rqt_sample(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), B, cbs,
+                                                 int(start_loc[0]), int(start_loc[1]), float(temperature), tk, tp,
+                                                 int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(bool(use_graph)),
+                                                 ptr(out), stream_of(partial)))
         return out
 
     def logits(self, codes, cond, codebooks):
+        self._check(codes, cond, codebooks)
         B = codes.shape[0]
         c = self.cfg
         out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
-        check(lib().rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
-                                     ptr(out), stream_of(codes)))
+        cbs = _ptr_array(codebooks[:c.D])
+        self._run(lambda: lib().rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
+                                                 ptr(out), stream_of(codes)))
         return out
 
     def forward(self, codes, cond, codebooks):
         """(seq_logits (B,H,W,D,V), cond_logits (B, block_size_cond-1, vocab_size_cond)) -- text-conditioned models"""
+        self._check(codes, cond, codebooks)
         B = codes.shape[0]
         c = self.cfg
         out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
         cl = torch.empty((B, c.block_size_cond - 1, max(c.vocab_size_cond, 1)), dtype=torch.float32, device=codes.device)
-        check(lib().rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, _ptr_array(codebooks),
-                                      ptr(out), ptr(cl), stream_of(codes)))
+        cbs = _ptr_array(codebooks[:c.D])
+        self._run(lambda: lib().rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
+                                                  ptr(out), ptr(cl), stream_of(codes)))
         return out, cl
 
     def set_profile(self, on):

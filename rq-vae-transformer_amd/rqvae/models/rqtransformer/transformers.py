@@ -86,6 +86,9 @@ class RQTransformer(Stage2Model):
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
         sig = signature(self)
+        if self._engine is not None and self._engine.device != self.pos_emb_hw.device:
+            self._engine.close()                        # the module moved (model.to(other device)): rebuild there
+            self._engine = None
         if self._engine is None or sig != self._engine_sig:
             if self._engine is None:
                 c = self.config
@@ -96,7 +99,8 @@ class RQTransformer(Stage2Model):
                 self._engine = _native.RqtEngine(
                     embed_dim=c.embed_dim, n_head=c.body.block.n_head, n_layer_body=c.body.n_layer, n_layer_head=c.head.n_layer,
                     vocab_size=self.vocab_size[0], input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
-                    block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=c.body.block.gelu == 'v2')
+                    block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=c.body.block.gelu == 'v2',
+                    device=self.pos_emb_hw.device)
             push_all(self, self._engine)
             self._engine_sig = sig
         return self._engine

@@ -29,13 +29,23 @@ class VQEmbedding(nn.Embedding):
         """weight[:-1] (quantizations.py:45): the searchable rows, a contiguous view."""
         return self.weight.detach()[:-1]
 
+    def code_norms(self):
+        """||c||^2 per code (the codebook term of compute_distances, quantizations.py:51-52), cached per codebook
+        version: recomputed only after load_state_dict / .to(device) / an in-place edit of the weight."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, '_norm_key', None) != key:
+            self._norms = _native.rq_code_norms(self.codebook())
+            self._norm_key = key
+        return self._norms
+
     @torch.no_grad()
     def find_nearest_embedding(self, inputs):
         """quantizations.py:64-69"""
         shape = inputs.shape
         assert shape[-1] == self.weight.shape[1]
         x = inputs.detach().reshape(-1, shape[-1]).to(torch.float32).contiguous()
-        codes, _ = _native.rq_quantize(x, [self.codebook()], want_quants=False)
+        codes, _ = _native.rq_quantize(x, [self.codebook()], want_quants=False, norms=[self.code_norms()])
         return codes.reshape(shape[:-1])
 
     @torch.no_grad()
@@ -102,19 +112,31 @@ class RQBottleneck(nn.Module):
     def codebook_list(self):
         return [cb.codebook() for cb in self.codebooks]
 
+    def _norm_list(self):
+        return [cb.code_norms() for cb in self.codebooks]
+
+    def _no_training(self):
+        # the reference's train-mode quantize() runs VQEmbedding.forward, which updates the EMA codebook statistics and
+        # restarts dead codes (quantizations.py:80-129,131-142); that is stage-1 training, not this path -- refuse loudly
+        # rather than quantise with codebooks that silently never update
+        if self.training and any(cb.ema for cb in self.codebooks):
+            raise NotImplementedError('RQBottleneck in train mode updates its EMA codebooks (stage-1 training, out of scope): '
+                                      'call .eval() for the sampling / reconstruction path')
+
     # ---- the hot path
     def quantize(self, x):
         """quantizations.py:237-271 -> (quant_list: depth x (B,h,w,D) cumulative, codes (B,h,w,depth) int64)"""
+        self._no_training()
         B, h, w, embed_dim = x.shape
         flat = x.detach().reshape(-1, embed_dim).to(torch.float32).contiguous()
-        codes, quants = _native.rq_quantize(flat, self.codebook_list(), want_quants=True)
+        codes, quants = _native.rq_quantize(flat, self.codebook_list(), want_quants=True, norms=self._norm_list())
         quant_list = [quants[i].reshape(B, h, w, embed_dim) for i in range(quants.shape[0])]
         return quant_list, codes.reshape(B, h, w, -1)
 
     def get_codes_only(self, x):
         B, h, w, embed_dim = x.shape
         flat = x.detach().reshape(-1, embed_dim).to(torch.float32).contiguous()
-        codes, _ = _native.rq_quantize(flat, self.codebook_list(), want_quants=False)
+        codes, _ = _native.rq_quantize(flat, self.codebook_list(), want_quants=False, norms=self._norm_list())
         return codes.reshape(B, h, w, -1)
 
     def forward(self, x):

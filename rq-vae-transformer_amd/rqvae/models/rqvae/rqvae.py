@@ -65,9 +65,13 @@ class RQVAE(Stage1Model):
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
         sig = signature(self)
+        dev = self.quant_conv.weight.device
+        if self._engine is not None and self._engine.device != dev:
+            self._engine.close()                        # the module moved (model.to(other device)): rebuild there
+            self._engine = None
         if self._engine is None or sig != self._engine_sig:
             if self._engine is None:
-                self._engine = _native.VaeEngine(self.ddconfig, self.embed_dim)
+                self._engine = _native.VaeEngine(self.ddconfig, self.embed_dim, device=dev)
             push_all(self, self._engine, skip_prefixes=('quantizer.',))
             self._engine_sig = sig
         return self._engine

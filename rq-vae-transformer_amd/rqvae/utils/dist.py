@@ -64,7 +64,12 @@ def dataparallel_and_sync(distenv, model, find_unused_parameters=False):
             dist.broadcast(param, 0)
         dist.barrier()
     else:
-        model = torch.nn.DataParallel(model)
+        # single process: the reference wraps in nn.DataParallel and only ever goes through `.module`
+        # (main_sampling_fid.py:184,202,210).  Pinned to the model's own device: the native engine handle belongs to one
+        # device and must never be shared by replicas on several.
+        p = next(model.parameters(), None)
+        ids = [p.device.index if p.device.index is not None else torch.cuda.current_device()] if p is not None and p.is_cuda else None
+        model = torch.nn.DataParallel(model, device_ids=ids)
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     return model
@@ -85,7 +90,7 @@ def all_gather_cat(distenv, tensor, dim=0):
     if distenv.world_size == 1:
         return tensor
     t = tensor.contiguous()
-    if dim == 0 and dist.get_backend() != 'gloo':
+    if dim == 0:
         out = torch.empty((distenv.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out, t)
         return out

@@ -260,6 +260,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); memset(*p, 0xFF, n); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t) {

@@ -64,3 +64,28 @@ def test_two_rank_sharding_and_gather():
     want = [float(lbl) + 0.01 * ((i // 2) % 2) for i, lbl in enumerate(res['labels'])]
     assert all(abs(a - b) < 1e-6 for a, b in zip(res['pix0'], want))
     assert res['w'] == 0.0                                        # rank 0's parameters were broadcast
+
+
+def _run_bench(args, env_extra=None):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_self_launch_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment must start two ranks itself (one process per GPU in the
+    real run; gloo on CPU here, --dry-run = no kernels) and report the world size it actually joined."""
+    out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '4', '--dry-run'])
+    assert out['n_gpus'] == 2 and out['world_size'] == 2 and out['requested_gpus'] == 2
+    assert out['steps'] == 2 and out['warmup'] == 1 and out['scaling'] == 'weak' and out['gather_rank_major_ok'] is True
+    assert out['config']['global_batch'] == 8
+    one = _run_bench(['--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '4', '--dry-run'])
+    assert one['n_gpus'] == 1

@@ -23,10 +23,10 @@ def nat():
     import build_emu
     path = build_emu.build()
     from rqvae import _native
-    saved = (_native._lib, _native._allow_host_pointers)
-    _native._load_for_testing(path, allow_host_pointers=True)
+    import emu_binding
+    saved = emu_binding.install(_native, path)
     yield _native
-    _native._lib, _native._allow_host_pointers = saved
+    emu_binding.restore(_native, saved)
 
 
 def T(a):
@@ -134,7 +134,7 @@ def _rqt_engine(nat, cfg, params):
     eng = nat.RqtEngine(embed_dim=cfg['embed_dim'], n_head=cfg['body']['block']['n_head'], n_layer_body=cfg['body']['n_layer'],
                         n_layer_head=cfg['head']['n_layer'], vocab_size=cfg['vocab_size'], input_embed_dim=cfg['input_embed_dim'],
                         vocab_size_cond=cfg['vocab_size_cond'], block_size_cond=cfg['block_size_cond'],
-                        block_size=cfg['block_size'], gelu_v2=cfg.get('gelu', 'v1') == 'v2')
+                        block_size=cfg['block_size'], gelu_v2=cfg.get('gelu', 'v1') == 'v2', device='cpu')
     for k, v in params.items():
         eng.set_param(k, T(v))
     return eng
@@ -199,6 +199,22 @@ def test_emu_rqt_long_prefix(nat):
     assert e1 < 0.06 and e2 < 0.06
 
 
+def test_emu_rqt_depth1_no_head_stack(nat):
+    """head.n_layer = 0 with depth-1 codes: the "VQ-GAN" transformer shapes of the throughput script
+    (measure_throughput/__main__.py:166-210); the classifier reads the body output + pos_emb_d directly."""
+    cfg = C.rqt(128, 2, 2, 0, 500, vocab_cond=10, block_size=(4, 4, 1), input_embed_dim=64)
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), 45)
+    rng = np.random.default_rng(46)
+    cb = rng.standard_normal((500, 64), dtype=np.float32)
+    codes, cond = rng.integers(0, 500, (3, 4, 4, 1)), rng.integers(0, 10, (3, 1))
+    eng = _rqt_engine(nat, cfg, params)
+    logits = eng.logits(T(codes), T(cond), [T(cb)]).numpy()
+    ref = oracle.RQTransformerOracle(cfg, params).forward(codes, [cb], cond)
+    assert np.abs(logits - ref).max() < 0.06
+    out = eng.sample(torch.zeros((3, 4, 4, 1), dtype=torch.int64), T(cond), [T(cb)], (0, 0), 1.0, [50], [0.9], seed=3, offset=0, use_graph=False)
+    assert out.shape == (3, 4, 4, 1) and int(out.min()) >= 0 and int(out.max()) < 500
+
+
 def test_emu_rqt_tiny_sample(nat, golden):
     """sample(): teacher-forcing the sampled codes back through the logits path must reproduce, at every
     step, a distribution under which the sampled code has non-zero filtered probability."""
@@ -225,7 +241,7 @@ def test_emu_rqt_tiny_sample(nat, golden):
 
 
 def _vae_engine(nat, hps, dd, params):
-    eng = nat.VaeEngine(dd, hps['embed_dim'])
+    eng = nat.VaeEngine(dd, hps['embed_dim'], device='cpu')
     for k, v in params.items():
         if not k.startswith('quantizer.'):
             eng.set_param(k, T(v))

@@ -73,7 +73,11 @@ arch:
     c2.body.n_layer = 1
     assert arch.body.n_layer == 42
     v = augment_arch_defaults(Config({'type': 'rq-vae', 'hparams': {'a': 1}}))
-    assert v.ema is None and dict(**v.hparams) == {'a': 1}
+    # config.py:31-43 of the reference: the stage-1 defaults are merged UNDER the given config
+    assert v.ema is None and v.checkpointing is False
+    assert dict(**v.hparams) == {'loss_type': 'l1', 'restart_unused_codes': False, 'use_padding_idx': False, 'masked_dropout': 0.0, 'a': 1}
+    v2 = augment_arch_defaults(Config({'type': 'rq-vae', 'hparams': {'loss_type': 'mse'}, 'checkpointing': True}))
+    assert v2.hparams.loss_type == 'mse' and v2.checkpointing is True
     with pytest.raises(NotImplementedError):
         augment_arch_defaults(Config({'type': 'other'}))
 
@@ -93,7 +97,7 @@ def test_sample_argument_normalisation(monkeypatch):
         class quantizer:
             @staticmethod
             def codebook_list():
-                return [None] * 4
+                return [torch.zeros((500, 64))] * 4
     monkeypatch.setattr(ar, '_eng', lambda: FakeEngine())
     z = torch.zeros((2, 4, 4, 4), dtype=torch.long)
     ar.sample(z, Aux)
@@ -108,3 +112,11 @@ def test_sample_argument_normalisation(monkeypatch):
         ar.sample(torch.zeros((2, 8, 8, 4), dtype=torch.long), Aux)   # transformers.py:310
     with pytest.raises(ValueError):
         ar.sample(z, None)
+
+    class BadAux:                                   # a codebook too small / too narrow for this transformer is refused
+        class quantizer:
+            @staticmethod
+            def codebook_list():
+                return [torch.zeros((100, 64))] * 4
+    with pytest.raises(ValueError):
+        ar.sample(z, BadAux)
