@@ -787,6 +787,219 @@ __global__ __launch_bounds__(256, BM == 256 ? 2 : 3) void gemm_rb_kernel(GemmArg
     rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0);
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// tile id -> (m-tile, n-tile) under the XCD-aware schedules described in gemm_bf16_kernel; false = surplus workgroup of the
+// padded grid (must return before any barrier).
+static __device__ __forceinline__ bool rq_gemm_tile_coords(const GemmArgs& p, int BM, int BN, int& mt, int& nt) {
+    const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    if (p.sched == 1) {
+        const int nb = NT >> 3, rem = NT & 7;
+        const int nn = nb + (xcd < rem ? 1 : 0);
+        const int n_lo = xcd * nb + (xcd < rem ? xcd : rem);
+        if (slot >= nn * MT) return false;
+        const int per_group = p.sched_gm * nn;
+        const int mg = slot / per_group, r = slot - mg * per_group;
+        int gm = MT - mg * p.sched_gm;
+        gm = gm < p.sched_gm ? gm : p.sched_gm;
+        nt = n_lo + r / gm;
+        mt = mg * p.sched_gm + (r - (r / gm) * gm);
+    } else if (p.sched == 2) {
+        const int mm = (MT + 7) >> 3;
+        mt = xcd * mm + slot / NT;
+        nt = slot - (slot / NT) * NT;
+        if (slot >= mm * NT || mt >= MT) return false;
+    } else {
+        mt = id / NT;
+        nt = id - mt * NT;
+        if (mt >= MT) return false;
+    }
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "eight-phase" dense GEMM for the compute-bound decode steps (M >= ~2048 rows): 8 wavefronts as 2 (M) x 4 (N),
+// wave tile 128 x 64 = acc[4][2] of v_mfma_f32_32x32x16_bf16 (128 accumulator registers), 128 KB of LDS as a ring of EIGHT 16-KB
+// units filled by LDS-DMA, counted vmcnt waits, raw s_barriers, s_setprio around the MFMA bursts
+// (/opt/skills/guides/cdna_hip_programming.md, "The 256^2 8-phase template"; written from that description).
+//
+// Why: the 128x128 kernel above reads 1 KB of fragments from LDS per MFMA and drains its staging at a barrier every K-tile
+// (measured: 0.30 of the MFMA peak, 33-47 % of wave time parked at s_barrier / s_waitcnt).  Here a wave reads 0.75 KB per MFMA,
+// the two wave rows run half a phase apart -- one row's MFMA burst covers the other row's ds_reads and DMA issue on the same
+// SIMDs -- and no wait ever drains the DMA queue: four units (64 KB) stay in flight across every barrier.
+//
+// K-tile t lives in LDS buffer t & 1 as four units, each [128 rows][64 k] bf16 with the 16-byte-chunk swizzle
+// chunk ^ ((row >> 1) & 7) (conflict-free ds_read_b128; the DMA writes lane-linear, so the permutation is applied to the
+// per-lane source address):
+//   AH0 / AH1: A rows  m0 + wm*128 + mh*64 + [0,64)   for wm = 0,1   (unit row u = wm*64 + r)
+//   BH0 / BH1: W rows  n0 + wn*64  + nb*32 + [0,32)   for wn = 0..3  (unit row u = wn*32 + r)
+// so every unit is consumed by ALL waves in exactly ONE phase.  Phase j of tile t (global phase k = 4t + j):
+//   j   ds_read (this wave)          MFMAs (8 = 2 m-blocks x 4 k-steps)   DMA issued (one unit, 2 instructions per wave)
+//   1   BH0 -> B(n0), AH0 -> A(mh0)  (mh0, n0)                            BH1 of tile t+1
+//   2   BH1 -> B(n1)                 (mh0, n1)                            AH1 of tile t+1
+//   3   AH1 -> A(mh1)                (mh1, n1)                            AH0 of tile t+2
+//   4   --  (B(n0) kept in registers) (mh1, n0)                           BH0 of tile t+2
+// Each phase is  { ds_reads; DMA issue; s_waitcnt vmcnt(8); s_barrier }  { s_waitcnt lgkmcnt(0); 8 MFMAs; s_barrier },
+// and wave row 1 executes one extra s_barrier up front, so it always runs one half-phase behind wave row 0.
+// Hazards, with that stagger (intervals between consecutive workgroup barriers; row 0 loads in interval 2k-1 and computes in
+// 2k, row 1 loads in 2k and computes in 2k+1):
+//   RAW  a unit waited for in phase k (vmcnt before the barrier that ends the load half) is read in phase >= k+1.  vmcnt(8)
+//        after this phase's issue leaves the four newest units in flight and retires the one issued four phases ago, which is
+//        exactly the unit the next phase reads (check: BH1(t+1) issued at 4t+1, retired at 4t+5, read at 4t+6 = phase 2 of t+1).
+//   WAR  a unit is refilled >= 2 phases after its last ds_read (AH0: read phase 1, refilled phase 3; BH0 1 -> 4; BH1 2 -> 5;
+//        AH1 3 -> 6): row 1 retires its phase-k reads (lgkmcnt(0)) in interval 2k+1, row 0 issues the refill in interval
+//        2(k+2)-1 = 2k+3.
+// The last two K-tiles issue nothing new and wait with the matching smaller counts.  Needs K/64 (per split) >= 2.
+template <int TR>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4;
+    constexpr int UNIT = 128 * BK * 2;                 // 16 KB
+    constexpr int BUF = 4 * UNIT;                      // one K-tile: AH0, BH0, BH1, AH1
+    constexpr int U_AH0 = 0, U_BH0 = UNIT, U_BH1 = 2 * UNIT, U_AH1 = 3 * UNIT;
+    constexpr int SMEM_BYTES = BM * (BN * 2 + 16);     // the bf16 epilogue tile (135 168 B) >= the 128-KB operand ring
+    RQ_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rq_uniform(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int mt, nt;
+    if (!rq_gemm_tile_coords(p, BM, BN, mt, nt)) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int kt_total = p.K / BK;
+    const int per = (kt_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = (kt0 + per < kt_total) ? kt0 + per : kt_total;
+    const int nk = kt1 - kt0;
+
+    // ---- DMA source offsets: wave w fills 8-row groups 2w and 2w+1 of every unit; lane (lr, lc) fills (row 8g + lr, chunk lc)
+    const int lr = lane >> 3, lc = lane & 7;
+    unsigned a_off[2][2], b_off[2][2];                                // [mh | nb][q]; rows >= M / >= N are clamped (never stored)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = (2 * wave + q) * 8 + lr;                       // unit row 0..127
+        const unsigned sw = (unsigned)((lc ^ ((u >> 1) & 7)) << 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int m = m0 + (u >> 6) * 128 + h * 64 + (u & 63);
+            int n = n0 + (u >> 5) * 64 + h * 32 + (u & 31);
+            m = m < p.M - 1 ? m : p.M - 1;
+            n = n < p.N - 1 ? n : p.N - 1;
+            a_off[h][q] = (unsigned)m * (unsigned)p.lda * 2u + sw;
+            b_off[h][q] = (unsigned)n * (unsigned)p.K * 2u + sw;
+        }
+    }
+    const char* gA = (const char*)p.A;
+    const char* gW = (const char*)p.W;
+    const rq_lds_t lds0 = rq_lds_addr(smem);
+    const rq_lds_t my_grp = (rq_lds_t)(2 * wave) * 1024;
+    // unit `uo` (byte offset inside a buffer) of K-tile kt (absolute index) into buffer (kt - kt0) & 1
+    auto stage_a = [&](int kt, int uo, int mh) {
+        const char* base = gA + (size_t)kt * (BK * 2);
+        const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
+        rq_glds16_s(dst, base, a_off[mh][0]);
+        rq_glds16_s(dst + 1024, base, a_off[mh][1]);
+    };
+    auto stage_b = [&](int kt, int uo, int nb) {
+        const char* base = gW + (size_t)kt * (BK * 2);
+        const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
+        rq_glds16_s(dst, base, b_off[nb][0]);
+        rq_glds16_s(dst + 1024, base, b_off[nb][1]);
+    };
+
+    // ---- fragment read offsets: row = (wave block) + (lane & 31), 16-byte chunk 2 ks + (lane >> 5), swizzled
+    const int frow = lane & 31, fk = lane >> 5;
+    unsigned rd_a[4], rd_b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned c = (unsigned)(((ks * 2 + fk) ^ ((frow >> 1) & 7)) << 4);
+        rd_a[ks] = (unsigned)((wm * 64 + frow) * (BK * 2)) + c;      // + (i & 1) * 32 rows, unit AH[i >> 1]
+        rd_b[ks] = (unsigned)((wn * 32 + frow) * (BK * 2)) + c;      // unit BH[j]
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[2][4], fb0[4], fb1[4];          // A fragments of the current m-half, B fragments of n-block 0 / 1
+
+    auto read_a = [&](const char* sb, int uo) {        // 8 x ds_read_b128
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = as_bf16x8(ld128(sb + uo + rd_a[ks] + ii * (32 * BK * 2)));
+    };
+    auto read_b = [&](const char* sb, int uo, bf16x8 (&fb)[4]) {   // 4 x ds_read_b128
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = as_bf16x8(ld128(sb + uo + rd_b[ks]));
+    };
+    auto mma = [&](int ih, int j, const bf16x8 (&fb)[4]) {          // 8 MFMAs: m-blocks 2 ih, 2 ih + 1 x n-block j x 4 k-steps
+        rq_sched_barrier();
+        rq_wait_lgkmcnt<0>();
+        rq_sched_barrier();            // keeps the register-only MFMAs below the wait (hipcc hoists them past inline-asm waits)
+        rq_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+                acc[2 * ih + ii][j] = TR ? rq_mfma_32x32x16_bf16(fb[ks], fa[ii][ks], acc[2 * ih + ii][j])
+                                         : rq_mfma_32x32x16_bf16(fa[ii][ks], fb[ks], acc[2 * ih + ii][j]);
+        rq_setprio(0);
+        rq_sched_barrier();
+        rq_barrier_raw();
+        rq_sched_barrier();
+    };
+    // end of a load half: the DMA wait (N = 2 x units allowed to stay in flight), then the barrier that publishes it
+#define RQ_P8_LOAD_END(N)          \
+    rq_sched_barrier();            \
+    rq_wait_vmcnt<N>();            \
+    rq_barrier_raw();              \
+    rq_sched_barrier();
+
+    if (nk >= 2) {
+        // prologue: tile 0 whole, AH0 / BH0 of tile 1; the first two units must have landed before phase 1 reads them
+        stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1);
+        stage_a(kt0 + 1, U_AH0, 0); stage_b(kt0 + 1, U_BH0, 0);
+        RQ_P8_LOAD_END(8)
+        if (wm == 1) rq_barrier_raw();           // wave row 1 runs half a phase behind (uniform per wave: wm is scalar)
+        rq_sched_barrier();
+        for (int t = 0; t < nk; ++t) {
+            const char* sb = (const char*)smem + (t & 1) * BUF;
+            const int kt = kt0 + t;
+            const int ahead = nk - 1 - t;        // K-tiles after this one
+            // ---- phase 1
+            read_b(sb, U_BH0, fb0);
+            rq_sched_barrier();
+            read_a(sb, U_AH0);
+            if (ahead >= 1) { stage_b(kt + 1, U_BH1, 1); RQ_P8_LOAD_END(8) }          // in flight: AH1(t+1) .. this one
+            else { RQ_P8_LOAD_END(2) }                                                   // last tile: only AH1(t) may still be pending
+            mma(0, 0, fb0);
+            // ---- phase 2
+            read_b(sb, U_BH1, fb1);
+            if (ahead >= 1) { stage_a(kt + 1, U_AH1, 1); RQ_P8_LOAD_END(8) }
+            else { RQ_P8_LOAD_END(0) }
+            mma(0, 1, fb1);
+            // ---- phase 3
+            read_a(sb, U_AH1);
+            if (ahead >= 2) { stage_a(kt + 2, U_AH0, 0); RQ_P8_LOAD_END(8) }
+            else if (ahead == 1) { RQ_P8_LOAD_END(6) }                                   // BH0(t+1), BH1(t+1), AH1(t+1) stay in flight
+            else { RQ_P8_LOAD_END(0) }
+            mma(1, 1, fb1);
+            // ---- phase 4 (no LDS reads: B(n0) is still in registers)
+            if (ahead >= 2) { stage_b(kt + 2, U_BH0, 0); RQ_P8_LOAD_END(8) }
+            else if (ahead == 1) { RQ_P8_LOAD_END(4) }                                   // BH1(t+1), AH1(t+1) stay in flight
+            else { RQ_P8_LOAD_END(0) }
+            mma(1, 0, fb0);
+        }
+        if (wm == 0) rq_barrier_raw();           // wave row 0 catches up: every wave has executed the same number of barriers
+        rq_sched_barrier();
+    }
+#undef RQ_P8_LOAD_END
+    rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0);
+}
+
 // host-side launcher (gemm.hip)
 int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 // picks (BM, BN, splitk) for a weight-streaming decode GEMM; returns splitk actually used via args

@@ -72,6 +72,40 @@ static int launch_rb(const GemmArgs& a, hipStream_t stream) {
     return rq_check_launch("gemm_rb_kernel");
 }
 
+// 256 x 256 eight-phase kernel (gemm.h): dense operands, >= 2 K-tiles per split
+template <int TR>
+static int launch_p8(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = 256, BN = 256;
+    const size_t smem = (size_t)BM * (BN * 2 + 16);
+    static RqDeviceOnce attr_once;
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    }
+    GemmArgs g = a;
+    const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
+    int nblocks;
+    static const bool env_sched0 = getenv("RQAMD_GEMM_SCHED0") != nullptr;
+    if (env_sched0) {
+        g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
+    } else if (NT >= 8 && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6) {
+        g.sched = 2; g.sched_gm = 1;                               // m-bands per XCD (activations outweigh the weights)
+        nblocks = 8 * ((MT + 7) / 8) * NT;
+    } else if (NT >= 8) {
+        const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
+        long panel = (long)BM * ktiles * 64 * 2;
+        int gm = (int)((3 << 19) / (panel > 0 ? panel : 1));
+        if (gm < 1) gm = 1;
+        if (gm > MT) gm = MT;
+        g.sched = 1; g.sched_gm = gm;                              // n-ranges per XCD, L2-sized m-groups
+        nblocks = 8 * ((NT + 7) / 8) * MT;
+    } else {
+        g.sched = 2; g.sched_gm = 1;
+        nblocks = 8 * ((MT + 7) / 8) * NT;
+    }
+    RQ_LAUNCH((gemm_p8_kernel<TR>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
+    return rq_check_launch("gemm_p8_kernel");
+}
+
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     // transposed accumulators (TR = 1) for everything except wide fp32 rows (logits / fp32 activations)
@@ -102,6 +136,12 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     }
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
+    if (bm == 256 && bn == 256) {     // eight-phase kernel
+        const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
+        if (a.conv || ktiles < 2 || (a.K / 64) % a.splitk != 0)
+            return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm 256x256: dense operands and >= 2 K-tiles per (even) split needed");
+        return a.epi != EPI_F32 ? launch_p8<1>(a, stream) : launch_p8<0>(a, stream);
+    }
     {   // LDS-DMA staged variants (dense operands): RQAMD_GEMM_GL = number of LDS stages (experiment switch)
         static const int gl_env = getenv("RQAMD_GEMM_GL") ? atoi(getenv("RQAMD_GEMM_GL")) : 0;
         const int gl = a.glds ? a.glds : gl_env;

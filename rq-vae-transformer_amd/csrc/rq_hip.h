@@ -83,7 +83,15 @@ static __device__ __forceinline__ void rq_glds16(unsigned lds_base, const void* 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// Same DMA with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): the per-lane offset is
+// loop invariant and the K-tile advance is one scalar add on the base, so a staging instruction costs no VALU work at all.
+static __device__ __forceinline__ void rq_glds16_s(unsigned lds_base, const void* sbase, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
 template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+template <int N> static __device__ __forceinline__ void rq_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
 static __device__ __forceinline__ void rq_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 // pins instruction order at this point (hipcc otherwise sinks independent global loads below LDS writes)
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)

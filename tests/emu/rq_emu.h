@@ -129,7 +129,9 @@ static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
     }
     memcpy(dst, gsrc, 16);
 }
+static inline void rq_glds16_s(uintptr_t lds_base, const void* sbase, unsigned voff) { rq_glds16(lds_base, (const char*)sbase + voff); }
 template <int N> static inline void rq_wait_vmcnt() {}
+template <int N> static inline void rq_wait_lgkmcnt() {}
 static inline void rq_barrier_raw() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)

@@ -287,6 +287,30 @@ def test_emu_gemm_tiles_and_lds_dma(nat):
                     assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K, gl, bm, bn)
 
 
+def test_emu_gemm_256x256_eight_phase(nat):
+    """256 x 256 eight-phase kernel (gemm_p8_kernel): unit layout / swizzle / fragment maps, the staggered barrier count
+    (wave row 1 runs one barrier behind and the counts must match at the end), partial M / N tiles, the shortened waits of
+    the last two K-tiles, split-K, and all epilogue families.  The emulator executes an LDS-DMA at issue, so it cannot see a
+    RAW hazard (a read before the data landed); a WAR hazard (a unit refilled while some wave still has to read it) shows up
+    as wrong results for the fiber interleavings the emulator produces."""
+    rng = np.random.default_rng(17)
+    for (M, N, K) in ((300, 512, 256), (256, 300, 128), (520, 256, 384)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+        out = nat.dbg_gemm(a, w, bias, epi=3, bm=256, bn=256, splitk=1).numpy()              # fp32 rows (TR = 0)
+        assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
+        out = nat.dbg_gemm(a, w, bias, epi=0, bm=256, bn=256, splitk=1).float().numpy()      # bf16 through the LDS transpose (TR = 1)
+        assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max(), (M, N, K)
+        if K >= 256:
+            out = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=2).numpy().sum(0)   # split-K slabs, 2 K-tiles per split
+            assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
+    with pytest.raises(NotImplementedError):
+        nat.dbg_gemm(a, w, bias, epi=3, bm=256, bn=256, splitk=0 + 0, out=None) if False else nat.dbg_gemm(
+            a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
+
+
 def test_emu_conv_halo(nat):
     """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual;
     against the oracle's conv2d / silu on the bf16-rounded operands."""
