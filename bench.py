@@ -42,6 +42,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3    # fp32-input MFMA = fp32 vector rate
 A100_FIG4_IMG_S = 52.6          # reference Fig. 4, 1.4B 8x8x4, batch 500, 1x A100 (fp32)
+# Per-GPU batch: as large as 288 GB allows (KV cache = 16.5 MB / image for the 1.4B model), and chosen so that the 256-row
+# tiles of the decode-step GEMMs fill whole rounds of the 256 CUs: M = 10752 = 42 m-tiles gives 252 / 756 / 1008 workgroups
+# for the N = 1536 / 4608 / 6144 GEMMs of the 1.4B model (98 % of 1 / 3 / 4 rounds); 16384 = 64 m-tiles for E = 1024,
+# 6400 = 25 m-tiles for E = 2560.
+DEFAULT_BATCH = {'huge': 10752, 'large': 10752, 'small': 10752, 'medium': 16384, 'xhuge': 6400, 'txt3900m': 2048, 'cc3m': 4096, 'tiny': 64}
 WORKLOADS = {'huge': 'BASELINE configs[2]', 'medium': 'BASELINE configs[1]', 'xhuge': 'BASELINE configs[3] dims',
              'txt3900m': 'BASELINE configs[4] dims', 'cc3m': 'CC-3M 654M'}
 
@@ -51,7 +56,8 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 8192)), help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('RQ_BENCH_BATCH', 0)),
+                    help='images per GPU per step (0 = the per-model default, DEFAULT_BATCH)')
     ap.add_argument('--model', default='huge')
     # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
     ap.add_argument('--top-k', type=int, default=1024)
@@ -239,7 +245,7 @@ def dry_run(args, rank, world, local_rank):
         dist.init_process_group(backend='gloo', init_method='env://', world_size=world, rank=rank)
         distenv = DistEnv(world, rank, local_rank, 1, rank == 0, 'cpu')
     set_seed(0 + rank)
-    B = args.batch
+    B = args.batch if args.batch > 0 else 4
 
     def sync():
         if world > 1:
@@ -303,7 +309,7 @@ def main(argv=None):
     vae, ar, cfg = presets.build(args.model, device=device, seed=0)
     vcfg = presets.RQVAE[presets.RQTRANSFORMER[args.model][1]]
     set_seed(0 + rank)                                   # main_sampling_fid.py:166-169
-    B = args.batch
+    B = args.batch if args.batch > 0 else DEFAULT_BATCH.get(args.model, 1024)
     empty_sample = torch.zeros((B,) + tuple(ar.block_size), device=device, dtype=torch.long)
     empty_cond = torch.zeros((B, ar.block_size_cond), device=device, dtype=torch.long)
 

@@ -810,6 +810,21 @@ static __device__ __forceinline__ bool rq_gemm_tile_coords(const GemmArgs& p, in
         mt = xcd * mm + slot / NT;
         nt = slot - (slot / NT) * NT;
         if (slot >= mm * NT || mt >= MT) return false;
+    } else if (p.sched == 3) {
+        // balanced: the tile space is walked in groups of sched_gm m-tiles x all n-tiles (m fastest inside a group, so
+        // consecutive tiles share a W panel and neighbouring A panels), and XCD x owns a CONTIGUOUS range of that walk whose
+        // length differs by at most one tile between XCDs -- an XCD is a 32-CU machine of its own, so the per-XCD counts,
+        // not the total, decide how many rounds a launch takes (42 m-tiles in bands of 6 left one XCD idle).
+        const int T = MT * NT, q = T >> 3, r = T & 7;
+        const int cnt = q + (xcd < r ? 1 : 0);
+        if (slot >= cnt) return false;
+        const int L = xcd * q + (xcd < r ? xcd : r) + slot;
+        const int G = p.sched_gm * NT;
+        const int mg = L / G, rem = L - mg * G;
+        int gm = MT - mg * p.sched_gm;
+        gm = gm < p.sched_gm ? gm : p.sched_gm;
+        nt = rem / gm;
+        mt = mg * p.sched_gm + (rem - nt * gm);
     } else {
         mt = id / NT;
         nt = id - mt * NT;

@@ -85,22 +85,16 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
     int nblocks;
     static const bool env_sched0 = getenv("RQAMD_GEMM_SCHED0") != nullptr;
+    static const int env_gm = getenv("RQAMD_P8_GM") ? atoi(getenv("RQAMD_P8_GM")) : 0;      // A/B switch
     if (env_sched0) {
         g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
-    } else if (NT >= 8 && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6) {
-        g.sched = 2; g.sched_gm = 1;                               // m-bands per XCD (activations outweigh the weights)
-        nblocks = 8 * ((MT + 7) / 8) * NT;
-    } else if (NT >= 8) {
-        const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
-        long panel = (long)BM * ktiles * 64 * 2;
-        int gm = (int)((3 << 19) / (panel > 0 ? panel : 1));
-        if (gm < 1) gm = 1;
-        if (gm > MT) gm = MT;
-        g.sched = 1; g.sched_gm = gm;                              // n-ranges per XCD, L2-sized m-groups
-        nblocks = 8 * ((NT + 7) / 8) * MT;
     } else {
-        g.sched = 2; g.sched_gm = 1;
-        nblocks = 8 * ((MT + 7) / 8) * NT;
+        // balanced contiguous ranges per XCD (sched 3 in rq_gemm_tile_coords); groups of 8 m-tiles: 32 concurrent tiles of
+        // an XCD = 8 A panels x 4 W panels
+        g.sched = 3;
+        g.sched_gm = env_gm > 0 ? env_gm : 8;
+        if (g.sched_gm > MT) g.sched_gm = MT;
+        nblocks = 8 * ((MT * NT + 7) / 8);
     }
     RQ_LAUNCH((gemm_p8_kernel<TR>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
     return rq_check_launch("gemm_p8_kernel");
@@ -184,7 +178,27 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     // LDS-DMA staged operands win or tie from M = 512 up (profiles/r01_gemm_bench_lds_dma.txt, MI355X): 8-12 % at
     // M = 4096.  Tiles per shape class, from the same sweep:
     static const bool no_glds = getenv("RQAMD_NO_GLDS") != nullptr;
+    static const bool no_p8 = getenv("RQAMD_NO_P8") != nullptr;        // A/B switch
     if (glds) *glds = 0;
+    // 256 x 256 eight-phase kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how well the tile count fills
+    // rounds of 256 CUs.  From the interleaved A/B on MI355X (profiles/r02_gemm_p8_ab.txt): it wins whenever the last round is
+    // >= ~85 % full or there are >= 4 rounds; residual-producing GEMMs may split K to reach ~192-256 workgroups (M = 4096 fc2:
+    // 2 splits 76 us vs 102; M = 2048: 4 splits 45 vs 59), with >= 12 K-tiles per split.
+    if (glds && !no_glds && !no_p8 && M >= 2048 && K % 64 == 0 && K / 64 >= 2) {
+        const int MT = (M + 255) / 256, NT = (N + 255) / 256;
+        const long tiles = (long)MT * NT;
+        int sk = 1;
+        if (allow_splitk && tiles < 160) {
+            while (sk < 4 && tiles * sk < 160 && (K / 64) % (sk * 2) == 0 && K / 64 / (sk * 2) >= 12) sk *= 2;
+        }
+        const long wgs = tiles * sk;
+        const long rounds = (wgs + 255) / 256;
+        const double fill = (double)wgs / (256.0 * rounds);
+        if (wgs >= 160 && (fill >= 0.84 || rounds >= 4 || (fill >= 0.74 && (N <= 2048 || M >= 8192)))) {
+            *bm = 256; *bn = 256; *splitk = sk; *glds = 2;
+            return;
+        }
+    }
     if (glds && !no_glds && M >= 512 && K % 64 == 0) {
         *glds = 2;
         if (N >= 16384 && M >= 512) {                       // classifier: wide N, fp32 rows

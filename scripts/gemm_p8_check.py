@@ -54,7 +54,7 @@ def timeit(a, ws, bias, epi, bm, bn, sk, reps=30):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     ok = True
     for (M, N, K, epi, sk) in ((8192, 4608, 1536, 0, 1), (8192, 1536, 1536, 4, 1), (8192, 6144, 1536, 1, 1), (8192, 1536, 6144, 4, 2),
                                (4096, 16384, 1536, 3, 1), (500, 6144, 1536, 1, 1), (2049, 1536, 6144, 4, 4), (8192, 2560, 2560, 4, 1)):
