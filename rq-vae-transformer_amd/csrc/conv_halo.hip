@@ -59,14 +59,19 @@ static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) 
 // 230 us launch, nearly additive) -- so two independent workgroups per CU let one's staging / epilogue run under the
 // other's MFMAs.  The price: a 6 x 34 patch per 4 x 32 tile (1.59x the interior instead of 1.33x), every weight tile
 // staged for half as many pixels, and an extra barrier per chunk (the patch buffer is refilled in place).
+// TH = 16 (round 2, optional): sixteen rows per tile with FOUR rows per wavefront -- wave tile 128 pixels x 64 channels =
+// acc[4][2], 0.75 KB of LDS fragment reads per MFMA instead of 1 KB, 32 MFMAs per wavefront between barriers instead of 16,
+// a (16+2) x 34 patch = 1.20x the interior (1.33x at 8 rows) and every weight tile staged for twice the pixels.  The patch
+// (78 KB per 64-channel chunk) is single-buffered: the next chunk's pieces wait, already normalised, in their registers.
 template <int FUSE_GN, int UPS, int TH>
-__global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(ConvHaloArgs p) {
-    constexpr int NTH = TH * 64;                   // threads: one wavefront per (row pair, cout half)
+__global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    constexpr int NTH = (TH == 16 ? 8 : TH) * 64;  // threads: one wavefront per (row group, cout half)
+    constexpr int RPW = TH == 16 ? 4 : 2;          // tile rows per wavefront
     constexpr int NB_H = TH == 8 ? 2 : 1;          // patch buffers
     constexpr int W_IT = 1024 / NTH;               // 16-byte chunks of a weight tile per thread
     constexpr int TPX = TH * HT_W;                 // pixels per tile
     // with two workgroups per CU the other one covers global latency: shallow prefetch, fewer registers (<= 256 needed)
-    constexpr int W_SETS = TH == 8 ? 3 : 1;        // weight tiles in flight (register sets)
+    constexpr int W_SETS = TH == 8 ? 3 : 1;   // weight tiles in flight (register sets)
     constexpr bool RPRE = TH == 8;                 // residual tile prefetched into registers during the last taps
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
     constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
     char* sH = (char*)smem;                        // [2][HALO_BYTES]
     char* sW = sH + NB_H * HALO_BYTES;             // [2][HW_BYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;       // (TH/2) x 2 wavefronts: rows (tile y pairs) x cout halves
+    const int wm = wave >> 1, wn = wave & 1;       // (TH/RPW) x 2 wavefronts: rows (groups of RPW tile rows) x cout halves
 
     // ---- tile decode: contiguous band of tiles per XCD (neighbouring tiles share halo rows in that L2)
     const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
@@ -92,22 +97,30 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
     const int n0 = nt * H_BN;
 
-    // ---- halo staging bookkeeping (loop-invariant): byte offsets from x, validity, LDS offsets
-    unsigned h_goff[H_IT], h_loff[H_IT];
-    bool h_in[H_IT], h_ok[H_IT];
+    // ---- halo staging bookkeeping (loop-invariant), ONE packed register per piece: source pixel index inside the image
+    // (16 bits: H * W <= 65536, clamped into the image so that every load is readable), LDS offset in 16-byte units
+    // (13 bits), "inside the image" (bit 29: else the piece is stored as zeros) and "piece exists" (bit 30).  Kept packed
+    // because the 16-row variant has 10 pieces per thread next to 128 accumulator registers.
+    unsigned hd[H_IT];
+    const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;                       // source image
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
         const int q = tid + NTH * it;
         const int hp = q >> 3, c8 = q & 7;
-        h_in[it] = hp < HP_N;
+        const bool in = hp < HP_N;
         const int hy = hp / PW, hx = hp - hy * PW;
-        const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;                       // source image
         const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
-        h_ok[it] = h_in[it] && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
         const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
-        h_goff[it] = (unsigned)((((long)img * Hs + cy) * Ws + cx) * p.Cin + c8 * 8) * 2u;     // clamped: always readable
-        h_loff[it] = h_in[it] ? halo_lds_off<PW>(hy, hx, c8) : 0u;
+        const unsigned loff16 = in ? halo_lds_off<PW>(hy, hx, c8) >> 4 : 0u;
+        hd[it] = (unsigned)(cy * Ws + cx) | (loff16 << 16) | (ok ? 1u << 29 : 0u) | (in ? 1u << 30 : 0u);
     }
+    const unsigned x_img = (unsigned)((long)img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);   // bytes; < 4 GiB (launcher)
+    const unsigned cin2 = (unsigned)p.Cin * 2u;
+    auto h_in = [&](int it) { return (hd[it] >> 30) & 1u; };
+    auto h_ok = [&](int it) { return (hd[it] >> 29) & 1u; };
+    auto h_loff = [&](int it) { return ((hd[it] >> 16) & 0x1fffu) << 4; };
+    auto h_goff = [&](int it) { return x_img + (hd[it] & 0xffffu) * cin2; };
     // weight staging: 128 rows x 8 chunks = 1024 chunks, W_IT per thread
     const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row + (NTH / 8) i
     unsigned w_goff[W_IT], w_loff[W_IT];
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
     f32x4 gs[4];
     auto load_halo = [&](int c, rq_u128* rh) {
 #pragma unroll
-        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff[it] + (unsigned)c * 128u));
+        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u));
         if (FUSE_GN) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
@@ -154,13 +167,13 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
             v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
             v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
         }
-        if (!h_ok[it]) v = zero128();              // zero padding of the (normalised) input
+        if (!h_ok(it)) v = zero128();              // zero padding of the (normalised) input
         return v;
     };
     // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS
     auto store_halo_piece = [&](int c, int buf, const rq_u128* rh, int it) {
-        if (!h_in[it]) return;
-        st128(sH + buf * HALO_BYTES + h_loff[it], halo_piece_value(rh, it));
+        if (!h_in(it)) return;
+        st128(sH + buf * HALO_BYTES + h_loff(it), halo_piece_value(rh, it));
     };
     auto store_halo = [&](int c, int buf, const rq_u128* rh) {
 #pragma unroll
@@ -176,38 +189,41 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
         for (int i = 0; i < W_IT; ++i) st128(sW + buf * HW_BYTES + w_loff[i], rw[i]);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[RPW][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RPW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int ftx = lane & 31, fk = lane >> 5;
-    // fragment base addresses for k-step 0: weights row = wn*64 + ftx (+32 j); patch pixel (wm*2, ftx + kx)
+    // fragment base addresses for k-step 0: weights row = wn*64 + ftx (+32 j); patch pixel (wm*RPW, ftx + kx)
     const unsigned rd_w0 = (unsigned)((wn * 64 + ftx) * 128 + ((fk ^ ((ftx >> 1) & 7)) << 4));
     unsigned rd_h0[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
-        rd_h0[kx] = UPS ? halo_lds_off<PW>(wm, (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * 2, ftx + kx, fk);
+        rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
 
     auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
         const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES);
         const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[RPW], bfr[2];
             const char* hb = sH + (ha ^ (unsigned)(ks << 5));
             const char* wb = sW + (wa ^ (unsigned)(ks << 5));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
+            for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
             for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);   // transposed tile
+            // 128 accumulator registers leave room for two k-steps of fragments (48 registers), not for the four the
+            // scheduler would like to hoist: fence every k-step (the co-resident wavefront covers the LDS latency)
+            if (RPW == 4) rq_sched_barrier();
         }
     };
 
@@ -257,29 +273,39 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
                 }
             }
             rq_sched_barrier();
-            // next chunk's patch: pieces 0..5 in taps 3..8 (the loads were issued three taps earlier).  The fused
-            // GroupNorm+SiLU arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no
-            // fence in between) so that its VALU / transcendental instructions issue in the MFMAs' shadow.
-            const bool piece = !LAST && tap >= 9 - H_IT;
-            const int it = piece ? tap - (9 - H_IT) : 0;
-            rq_u128 pv = zero128();
-            if (piece) pv = halo_piece_value(rh, it);
-            compute(hbuf, wbuf, ky, kx);
-            if (FUSE_GN && piece) {
-                // pipeline: each MFMA (8 passes) carries a slice of the piece's ~100 VALU instructions
+            // next chunk's patch: PPT pieces per tap over the last taps of the chunk (8 rows: pieces 0..5 in taps 3..8, the
+            // loads were issued three taps earlier; 16 rows: two pieces per tap in taps 4..8).  The fused GroupNorm+SiLU
+            // arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no fence in between) so that its
+            // VALU / transcendental instructions issue in the MFMAs' shadow.
+            constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
+            const bool ptap = !LAST && tap >= FIRST;
+            // (the finished piece replaces the raw one in its register: no second copy)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
+            for (int k = 0; k < PPT; ++k) {
+                const int it = (tap - FIRST) * PPT + k;
+                if (ptap && it < H_IT) rh[it < H_IT ? it : 0] = halo_piece_value(rh, it < H_IT ? it : 0);
+            }
+            compute(hbuf, wbuf, ky, kx);
+            if (FUSE_GN && ptap) {
+                // pipeline: each MFMA (8 passes) carries a slice of the pieces' ~100 VALU instructions each
+#pragma unroll
+                for (int g = 0; g < 8 * RPW; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
             }
             store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
-            if (NB_H == 2) { if (piece && h_in[it]) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff[it], pv); }
-            else if (piece) rh[it] = pv;                   // single buffer: the finished piece waits in its register
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int it = (tap - FIRST) * PPT + k;
+                if (!(ptap && it < H_IT)) continue;
+                if (NB_H == 2) { if (h_in(it)) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff(it), rh[it]); }
+                // single buffer: the finished piece waits in its register until the chunk's last tap has been read
+            }
             rq_syncthreads();
             wbuf ^= 1;
         }
         if (NB_H == 1 && !LAST) {                          // every wave is past its reads of this chunk: refill the buffer
 #pragma unroll
             for (int it = 0; it < H_IT; ++it)
-                if (h_in[it]) st128(sH + h_loff[it], rh[it]);
+                if (h_in(it)) st128(sH + h_loff(it), rh[it]);
             rq_syncthreads();
         }
     };
@@ -288,7 +314,7 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
 
     // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
     constexpr int LDR = H_BN * 2 + 16;
-    static_assert(TPX * LDR <= NB_H * (TH + 2) * HP_W * 128 + 2 * HW_BYTES, "epilogue tile must fit the launch's LDS segment");
+    static_assert(TPX * LDR + 4096 <= 160 * 1024, "epilogue tile must fit the CU's LDS (the launcher allocates max(staging, epilogue))");
     char* sT = (char*)smem;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
     if (p.resid) {
@@ -309,8 +335,8 @@ __global__ __launch_bounds__(TH * 64, TH == 8 ? 1 : 2) void conv3x3_halo_kernel(
         rq_syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ty = wm * 2 + i, tx = lane & 31;
+    for (int i = 0; i < RPW; ++i) {
+        const int ty = wm * RPW + i, tx = lane & 31;
         const int ml = ty * HT_W + tx;
         const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
 #pragma unroll
@@ -717,13 +743,18 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
 // Measured (profiles/r01_conv_halo_tile_height.txt): equal on the 128-channel 256^2 layers, the 4-row variant 10 %
 // slower on the 256-channel layers -- the expected overlap of one workgroup's staging / epilogue with the other's MFMAs
 // is eaten by the larger halo (1.59x vs 1.33x), twice the weight staging per pixel and the shallower prefetch.
+// 16 (round 2) = four rows per wavefront (128 x 64 wave tiles, 0.75 KB of LDS reads per MFMA), single-buffered patch whose next
+// chunk waits in registers: +3..5 % on the plain conv (978 vs 929 TF at 128->128 @256^2), but with GroupNorm+SiLU fused the
+// ten patch pieces + 128 accumulators + scale/shift registers exceed 256 VGPRs and the spills cost 4-11 %
+// (profiles/r02_conv_halo_tile_height.txt) -- every ResnetBlock conv of the decoder is a fused one, so 8 stays the default.
 static int halo_th() {
-    static const int th = (getenv("RQAMD_HALO_TH") && atoi(getenv("RQAMD_HALO_TH")) == 4) ? 4 : 8;
+    static const int env = getenv("RQAMD_HALO_TH") ? atoi(getenv("RQAMD_HALO_TH")) : 0;
+    static const int th = (env == 4 || env == 16) ? env : 8;
     return th;
 }
 
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
-    return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64;
+    return H % 16 == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64 && H * W <= 65536;
 }
 
 int rq_conv_halo_stat_tiles(int H, int W) { return (H / halo_th()) * (W / HT_W); }
@@ -732,6 +763,7 @@ static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a t
 template <int TH>
 static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     constexpr size_t patch = (size_t)(TH + 2) * HP_W * 128, stage = (TH == 8 ? 2 : 1) * patch + 2 * HW_BYTES;
+    constexpr int NTHR = (TH == 16 ? 8 : TH) * 64;
     constexpr size_t epi = (size_t)TH * HT_W * (H_BN * 2 + 16);
     const size_t smem = stage > epi ? stage : epi;
     static RqDeviceOnce attr_once;      // kernel attributes are per device
@@ -742,9 +774,9 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
-    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
-    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(TH * 64), smem, s, a);
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
     return rq_check_launch("conv3x3_halo_kernel");
 }
 
@@ -757,7 +789,7 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const int th = g_conv_halo_dbg_th ? g_conv_halo_dbg_th : halo_th();
-    return th == 8 ? launch_conv_halo_th<8>(a, ups, s) : launch_conv_halo_th<4>(a, ups, s);
+    return th == 16 ? launch_conv_halo_th<16>(a, ups, s) : th == 8 ? launch_conv_halo_th<8>(a, ups, s) : launch_conv_halo_th<4>(a, ups, s);
 }
 
 // nchunk_have > 0: `part` already holds that many partials per image (written by the producing conv's epilogue)
@@ -773,7 +805,7 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
 extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
                                         int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
-    g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : 0;      // ups bit 1 / bit 2: force the 8-row / 4-row tile variant
+    g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : (ups & 8) ? 16 : 0;      // ups bits 1 / 2 / 3: force the 8- / 4- / 16-row tile variant
     const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
                                        Cin, Cout, ups & 1, (hipStream_t)stream);
     g_conv_halo_dbg_th = 0;

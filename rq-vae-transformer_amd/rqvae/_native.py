@@ -238,7 +238,7 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
     check(lib().rqamd_dbg_conv_halo_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias, torch.float32), ptr(gn), ptr(resid),
-                                         B, H, W, Cin, Cout, (1 if ups else 0) | (2 if tile_h == 8 else 4 if tile_h == 4 else 0),
+                                         B, H, W, Cin, Cout, (1 if ups else 0) | (2 if tile_h == 8 else 4 if tile_h == 4 else 8 if tile_h == 16 else 0),
                                          ptr(out), ptr(stats), stream_of(x)))
     return out
 

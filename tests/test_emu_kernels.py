@@ -330,7 +330,7 @@ def test_emu_conv_halo(nat):
     xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
     xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
-    for th in (8, 4):            # 8 x 32 tiles / 8 waves / double-buffered patch, and 4 x 32 tiles / 4 waves / single buffer
+    for th in (16, 8, 4):        # 16 x 32 tiles (4 rows per wave, single buffer), 8 x 32 (double-buffered patch), 4 x 32 (4 waves)
         out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float().numpy()
         assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max(), th
         stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), dtype=torch.float32)
@@ -344,7 +344,7 @@ def test_emu_conv_halo(nat):
     xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
     xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
     ref_up = conv2d(xu, wf, bias.numpy())
-    for th in (8, 4):
+    for th in (16, 8, 4):
         out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float().numpy()
         assert out.shape == (B, H, W, Cout)
         assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), th

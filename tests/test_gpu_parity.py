@@ -398,7 +398,7 @@ def test_conv_kernels_vs_torch(nat):
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1)
         xn = F.silu(x.float() * gn[:, None, None, :, 0] + gn[:, None, None, :, 1]).to(torch.bfloat16).float()
         ref_gn = F.conv2d(xn.permute(0, 3, 1, 2), wt, bias, padding=1).permute(0, 2, 3, 1) + resid.float()
-        for th in (8, 4):        # both tile variants of the kernel
+        for th in (16, 8, 4):    # all tile variants of the kernel
             out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float()
             assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max()), th
             stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), device=DEV)
@@ -412,7 +412,7 @@ def test_conv_kernels_vs_torch(nat):
         xs = rn(B, H // 2, W // 2, Cin).to(torch.bfloat16)
         xu = F.interpolate(xs.float().permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest')
         ref = F.conv2d(xu, wt, bias, padding=1).permute(0, 2, 3, 1)
-        for th in (8, 4):
+        for th in (16, 8, 4):
             out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float()
             assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max()), th
     # MFMA Encoder.conv_in: NCHW fp32 image -> NHWC bf16
