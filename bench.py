@@ -206,6 +206,24 @@ def per_image_decode(vae, ar, device, n=64):
             'what': 'decode_code(codes[i:i+1]) one image per call + cat + clamp, as measure_throughput/__main__.py:297-299 does'}
 
 
+def per_image_recon(vae, device, n=32):
+    """The rFID loop (rqvae/metrics/fid.py:167-169): stage1_model(img)[0] on ONE image per call = encode + residual
+    quantisation + commitment loss + decode."""
+    x = torch.randn((n, 3, 256, 256), device=device).clamp(-1, 1)
+    for i in range(3):
+        vae(x[i:i + 1])
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    outs = [vae(x[i:i + 1])[0] for i in range(n)]
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    del outs
+    return {'ms_per_image': ms, 'images_per_sec': 1e3 / ms, 'images': n,
+            'what': 'stage1_model(img[i:i+1])[0]: encode -> RQ -> decode, one image per call (rqvae/metrics/fid.py:167-169)'}
+
+
 def rq_roofline(vae, device, n_img=256):
     """Residual quantiser alone (RQBottleneck.quantize on encoder-shaped latents): FLOPs 2*K*D per vector-depth, bytes =
     z read + quants/codes written + codebook once."""
@@ -395,9 +413,10 @@ def main(argv=None):
             del es, ec
 
     # ---- per-image decode (the drivers' call pattern), BASELINE's second metric (codes/sec) and the quantiser roofline
-    pid = enc = rqr = None
+    pid = pir = enc = rqr = None
     if rank == 0 and not args.no_profile:
         pid = per_image_decode(vae, ar, device)
+        pir = per_image_recon(vae, device)
         xb = torch.randn((256, 3, 256, 256), device=device).clamp(-1, 1)
         vae.get_codes(xb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -440,7 +459,7 @@ def main(argv=None):
                                           'different batch / precision / hardware -- context, not a like-for-like ratio'},
             'ar_ms_per_image': t_ar / (args.steps * B) if not args.overlap else None,
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
-            'roofline': roofline, 'batch_sweep': sweep, 'per_image_decode': pid, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'roofline': roofline, 'batch_sweep': sweep, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

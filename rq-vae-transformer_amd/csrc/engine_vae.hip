@@ -30,6 +30,16 @@ struct rqamd_vae {
     int chunk_max = 128;
     bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false;
     std::string missing;
+    // Small batches (the drivers decode ONE image per call, measure_throughput/__main__.py:297-299, main_sampling_fid.py:223;
+    // the rFID loop encodes and decodes one image per call, rqvae/metrics/fid.py:167-169) are launch-bound: ~200 launches
+    // per image.  Their launch sequence is captured once per (direction, batch) as a hipGraph over engine-owned input /
+    // output staging buffers and replayed; the caller's tensors are copied in / out on the same stream.
+    static constexpr int GRAPH_MAX_B = 4;
+    struct Graph { hipGraphExec_t exec = nullptr; void* stream = nullptr; unsigned gen = 0; const void* io = nullptr; };
+    Graph gdec[GRAPH_MAX_B], genc[GRAPH_MAX_B];
+    DevBuf gio;                // [decode in | decode out | encode in | encode out] for GRAPH_MAX_B images
+    unsigned gen = 0;          // bumped whenever the workspace is reallocated (captured pointers become stale)
+    bool use_graph = true, graph_warned = false;
 };
 
 static int vae_level_res(const rqamd_vae_config& c, int level) { return c.resolution >> level; }
@@ -53,11 +63,15 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
+    if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RQAMD_OK;
 }
 
 extern "C" int rqamd_vae_destroy(rqamd_vae* h) {
+    if (!h) return RQAMD_OK;
+    for (auto& g : h->gdec) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : h->genc) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     delete h;
     return RQAMD_OK;
 }
@@ -246,6 +260,7 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
     // allocation succeeded (a failed hipMalloc leaves the handle empty -- chunk 0, no buffers -- never dangling)
     h->chunk = 0;
     h->cap_elems = 0;
+    h->gen++;                                    // captured graphs point into the old workspace
     for (int i = 0; i < 5; ++i) h->buf[i] = nullptr;
     const size_t elems = per_img * chunk;
     const size_t bytes = (elems * 2 + 255) & ~(size_t)255;
@@ -348,6 +363,53 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
     return r.err;
 }
 
+static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipStream_t st);
+static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStream_t st);
+
+// returns RQAMD_OK when the call was served by a graph replay, 1 when the caller should run the eager path
+static int vae_graph_run(rqamd_vae* h, bool dec, const float* in, int B, float* out, hipStream_t st) {
+    const rqamd_vae_config& c = h->cfg;
+    if (!h->use_graph || B < 1 || B > rqamd_vae::GRAPH_MAX_B || st == nullptr) return 1;      // the legacy stream cannot capture
+    const int lowres = vae_level_res(c, c.n_levels - 1);
+    const size_t lat = (size_t)lowres * lowres * c.embed_dim * 4, dpix = (size_t)c.out_ch * c.resolution * c.resolution * 4,
+                 epix = (size_t)c.in_channels * c.resolution * c.resolution * 4;
+    const size_t M = rqamd_vae::GRAPH_MAX_B;
+    const size_t o_din = 0, o_dout = o_din + M * lat, o_ein = o_dout + M * dpix, o_eout = o_ein + M * epix, total = o_eout + M * lat;
+    RQ_TRY(vae_prepare(h, B > h->chunk ? B : h->chunk));          // allocation happens outside the capture
+    if (h->gio.bytes < total) { RQ_TRY(h->gio.reserve(total)); h->gen++; }
+    char* io = (char*)h->gio.p;
+    float* gin = (float*)(io + (dec ? o_din : o_ein));
+    float* gout = (float*)(io + (dec ? o_dout : o_eout));
+    rqamd_vae::Graph& g = (dec ? h->gdec : h->genc)[B - 1];
+    if (!g.exec || g.stream != (void*)st || g.gen != h->gen || g.io != h->gio.p) {
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (!h->graph_warned) {
+                fprintf(stderr, "librqamd: hipStreamBeginCapture failed (%s); per-image encode / decode runs with eager launches\n", hipGetErrorString(e));
+                h->graph_warned = true;
+            }
+            h->use_graph = false;
+            return 1;
+        }
+        const int rc = dec ? decode_chunk(h, gin, B, gout, st) : encode_chunk(h, gin, B, gout, st);
+        hipGraph_t graph = nullptr;
+        e = hipStreamEndCapture(st, &graph);
+        if (rc != RQAMD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { g.exec = nullptr; return rq_fail(RQAMD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        g.stream = (void*)st; g.gen = h->gen; g.io = h->gio.p;
+    }
+    const size_t in_bytes = (size_t)B * (dec ? lat : epix), out_bytes = (size_t)B * (dec ? dpix : lat);
+    RQ_HIP(hipMemcpyAsync(gin, in, in_bytes, hipMemcpyDeviceToDevice, st));
+    RQ_HIP(hipGraphLaunch(g.exec, st));
+    RQ_HIP(hipMemcpyAsync(out, gout, out_bytes, hipMemcpyDeviceToDevice, st));
+    return RQAMD_OK;
+}
+
 extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float* out, void* stream) {
     if (!h || !z_q || !out) return rq_fail(RQAMD_ERR_INVALID, "vae_decode: null argument");
     if (batch < 0) return rq_fail(RQAMD_ERR_INVALID, "vae_decode: batch < 0");
@@ -355,6 +417,10 @@ extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float
     const int lowres = vae_level_res(c, c.n_levels - 1);
     const int chunk = batch < h->chunk_max ? batch : h->chunk_max;
     if (batch == 0) return RQAMD_OK;
+    {
+        const int g = vae_graph_run(h, true, z_q, batch, out, (hipStream_t)stream);
+        if (g != 1) return g;
+    }
     RQ_TRY(vae_prepare(h, chunk));
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
@@ -371,6 +437,10 @@ extern "C" int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* 
     const int lowres = vae_level_res(c, c.n_levels - 1);
     const int chunk = batch < h->chunk_max ? batch : h->chunk_max;
     if (batch == 0) return RQAMD_OK;
+    {
+        const int g = vae_graph_run(h, false, x, batch, z_e, (hipStream_t)stream);
+        if (g != 1) return g;
+    }
     RQ_TRY(vae_prepare(h, chunk));
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;

@@ -19,3 +19,28 @@ def push_all(module, engine, skip_prefixes=()):
             if any(k.startswith(p) for p in skip_prefixes):
                 continue
             engine.set_param(k, v)
+
+
+class SideStream:
+    """hipGraph capture is illegal on the legacy default stream, which is what torch hands out as the current stream unless
+    the caller set one.  The engines therefore run on a stream of their own, ordered after the caller's current stream on
+    entry and before it on exit; results are tagged for the caller's stream (record_stream) so that the caching allocator
+    does not recycle them early."""
+
+    def __init__(self):
+        self._stream = None
+
+    def run(self, device, fn):
+        if device.type != 'cuda':
+            return fn()
+        cur = torch.cuda.current_stream(device)
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        side = self._stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = fn()
+        cur.wait_stream(side)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            t.record_stream(cur)
+        return out

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import _native
-from .._sync import push_all, signature
+from .._sync import SideStream, push_all, signature
 from ..interfaces import Stage2Model
 from .attentions import AttentionStack
 from .configs import resolve
@@ -80,7 +80,7 @@ class RQTransformer(Stage2Model):
         self._cache = None
         self._engine = None
         self._engine_sig = None
-        self._side_stream = None
+        self._side = SideStream()
         self.use_graph = os.environ.get('RQAMD_GRAPH', '1') != '0'
 
     # ------------------------------------------------------------------ engine plumbing
@@ -133,21 +133,7 @@ class RQTransformer(Stage2Model):
         return cond.reshape(B, self.block_size_cond).to(device=device, dtype=torch.long).contiguous()
 
     def _on_side_stream(self, device, fn):
-        """hipGraph capture is illegal on the legacy default stream, so the engine runs on its own stream,
-        ordered after / before the caller's current stream."""
-        if device.type != 'cuda':
-            return fn()
-        cur = torch.cuda.current_stream(device)
-        if self._side_stream is None or self._side_stream.device != device:
-            self._side_stream = torch.cuda.Stream(device=device)
-        side = self._side_stream
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            out = fn()
-        cur.wait_stream(side)
-        for t in (out if isinstance(out, tuple) else (out,)):
-            t.record_stream(cur)
-        return out
+        return self._side.run(device, fn)
 
     # ------------------------------------------------------------------ reference API
     def init_cache(self):

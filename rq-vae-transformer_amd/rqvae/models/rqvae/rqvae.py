@@ -9,7 +9,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from ... import _native
-from .._sync import push_all, signature
+from .._sync import SideStream, push_all, signature
 from ..interfaces import Stage1Model
 from .layers import ResnetBlock
 from .modules import Decoder, Encoder
@@ -61,6 +61,7 @@ class RQVAE(Stage1Model):
         self.latent_loss_weight = latent_loss_weight
         self._engine = None
         self._engine_sig = None
+        self._side = SideStream()
 
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
@@ -87,12 +88,16 @@ class RQVAE(Stage1Model):
     @torch.no_grad()
     def encode(self, x):
         """rqvae.py:80-83: (B,3,H,W) -> (B,h,w,embed_dim) NHWC fp32"""
-        return self._eng().encode(x.detach().to(torch.float32).contiguous())
+        x = x.detach().to(torch.float32).contiguous()
+        eng = self._eng()
+        return self._side.run(x.device, lambda: eng.encode(x))
 
     @torch.no_grad()
     def decode(self, z_q):
         """rqvae.py:85-89: (B,h,w,embed_dim) NHWC -> (B,3,H,W) fp32"""
-        return self._eng().decode(z_q.detach().to(torch.float32).contiguous())
+        z_q = z_q.detach().to(torch.float32).contiguous()
+        eng = self._eng()
+        return self._side.run(z_q.device, lambda: eng.decode(z_q))
 
     @torch.no_grad()
     def get_codes(self, xs):

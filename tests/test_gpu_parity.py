@@ -381,6 +381,29 @@ def test_vae_batch_invariance_and_chunking(nat, golden):
     assert torch.equal(vae.encode(x)[3:4], vae.encode(x[3:4].contiguous()))
 
 
+def test_vae_per_image_driver_loops(nat, golden):
+    """What the unchanged drivers do with the stage-1 model: decode ONE image per call and concatenate
+    (measure_throughput/__main__.py:297-299, main_sampling_fid.py:223), and the rFID loop's `stage1_model(img)[0]` on one
+    image per call (rqvae/metrics/fid.py:167-169).  Batches of <= 4 images replay a captured hipGraph; larger ones launch
+    eagerly -- both must give the same bits, row for row."""
+    g = golden('vae_imagenet.npz')
+    vae, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    rng = np.random.default_rng(7)
+    codes = G(rng.integers(0, 16384, (6, 8, 8, 4)), torch.long)
+    full = vae.decode_code(codes)                                              # eager (6 > 4)
+    loop = torch.cat([vae.decode_code(codes[i:i + 1]) for i in range(6)], dim=0)   # graph replays
+    assert torch.equal(full, loop)
+    pair = torch.cat([vae.decode_code(codes[i:i + 2]) for i in range(0, 6, 2)], dim=0)
+    assert torch.equal(full, pair)
+    x = G(np.clip(rng.standard_normal((5, 3, 256, 256), dtype=np.float32), -1, 1))
+    out_b, loss_b, code_b = vae(x)
+    outs = [vae(x[i:i + 1]) for i in range(5)]
+    assert torch.equal(torch.cat([o[2] for o in outs]), code_b)
+    assert torch.equal(torch.cat([o[0] for o in outs]), out_b)
+    xr, xrec = vae.get_recon_imgs(x, out_b)
+    assert float(xrec.min()) >= 0.0 and float(xrec.max()) <= 1.0 and xr.shape == x.shape
+
+
 def test_conv_kernels_vs_torch(nat):
     """The high-resolution conv kernels through the diagnostics ABI against torch fp32 convs on the bf16-rounded
     operands: halo 3x3 (plain / fused GroupNorm+SiLU / residual) and the MFMA conv_out (NCHW fp32 image out)."""
