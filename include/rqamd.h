@@ -42,9 +42,13 @@ const char* rqamd_last_error(void);
  * quant_cum (depth, n_vec, dim) fp32 cumulative quants (quant_list) or NULL.
  * code_norms[d] (n_embed[d]) fp32 = ||c||^2 per code from rqamd_rq_code_norms, owned and cached by the caller per codebook
  * version (no library-side scratch: calls on different streams / threads never share state).
- * Distances use the reference's expanded form ||x||^2+||c||^2-2x.c in fp32; ties -> lowest index. */
+ * Distances use the reference's expanded form ||x||^2+||c||^2-2x.c in fp32; ties -> lowest index.
+ * workspace (caller-owned device scratch, n_vec * dim * 4 + n_vec * 64 * 8 bytes, or NULL): lets small inputs (< 96 tiles
+ * of 64 vectors: the per-image rFID / get_codes calls) divide the codebook over the chip, one launch pair per depth; the
+ * result is bit-identical to the single-launch path. */
 int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
-                      int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream);
+                      int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 /* rqamd_rq_code_norms <- the codebook_t.pow(2).sum(0) term of compute_distances (quantizations.py:51-52). */
 int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream);
 

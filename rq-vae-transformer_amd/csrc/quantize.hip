@@ -18,11 +18,12 @@
 // Lane map of one 4-MFMA group (k-permutation is free as long as A and B agree): lane (i = l&31,
 // half = l>>5) loads float4 r[i][8q+4*half .. +3] and c[j][8q+4*half .. +3]; MFMA m of the group
 // consumes component m of both, so half 0 contributes dim 8q+m and half 1 dim 8q+4+m.
+#include <stdlib.h>
 #include "rq_common.h"
 
 #define RQ_MAX_DEPTH 8
 struct RqQuantArgs {
-    const float* x;
+    const float* x;                    // (n_vec, dim): the input; split mode, depth > 0: the residual buffer
     const float* cb[RQ_MAX_DEPTH];
     const float* cn[RQ_MAX_DEPTH];     // ||c||^2 per code
     int K[RQ_MAX_DEPTH];
@@ -30,11 +31,17 @@ struct RqQuantArgs {
     long n_vec;
     int64_t* codes;
     float* quant_cum;                  // (depth, n_vec, dim) or null
+    // split mode (few vectors: one launch per depth, the codebook divided over blockIdx.y)
+    int dep, n_split, tiles_per_split;
+    float* part_v;                     // [n_vec][n_split] partial minima
+    int* part_i;
+    float* resid;                      // [n_vec][dim] residual between the per-depth launches
 };
 
 constexpr int QT_M = 64;     // vectors per workgroup
-constexpr int QT_N = 128;    // codes per tile (4 waves x 32)
+constexpr int QT_N = 128;    // codes per tile (4 code groups x 32)
 constexpr int QT_K = 64;     // dims per staged chunk
+constexpr int QT_NTH = 512;  // 8 wavefronts: 2 vector halves x 4 code groups, one 32 x 32 accumulator each
 
 __global__ void rq_code_norm_kernel(const float* cb, int K, int dim, float* cn) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,7 +57,22 @@ __global__ void rq_code_norm_kernel(const float* cb, int K, int dim, float* cn) 
     cn[k] = (s0 + s1) + (s2 + s3);
 }
 
-__global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
+// ||r||^2 of one vector, accumulated by the 8 threads that share it (thread `useg` takes float4s useg, useg + 8, ...): the ONE
+// summation order used wherever a residual norm is formed (load phase, update phase, split-mode combine), so that the fused
+// and the split path produce bit-identical distances.
+static __device__ __forceinline__ float rq_norm8(float ss) {
+    ss += rq_shfl_xor(ss, 1);
+    ss += rq_shfl_xor(ss, 2);
+    ss += rq_shfl_xor(ss, 4);
+    return ss;
+}
+
+// SPLIT = 0: all depths in one launch (residual in LDS).  SPLIT = 1: depth p.dep only, codes of tiles
+// [blockIdx.y * tiles_per_split, ...) only; the per-vector partial minimum goes to part_v / part_i and
+// rq_split_combine_kernel finishes the depth.  Eight wavefronts (round 1 had four with two accumulators each: one wavefront per
+// SIMD, so every LDS / barrier latency was exposed -- 58 % of the fp32 MFMA peak); two per SIMD cover each other.
+template <int SPLIT>
+__global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
     RQ_DYN_SMEM(smem);
     const int D = p.dim;
     const int RS = D + 4;                 // residual row stride (floats): odd multiple of 16 B
@@ -63,52 +85,54 @@ __global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
     int* sCode = sRedI + 4 * QT_M;                    // [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vh = wave >> 2, cw = wave & 3;          // vector half (32 rows), code group (32 columns of the tile)
     const long v0 = (long)blockIdx.x * QT_M;
-    const int urow = tid >> 2, useg = tid & 3;        // update-phase mapping: 4 threads per vector
+    const int urow = tid >> 3, useg = tid & 7;        // load / update mapping: 8 threads per vector
     const long uvec = v0 + urow;
     const bool uok = uvec < p.n_vec;
-    const int nf4 = D / 16;                           // float4s per thread in the update phase
+    const int nf4 = D / 32;                           // float4s per thread
 
-    // ---- load x into the LDS residual, ||x||^2
+    // ---- load the vectors into the LDS residual, ||x||^2
     {
         float ss = 0.f;
         for (int i = 0; i < nf4; ++i) {
-            int f = useg + 4 * i;
+            int f = useg + 8 * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (uok) v = *(const f32x4*)(p.x + uvec * D + f * 4);
             *(f32x4*)(sR + urow * RS + f * 4) = v;
             ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
         }
-        ss += rq_shfl_xor(ss, 1);
-        ss += rq_shfl_xor(ss, 2);
+        ss = rq_norm8(ss);
         if (useg == 0) sXn[urow] = ss;
     }
     rq_syncthreads();
 
     const int fi = lane & 31, fh = lane >> 5;
     const int nchunk = D / QT_K;
-    const int srow = tid >> 4, sf4 = tid & 15;        // staging: 16 threads x float4 per 64-dim row
+    const int srow = tid >> 4, sf4 = tid & 15;        // staging: 16 threads x float4 per 64-dim row, rows srow + 32 i
 
-    for (int dep = 0; dep < p.depth; ++dep) {
+    const int dep_lo = SPLIT ? p.dep : 0, dep_hi = SPLIT ? p.dep + 1 : p.depth;
+    for (int dep = dep_lo; dep < dep_hi; ++dep) {
         const float* cb = p.cb[dep];
         const float* cn = p.cn[dep];
         const int K = p.K[dep];
-        const int ntile = (K + QT_N - 1) / QT_N;
-        const int nstep = ntile * nchunk;
+        const int ntile_all = (K + QT_N - 1) / QT_N;
+        const int tile_lo = SPLIT ? blockIdx.y * p.tiles_per_split : 0;
+        int tile_hi = SPLIT ? tile_lo + p.tiles_per_split : ntile_all;
+        tile_hi = tile_hi < ntile_all ? tile_hi : ntile_all;
+        const int nstep = (tile_hi - tile_lo) * nchunk;
 
-        float bestv[2][16];
-        int besti[2][16];
+        float bestv[16];
+        int besti[16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { bestv[h][r] = __int_as_float(0x7f800000); besti[h][r] = 0; }
+        for (int r = 0; r < 16; ++r) { bestv[r] = __int_as_float(0x7f800000); besti[r] = 0x7fffffff; }
 
-        f32x4 stage[8];
+        f32x4 stage[4];
         auto load_chunk = [&](int step) {
-            int tile = step / nchunk, c = step - tile * nchunk;
+            int tile = tile_lo + step / nchunk, c = step - (step / nchunk) * nchunk;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int code = tile * QT_N + srow + 16 * i;
+            for (int i = 0; i < 4; ++i) {
+                int code = tile * QT_N + srow + 32 * i;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (code < K) v = *(const f32x4*)(cb + (long)code * D + c * QT_K + sf4 * 4);
                 stage[i] = v;
@@ -117,74 +141,66 @@ __global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
         auto store_chunk = [&](int buf) {
             float* dst = sC + buf * QT_N * CS;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) *(f32x4*)(dst + (srow + 16 * i) * CS + sf4 * 4) = stage[i];
+            for (int i = 0; i < 4; ++i) *(f32x4*)(dst + (srow + 32 * i) * CS + sf4 * 4) = stage[i];
         };
 
-        f32x16 acc0, acc1;
+        f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-        load_chunk(0);
-        store_chunk(0);
+        if (nstep > 0) {
+            load_chunk(0);
+            store_chunk(0);
+        }
         rq_syncthreads();
         for (int step = 0; step < nstep; ++step) {
             const int buf = step & 1;
-            const int tile = step / nchunk, c = step - tile * nchunk;
+            const int tile = tile_lo + step / nchunk, c = step - (step / nchunk) * nchunk;
             const bool more = step + 1 < nstep;
             if (more) load_chunk(step + 1);
-            const float* cT = sC + buf * QT_N * CS + (wave * 32 + fi) * CS + 4 * fh;
-            const float* r0 = sR + fi * RS + c * QT_K + 4 * fh;
-            const float* r1 = r0 + 32 * RS;
+            const float* cT = sC + buf * QT_N * CS + (cw * 32 + fi) * CS + 4 * fh;
+            const float* r0 = sR + (vh * 32 + fi) * RS + c * QT_K + 4 * fh;
 #pragma unroll
             for (int q = 0; q < QT_K / 8; ++q) {
                 f32x4 b = *(const f32x4*)(cT + 8 * q);
                 f32x4 a0 = *(const f32x4*)(r0 + 8 * q);
-                f32x4 a1 = *(const f32x4*)(r1 + 8 * q);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    acc0 = rq_mfma_32x32x2_f32(a0[m], b[m], acc0);
-                    acc1 = rq_mfma_32x32x2_f32(a1[m], b[m], acc1);
-                }
+                for (int m = 0; m < 4; ++m) acc = rq_mfma_32x32x2_f32(a0[m], b[m], acc);
             }
             if (c == nchunk - 1) {
-                // distances of this lane's code column against its 32 rows
-                const int code = tile * QT_N + wave * 32 + fi;
+                // distances of this lane's code column against its 16 rows
+                const int code = tile * QT_N + cw * 32 + fi;
                 const bool valid = code < K;
                 const float cnv = valid ? cn[code] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    float d0 = fmaf(-2.0f, acc0[r], sXn[row] + cnv);
-                    float d1 = fmaf(-2.0f, acc1[r], sXn[row + 32] + cnv);
-                    if (valid && d0 < bestv[0][r]) { bestv[0][r] = d0; besti[0][r] = code; }
-                    if (valid && d1 < bestv[1][r]) { bestv[1][r] = d1; besti[1][r] = code; }
-                    acc0[r] = 0.f;
-                    acc1[r] = 0.f;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
+                    float d0 = fmaf(-2.0f, acc[r], sXn[row] + cnv);
+                    if (valid && d0 < bestv[r]) { bestv[r] = d0; besti[r] = code; }
+                    acc[r] = 0.f;
                 }
             }
             if (more) store_chunk(buf ^ 1);
             rq_syncthreads();
         }
 
-        // ---- wavefront (value, index) min-reduction over the 32 code columns of each half
+        // ---- wavefront (value, index) min-reduction over the 32 code columns, lowest index on ties
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+            float v = bestv[r];
+            int ix = besti[r];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = bestv[h][r];
-                int ix = besti[h][r];
-#pragma unroll
-                for (int m = 16; m >= 1; m >>= 1) {
-                    float ov = rq_shfl_xor(v, m);
-                    int oi = rq_shfl_xor_i(ix, m);
-                    if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-                }
-                if (fi == 0) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * h;
-                    sRedV[wave * QT_M + row] = v;
-                    sRedI[wave * QT_M + row] = ix;
-                }
+            for (int m = 16; m >= 1; m >>= 1) {
+                float ov = rq_shfl_xor(v, m);
+                int oi = rq_shfl_xor_i(ix, m);
+                if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
+            if (fi == 0) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
+                sRedV[cw * QT_M + row] = v;
+                sRedI[cw * QT_M + row] = ix;
+            }
+        }
         rq_syncthreads();
         if (tid < QT_M) {
             float v = sRedV[tid];
@@ -195,9 +211,17 @@ __global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
                 int oi = sRedI[w * QT_M + tid];
                 if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
-            sCode[tid] = ix;
-            if (v0 + tid < p.n_vec) p.codes[(v0 + tid) * p.depth + dep] = (int64_t)ix;
+            if (SPLIT) {
+                if (v0 + tid < p.n_vec) {
+                    p.part_v[(v0 + tid) * p.n_split + blockIdx.y] = v;
+                    p.part_i[(v0 + tid) * p.n_split + blockIdx.y] = ix;
+                }
+            } else {
+                sCode[tid] = ix;
+                if (v0 + tid < p.n_vec) p.codes[(v0 + tid) * p.depth + dep] = (int64_t)ix;
+            }
         }
+        if (SPLIT) return;
         rq_syncthreads();
 
         // ---- residual -= c[code]; aggregated += c[code]; new ||r||^2   (quantizations.py:264-267)
@@ -205,7 +229,7 @@ __global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
             const float* q = cb + (long)sCode[urow] * D;
             float ss = 0.f;
             for (int i = 0; i < nf4; ++i) {
-                int f = useg + 4 * i;
+                int f = useg + 8 * i;
                 f32x4 qv = *(const f32x4*)(q + f * 4);
                 f32x4 rv = *(f32x4*)(sR + urow * RS + f * 4);
                 rv = rv - qv;
@@ -217,11 +241,42 @@ __global__ __launch_bounds__(256) void rq_quantize_kernel(RqQuantArgs p) {
                     *(f32x4*)(p.quant_cum + ((long)dep * p.n_vec + uvec) * D + f * 4) = agg;
                 }
             }
-            ss += rq_shfl_xor(ss, 1);
-            ss += rq_shfl_xor(ss, 2);
+            ss = rq_norm8(ss);
             if (useg == 0) sXn[urow] = ss;
         }
         rq_syncthreads();
+    }
+}
+
+// split mode, second half of a depth: combine the per-split partial minima (splits are ascending code ranges: the lowest
+// index wins a tie), write the code, residual -= c[code] (into p.resid), aggregated += c[code].  8 threads per vector.
+__global__ __launch_bounds__(512) void rq_split_combine_kernel(RqQuantArgs p) {
+    const int tid = threadIdx.x;
+    const int urow = tid >> 3, useg = tid & 7;
+    const long vec = (long)blockIdx.x * 64 + urow;
+    if (vec >= p.n_vec) return;
+    const int D = p.dim, dep = p.dep;
+    float v = p.part_v[vec * p.n_split];
+    int ix = p.part_i[vec * p.n_split];
+    for (int s2 = 1; s2 < p.n_split; ++s2) {
+        const float ov = p.part_v[vec * p.n_split + s2];
+        const int oi = p.part_i[vec * p.n_split + s2];
+        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+    }
+    if (useg == 0) p.codes[vec * p.depth + dep] = (int64_t)ix;
+    const float* q = p.cb[dep] + (long)ix * D;
+    const float* src = p.x + vec * D;                  // depth 0: the input; later: the residual buffer (== p.resid)
+    for (int i = 0; i < D / 32; ++i) {
+        const int f = useg + 8 * i;
+        const f32x4 qv = *(const f32x4*)(q + f * 4);
+        f32x4 rv = *(const f32x4*)(src + f * 4);
+        rv = rv - qv;
+        *(f32x4*)(p.resid + vec * D + f * 4) = rv;
+        if (p.quant_cum) {
+            f32x4 agg = qv;
+            if (dep > 0) agg = *(const f32x4*)(p.quant_cum + ((long)(dep - 1) * p.n_vec + vec) * D + f * 4) + qv;
+            *(f32x4*)(p.quant_cum + ((long)dep * p.n_vec + vec) * D + f * 4) = agg;
+        }
     }
 }
 
@@ -272,7 +327,8 @@ extern "C" int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, 
 }
 
 extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
-                                 int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* stream) {
+                                 int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
     if (n_vec == 0) return RQAMD_OK;
     if (!x || !codebooks || !code_norms || !n_embed || !codes) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: null argument");
     if (depth < 1 || depth > RQ_MAX_DEPTH) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: depth %d not in 1..%d", depth, RQ_MAX_DEPTH);
@@ -281,20 +337,53 @@ extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, 
     if (n_vec < 0) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: n_vec < 0");
     hipStream_t st = (hipStream_t)stream;
     RqQuantArgs a{};
+    int kmin = 1 << 30;
     for (int d = 0; d < depth; ++d) {
         if (n_embed[d] < 1 || !codebooks[d] || !code_norms[d]) return rq_fail(RQAMD_ERR_INVALID, "rq_quantize: empty codebook / missing norms");
         a.cb[d] = codebooks[d];
         a.K[d] = n_embed[d];
         a.cn[d] = code_norms[d];
+        kmin = n_embed[d] < kmin ? n_embed[d] : kmin;
     }
     a.x = x; a.depth = depth; a.dim = dim; a.n_vec = n_vec; a.codes = codes; a.quant_cum = quant_cum;
     const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float)
                         + (4 * QT_M + QT_M) * sizeof(int);
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    RQ_LAUNCH(rq_quantize_kernel, dim3((unsigned)((n_vec + QT_M - 1) / QT_M)), dim3(256), smem, st, a);
+    const long ntiles = (n_vec + QT_M - 1) / QT_M;
+    // Few vectors (the per-image rFID / get_codes calls: 64 vectors = ONE workgroup scanning a 16.8 MB codebook four times):
+    // divide the codebook over blockIdx.y, one launch pair per depth.  Needs the caller's workspace (residual + partials).
+    static const bool no_split = getenv("RQAMD_RQ_NO_SPLIT") != nullptr;
+    if (!no_split && workspace && ntiles * g_rq_row_scale < 96 && kmin >= 1024) {
+        const int tiles_k = (kmin + QT_N - 1) / QT_N;
+        int S = (int)(512 / ntiles);
+        S = S > 64 ? 64 : S;
+        S = S > tiles_k ? tiles_k : S;
+        if (S >= 2) {
+            const size_t need = (size_t)n_vec * dim * 4 + (size_t)n_vec * S * 8;
+            if ((size_t)workspace_bytes >= need) {
+                a.resid = (float*)workspace;
+                a.part_v = a.resid + (size_t)n_vec * dim;
+                a.part_i = (int*)(a.part_v + (size_t)n_vec * S);
+                for (int d = 0; d < depth; ++d) {
+                    const int tk = (n_embed[d] + QT_N - 1) / QT_N;
+                    a.dep = d;
+                    a.tiles_per_split = (tk + S - 1) / S;
+                    a.n_split = (tk + a.tiles_per_split - 1) / a.tiles_per_split;
+                    a.x = d == 0 ? x : a.resid;
+                    RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, st, a);
+                    RQ_TRY(rq_check_launch("rq_quantize_kernel<split>"));
+                    RQ_LAUNCH(rq_split_combine_kernel, dim3((unsigned)ntiles), dim3(512), 0, st, a);
+                    RQ_TRY(rq_check_launch("rq_split_combine_kernel"));
+                }
+                return RQAMD_OK;
+            }
+        }
+    }
+    RQ_LAUNCH(rq_quantize_kernel<0>, dim3((unsigned)ntiles), dim3(QT_NTH), smem, st, a);
     return rq_check_launch("rq_quantize_kernel");
 }
 

@@ -36,7 +36,7 @@ _SIGS = {
     'rqamd_abi_version': (C.c_int, []),
     'rqamd_last_error': (C.c_char_p, []),
     'rqamd_rq_quantize': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
-                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'rqamd_rq_code_norms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
@@ -169,9 +169,13 @@ def rq_quantize(x, codebooks, want_quants=True, norms=None):
             norms.append(seen[key])
     codes = torch.empty((n_vec, depth), dtype=torch.int64, device=x.device)
     quants = torch.empty((depth, n_vec, dim), dtype=torch.float32, device=x.device) if want_quants else None
+    ws = None
+    if 0 < n_vec < 96 * 64:          # small inputs: scratch for the codebook-split path (residual + per-split partial minima)
+        ws = torch.empty((n_vec * dim * 4 + n_vec * 64 * 8,), dtype=torch.uint8, device=x.device)
     with on_device_of(x):
         check(lib().rqamd_rq_quantize(ptr(x, torch.float32), _ptr_array(codebooks), _ptr_array(norms),
-                                      _int_array([c.shape[0] for c in codebooks]), depth, n_vec, dim, ptr(codes), ptr(quants), stream_of(x)))
+                                      _int_array([c.shape[0] for c in codebooks]), depth, n_vec, dim, ptr(codes), ptr(quants),
+                                      ptr(ws), 0 if ws is None else ws.numel(), stream_of(x)))
     return codes, quants
 
 

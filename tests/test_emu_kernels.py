@@ -63,6 +63,26 @@ def test_emu_rq_quantize_ragged(nat):
     assert nat.rq_quantize(T(np.zeros((0, 128), np.float32)), [T(c) for c in cbs])[0].shape == (0, 3)
 
 
+def test_emu_rq_quantize_codebook_split(nat):
+    """Few vectors, K >= 1024: the codebook is divided over blockIdx.y, one launch pair per depth (partial minima + combine).
+    Must be bit-identical to the single-launch path (same vectors inside a batch large enough to take it) and to the oracle."""
+    rng = np.random.default_rng(6)
+    cbs = [rng.standard_normal((k, 64), dtype=np.float32) for k in (1100, 1100, 1300)]
+    cbs[1] = cbs[0]                                                  # depths 0 / 1 share a codebook
+    x = rng.standard_normal((70, 64), dtype=np.float32)
+    codes, quants = nat.rq_quantize(T(x), [T(c) for c in cbs])                       # 2 tiles: split path
+    oq, oc = oracle.rq_quantize(x.reshape(1, 1, 70, 64), cbs)
+    gaps, _ = oracle.rq_quantize_margins(x.reshape(1, 1, 70, 64), cbs)
+    assert gaps.min() > 1e-3
+    assert np.array_equal(codes.numpy().reshape(oc.shape), oc)
+    np.testing.assert_array_equal(quants.numpy().reshape(3, 1, 1, 70, 64), np.stack(oq))
+    big = np.concatenate([x, rng.standard_normal((96 * 64 - 70, 64), dtype=np.float32)])      # 96 tiles: single launch
+    codes_b, quants_b = nat.rq_quantize(T(big), [T(c) for c in cbs])
+    assert torch.equal(codes_b[:70], codes) and torch.equal(quants_b[:, :70], quants)
+    c2, none = nat.rq_quantize(T(x), [T(c) for c in cbs], want_quants=False)
+    assert none is None and torch.equal(c2, codes)
+
+
 @pytest.mark.parametrize('case', [3, 5, 6])
 def test_emu_sampler_filter(nat, golden, case):
     g = golden('sampler.npz')

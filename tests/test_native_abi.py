@@ -48,8 +48,8 @@ def test_status_codes_without_gpu(lib_path):
     assert lib.rqamd_rqt_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
     assert b'head_dim' in lib.rqamd_last_error()
     assert lib.rqamd_vae_decode(None, None, 1, None, None) == -1
-    lib.rqamd_rq_quantize.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 3
-    assert lib.rqamd_rq_quantize(None, None, None, None, 4, 0, 256, None, None, None) == 0     # empty input is a no-op
+    lib.rqamd_rq_quantize.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
+    assert lib.rqamd_rq_quantize(None, None, None, None, 4, 0, 256, None, None, None, 0, None) == 0     # empty input is a no-op
 
 
 def test_no_cpu_fallback(lib_path, monkeypatch):
