@@ -23,12 +23,13 @@
 struct rqamd_vae {
     rqamd_vae_config cfg;
     std::map<std::string, std::unique_ptr<DevBuf>> params;
+    DevBuf slab;               // fp32 split-K partial slabs of the small-batch mode (<= 8 images per call)
     DevBuf ws, part, gnp;      // gnp: [chunk][C][2] GroupNorm (scale, shift) for the fused norm->swish->conv
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
-    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false;
+    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false, no_splitk = false;
     std::string missing;
     // Small batches (the drivers decode ONE image per call, measure_throughput/__main__.py:297-299, main_sampling_fid.py:223;
     // the rFID loop encodes and decodes one image per call, rqvae/metrics/fid.py:167-169) are launch-bound: ~200 launches
@@ -63,6 +64,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
+    h->no_splitk = getenv("RQAMD_VAE_NO_SPLITK") != nullptr;
     if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RQAMD_OK;
@@ -181,6 +183,23 @@ struct VaeRun {
         int bm = a.M >= 128 ? 128 : 64;
         const int bn = (Cout % 128 == 0) ? 128 : 64;
         if (bn == 128 && (long)(a.M / 256) * (Cout / 128) >= 512) bm = 256;     // 8-wave tile for the big layers
+        // small-batch mode: a low-resolution conv with a long reduction has a handful of tiles (8x8, 512 -> 512: four
+        // workgroups walking 72 K-tiles each, 47 us) -- divide K over blockIdx.z and finish with splitk_reduce.  The split
+        // factor depends on the layer only, so results do not depend on the batch size inside this mode.
+        const int kt = a.K / 64;
+        if (B <= 8 && Hout * Wout <= 1024 && kt >= 16 && Cout % 4 == 0 && !h->no_splitk &&
+            (epi == EPI_BF16 || epi == EPI_BF16_RESID || epi == EPI_F32)) {
+            const int sk = kt >= 64 ? 16 : (kt >= 32 ? 8 : 4);
+            const size_t need = (size_t)sk * a.M * Cout * 4;
+            if (need <= h->slab.bytes) {
+                a.epi = EPI_F32_PARTIAL; a.bias = nullptr; a.resid = nullptr; a.out = h->slab.p; a.splitk = sk;
+                err = rq_gemm_launch(a, bm, bn, st);
+                if (err) return;
+                err = rq_launch_splitk_reduce(h->slab.as<float>(), sk, a.M, Cout, b, epi == EPI_BF16_RESID ? resid : nullptr, dst,
+                                              epi == EPI_F32 ? 1 : 0, st);
+                return;
+            }
+        }
         err = rq_gemm_launch(a, bm, bn, st);
     }
     bool stat_fits(int H, int W) const { return (size_t)B * rq_conv_halo_stat_tiles(H, W) * 32 * 2 * 4 <= h->part.bytes; }
@@ -273,6 +292,8 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
         RQ_TRY(h->part.reserve((size_t)chunk * per_img_parts * 32 * 2 * 4));
     }
     RQ_TRY(h->gnp.reserve((size_t)chunk * 2048 * 2 * 4));
+    // small-batch split-K slabs: 16 slabs x (8 images x 1024 pixels) x widest layer, fp32
+    RQ_TRY(h->slab.reserve((size_t)16 * 8 * 1024 * (size_t)(c.ch * c.ch_mult[c.n_levels - 1]) * 4));
     h->cap_elems = elems;
     h->chunk = chunk;
     return RQAMD_OK;

@@ -6,6 +6,9 @@
 
 int rq_launch_groupnorm(const bf16_t* x, bf16_t* y, float* part, const float* gamma, const float* beta, int B, int HW, int C,
                         int silu, hipStream_t s);
+// out[m][n] = (bf16 or fp32)(sum_z slabs[z][m][n] + bias[n] (+ resid[m][n])): finishes a split-K conv (small-batch mode)
+int rq_launch_splitk_reduce(const float* slabs, int n_slabs, int M, int N, const float* bias, const bf16_t* resid, void* out, int out_f32,
+                            hipStream_t s);
 int rq_launch_vae_attn(const bf16_t* qkv, bf16_t* out, int B, int T, int C, hipStream_t s);
 int rq_launch_conv_in3(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);
 int rq_launch_conv_out3(const bf16_t* x, const float* w, const float* bias, float* y, int B, int H, int W, int Cin, int Cout, hipStream_t s);

