@@ -117,6 +117,36 @@ def test_main_sampling_fid_load_model(tmp_path):
     assert 'RESULT ok' in out
 
 
+def test_sample_files_round_trip_through_reference_reader(tmp_path):
+    """Wire format either side of the path: what main_sampling_fid.py:231-241 writes per batch -- the
+    gathered fp32 NCHW pixels in [0,1] pickled as `samples_(i_n).pkl` with rqvae.utils.utils.save_pickle (this repo's) and
+    the labels as `targets_(i_n).npz` -- must be readable by the REFERENCE's own consumer, rqvae/metrics/fid.py
+    create_dataset_from_files (which globs samples*.pkl and must not pick up the npz files)."""
+    out = run_py('''
+    import numpy as np
+    from rqvae.utils.utils import save_pickle, set_seed                  # this repo's
+    import rqvae.utils.utils as U
+    assert 'rq-vae-transformer_amd' in U.__file__
+    from rqvae.metrics.fid import create_dataset_from_files               # the reference's
+    tmp = sys.argv[1]
+    set_seed(3)
+    n_batches, world, B = 3, 2, 4
+    for i in range(n_batches):
+        pixels = torch.rand(world * B, 3, 8, 8)                           # what all_gather_cat returns (rank-major), fp32 in [0,1]
+        targets = torch.arange(world * B) % 5
+        save_pickle(os.path.join(tmp, f'samples_({i+1}_{n_batches}).pkl'), pixels.cpu().numpy())
+        np.savez(os.path.join(tmp, f'targets_({i+1}_{n_batches}).npz'), targets=targets.cpu().numpy())
+    ds = create_dataset_from_files(tmp)
+    assert len(ds) == n_batches * world * B
+    x = ds[5][0]
+    assert x.dtype == torch.float32 and tuple(x.shape) == (3, 8, 8) and 0.0 <= float(x.min()) and float(x.max()) <= 1.0
+    t = np.load(os.path.join(tmp, 'targets_(1_3).npz'))['targets']
+    assert t.dtype == np.int64 and t.shape == (8,)
+    print('RESULT ok')
+    ''', str(tmp_path))
+    assert 'RESULT ok' in out
+
+
 def test_launcher_runs_measure_throughput_to_the_gpu_boundary():
     """rqamd_run.py -m measure_throughput: import order, CLI parsing and model construction of the unchanged script; it must
     stop only where the script moves the models to 'cuda' (no GPU in this container)."""
