@@ -49,6 +49,13 @@ const char* rqamd_last_error(void);
 int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
                       int depth, int64_t n_vec, int dim, int64_t* codes, float* quant_cum, void* workspace,
                       int64_t workspace_bytes, void* stream);
+/* rqamd_rq_soft_codes <- RQBottleneck.get_soft_codes (quantizations.py:371-400): per depth, soft_out[v][d][:] =
+ * softmax(-distances(residual_d, codebook) / temp) (n_vec, depth, n_embed) fp32 and codes[v][d] = argmin of the distances,
+ * or -- stochastic != 0 -- one multinomial draw from that soft code (Philox keyed by seed / offset); the residual is updated
+ * with the chosen code.  All codebooks must have one size.  workspace: n_vec * (dim * 4 + 512 + n_embed * 4) bytes. */
+int rqamd_rq_soft_codes(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
+                        int depth, int64_t n_vec, int dim, float temp, int stochastic, uint64_t seed, uint64_t offset,
+                        float* soft_out, int64_t* codes, void* workspace, int64_t workspace_bytes, void* stream);
 /* rqamd_rq_code_norms <- the codebook_t.pow(2).sum(0) term of compute_distances (quantizations.py:51-52). */
 int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream);
 

@@ -82,3 +82,23 @@ def rq_embed_code_with_depth(codes, codebooks):
     """quantizations.py:313-334: (..., depth, D), no reduction."""
     codes = np.asarray(codes)
     return np.stack([np.asarray(cb, np.float32)[codes[..., i]] for i, cb in enumerate(codebooks)], -2)
+
+
+def rq_soft_codes(x, codebooks, temp=1.0):
+    """RQBottleneck.get_soft_codes, stochastic=False (quantizations.py:371-400): per depth softmax(-distances / temp) over
+    the codebook and the argmin code; x (..., D) -> soft (..., depth, K) fp32, codes (..., depth) int64."""
+    x = np.asarray(x, np.float32)
+    lead = x.shape[:-1]
+    r = x.reshape(-1, x.shape[-1]).copy()
+    softs, codes = [], []
+    for cb in codebooks:
+        d = compute_distances(r, cb)
+        z = -d / np.float32(temp)
+        z = z - z.max(-1, keepdims=True)
+        e = np.exp(z)
+        softs.append((e / e.sum(-1, keepdims=True)).astype(np.float32))
+        k = d.argmin(-1)
+        codes.append(k)
+        r = r - cb[k]
+    soft = np.stack(softs, 1).reshape(*lead, len(codebooks), -1)
+    return soft, np.stack(codes, 1).reshape(*lead, len(codebooks)).astype(np.int64)

@@ -36,6 +36,9 @@ struct RqQuantArgs {
     float* part_v;                     // [n_vec][n_split] partial minima
     int* part_i;
     float* resid;                      // [n_vec][dim] residual between the per-depth launches
+    float* logit_out;                  // split mode, or null: [n_vec][K] receives -distance * inv_temp (soft codes)
+    float inv_temp;
+    int use_codes;                     // combine: take the code from p.codes (written by the sampler) instead of the partial minima
 };
 
 constexpr int QT_M = 64;     // vectors per workgroup
@@ -177,6 +180,8 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
                     float d0 = fmaf(-2.0f, acc[r], sXn[row] + cnv);
                     if (valid && d0 < bestv[r]) { bestv[r] = d0; besti[r] = code; }
+                    if (SPLIT && p.logit_out && valid && v0 + row < p.n_vec)       // soft codes: softmax(-d / temp) logits
+                        p.logit_out[(v0 + row) * K + code] = -d0 * p.inv_temp;
                     acc[r] = 0.f;
                 }
             }
@@ -256,14 +261,19 @@ __global__ __launch_bounds__(512) void rq_split_combine_kernel(RqQuantArgs p) {
     const long vec = (long)blockIdx.x * 64 + urow;
     if (vec >= p.n_vec) return;
     const int D = p.dim, dep = p.dep;
-    float v = p.part_v[vec * p.n_split];
-    int ix = p.part_i[vec * p.n_split];
-    for (int s2 = 1; s2 < p.n_split; ++s2) {
-        const float ov = p.part_v[vec * p.n_split + s2];
-        const int oi = p.part_i[vec * p.n_split + s2];
-        if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+    int ix;
+    if (p.use_codes) {
+        ix = (int)p.codes[vec * p.depth + dep];        // stochastic soft codes: the sampler already drew this depth's code
+    } else {
+        float v = p.part_v[vec * p.n_split];
+        ix = p.part_i[vec * p.n_split];
+        for (int s2 = 1; s2 < p.n_split; ++s2) {
+            const float ov = p.part_v[vec * p.n_split + s2];
+            const int oi = p.part_i[vec * p.n_split + s2];
+            if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (useg == 0) p.codes[vec * p.depth + dep] = (int64_t)ix;
     }
-    if (useg == 0) p.codes[vec * p.depth + dep] = (int64_t)ix;
     const float* q = p.cb[dep] + (long)ix * D;
     const float* src = p.x + vec * D;                  // depth 0: the input; later: the residual buffer (== p.resid)
     for (int i = 0; i < D / 32; ++i) {
@@ -385,6 +395,81 @@ extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, 
     }
     RQ_LAUNCH(rq_quantize_kernel<0>, dim3((unsigned)ntiles), dim3(QT_NTH), smem, st, a);
     return rq_check_launch("rq_quantize_kernel");
+}
+
+
+// -------------------------------------------------------------------------------------------------
+// Soft codes: RQBottleneck.get_soft_codes (quantizations.py:371-400) = per depth softmax(-distances / temp) over the
+// codebook, the code of that depth (argmin, or one multinomial draw from the soft code when stochastic), residual update.
+// Row softmax of the logits written by the split-mode quantiser kernel: one workgroup per (vector), K <= 65536.
+__global__ __launch_bounds__(256) void rq_softmax_rows_kernel(const float* logits, int K, float* out, long out_stride) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = logits + (long)blockIdx.x * K;
+    float* dst = out + (long)blockIdx.x * out_stride;
+    float m = -__int_as_float(0x7f800000);
+    for (int k = tid; k < K; k += 256) m = fmaxf(m, src[k]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    rq_syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = 0.f;
+    for (int k = tid; k < K; k += 256) s += rq_fast_exp2((src[k] - m) * 1.4426950408889634f);
+    s = wave_sum(s);
+    if (lane == 0) red[4 + wave] = s;
+    rq_syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    for (int k = tid; k < K; k += 256) dst[k] = rq_fast_exp2((src[k] - m) * 1.4426950408889634f) * inv;
+}
+
+int rq_launch_sample_rows(const float* logits, int rows, int vocab, uint64_t seed, uint64_t offset, int64_t* out, long out_stride, hipStream_t s);
+
+extern "C" int rqamd_rq_soft_codes(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
+                                   int depth, int64_t n_vec, int dim, float temp, int stochastic, uint64_t seed, uint64_t offset,
+                                   float* soft_out, int64_t* codes, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_vec == 0) return RQAMD_OK;
+    if (!x || !codebooks || !code_norms || !n_embed || !codes || !soft_out || !workspace) return rq_fail(RQAMD_ERR_INVALID, "rq_soft_codes: null argument");
+    if (depth < 1 || depth > RQ_MAX_DEPTH) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_soft_codes: depth %d not in 1..%d", depth, RQ_MAX_DEPTH);
+    if (dim % 64 != 0 || dim < 64 || dim > 256) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_soft_codes: dim %d must be 64, 128, 192 or 256", dim);
+    if (!(temp > 0.f)) return rq_fail(RQAMD_ERR_INVALID, "rq_soft_codes: temp must be > 0");
+    const int K = n_embed[0];
+    for (int d = 0; d < depth; ++d)
+        if (n_embed[d] != K || !codebooks[d] || !code_norms[d]) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_soft_codes: codebooks of one size needed (the reference concatenates the soft codes along depth)");
+    hipStream_t st = (hipStream_t)stream;
+    const long ntiles = (n_vec + QT_M - 1) / QT_M;
+    const int tiles_k = (K + QT_N - 1) / QT_N;
+    int S = (int)(512 / ntiles);
+    S = S < 1 ? 1 : (S > 64 ? 64 : S);
+    S = S > tiles_k ? tiles_k : S;
+    const size_t need = (size_t)n_vec * dim * 4 + (size_t)n_vec * 64 * 8 + (size_t)n_vec * K * 4;
+    if ((size_t)workspace_bytes < need) return rq_fail(RQAMD_ERR_INVALID, "rq_soft_codes: workspace of %zu bytes needed", need);
+    RqQuantArgs a{};
+    for (int d = 0; d < depth; ++d) { a.cb[d] = codebooks[d]; a.K[d] = K; a.cn[d] = code_norms[d]; }
+    a.depth = depth; a.dim = dim; a.n_vec = n_vec; a.codes = codes; a.quant_cum = nullptr;
+    a.resid = (float*)workspace;
+    a.part_v = a.resid + (size_t)n_vec * dim;
+    a.part_i = (int*)(a.part_v + (size_t)n_vec * 64);
+    a.logit_out = (float*)(a.part_i + (size_t)n_vec * 64);
+    a.inv_temp = 1.0f / temp;
+    a.use_codes = stochastic ? 1 : 0;
+    a.tiles_per_split = (tiles_k + S - 1) / S;
+    a.n_split = (tiles_k + a.tiles_per_split - 1) / a.tiles_per_split;
+    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float) + (4 * QT_M + QT_M) * sizeof(int);
+    static RqDeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int d = 0; d < depth; ++d) {
+        a.dep = d;
+        a.x = d == 0 ? x : a.resid;
+        RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, st, a);
+        RQ_TRY(rq_check_launch("rq_quantize_kernel<split>"));
+        if (stochastic)      // torch.multinomial(soft_code, 1) (quantizations.py:388-390): one draw per vector from softmax(logits)
+            RQ_TRY(rq_launch_sample_rows(a.logit_out, (int)n_vec, K, seed, offset + 4ull * d, codes + d, depth, st));
+        RQ_LAUNCH(rq_split_combine_kernel, dim3((unsigned)ntiles), dim3(512), 0, st, a);
+        RQ_TRY(rq_check_launch("rq_split_combine_kernel"));
+        RQ_LAUNCH(rq_softmax_rows_kernel, dim3((unsigned)n_vec), dim3(256), 0, st, (const float*)a.logit_out, K, soft_out + (size_t)d * K, (long)depth * K);
+        RQ_TRY(rq_check_launch("rq_softmax_rows_kernel"));
+    }
+    return RQAMD_OK;
 }
 
 extern "C" int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,

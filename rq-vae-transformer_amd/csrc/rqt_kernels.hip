@@ -1273,6 +1273,15 @@ int rq_launch_sample(const SampleArgs& a, hipStream_t s) {
     RQ_LAUNCH(sample_kernel, dim3(a.rows), dim3(SMP_T), smem, s, b);
     return rq_check_launch("sample_kernel");
 }
+// one unfiltered multinomial draw per row of `logits` (rows x vocab, contiguous) -> out[row * out_stride]; used by the
+// stochastic soft codes of the quantiser (csrc/quantize.hip)
+int rq_launch_sample_rows(const float* logits, int rows, int vocab, uint64_t seed, uint64_t offset, int64_t* out, long out_stride, hipStream_t s) {
+    SampleArgs a{};
+    a.logits = logits; a.rows = rows; a.V = vocab; a.temperature = 1.0f; a.top_k = 0; a.top_p = -1.0f;
+    a.seed = seed; a.offset = offset; a.out = out; a.out_stride = out_stride; a.D = 1;
+    return rq_launch_sample(a, s);
+}
+
 extern "C" int rqamd_sample_logits(const float* logits, int rows, int vocab, float temperature, int top_k, float top_p,
                                    uint64_t seed, uint64_t offset, int64_t* samples_out, float* probs_out, int* row_flags, void* stream) {
     if (!logits || rows < 0) return rq_fail(RQAMD_ERR_INVALID, "sample_logits: bad argument");

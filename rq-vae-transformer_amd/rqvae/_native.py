@@ -38,6 +38,9 @@ _SIGS = {
     'rqamd_rq_quantize': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'rqamd_rq_code_norms': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_rq_soft_codes': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
+                                      C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
     'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_sample_logits': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
@@ -177,6 +180,21 @@ def rq_quantize(x, codebooks, want_quants=True, norms=None):
                                       _int_array([c.shape[0] for c in codebooks]), depth, n_vec, dim, ptr(codes), ptr(quants),
                                       ptr(ws), 0 if ws is None else ws.numel(), stream_of(x)))
     return codes, quants
+
+
+def rq_soft_codes(x, codebooks, norms, temp=1.0, stochastic=False, seed=0, offset=0):
+    """x (n_vec, dim) fp32 -> (soft codes (n_vec, depth, K) fp32, codes (n_vec, depth) int64): RQBottleneck.get_soft_codes."""
+    n_vec, dim = x.shape
+    depth, K = len(codebooks), codebooks[0].shape[0]
+    soft = torch.empty((n_vec, depth, K), dtype=torch.float32, device=x.device)
+    codes = torch.empty((n_vec, depth), dtype=torch.int64, device=x.device)
+    ws = torch.empty((max(n_vec, 1) * (dim * 4 + 512 + K * 4),), dtype=torch.uint8, device=x.device)
+    with on_device_of(x):
+        check(lib().rqamd_rq_soft_codes(ptr(x, torch.float32), _ptr_array(codebooks), _ptr_array(norms),
+                                        _int_array([c.shape[0] for c in codebooks]), depth, n_vec, dim, float(temp), int(bool(stochastic)),
+                                        int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(soft), ptr(codes), ptr(ws), ws.numel(),
+                                        stream_of(x)))
+    return soft, codes
 
 
 def rq_embed(codes, codebooks, mode):

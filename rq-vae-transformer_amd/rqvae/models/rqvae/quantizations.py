@@ -1,8 +1,8 @@
 """Residual quantiser: API mirror of rqvae/models/rqvae/quantizations.py of the reference
 (VQEmbedding :24-146, RQBottleneck :149-334, inference paths).  The nearest-codebook search, residual
 update and code->embedding lookups run in librqamd (csrc/quantize.hip); the EMA codebook update,
-dead-code restart and soft codes (:80-129,:371-400) are stage-1/stage-2 *training* code and are out of
-scope -- they raise NotImplementedError."""
+dead-code restart (:80-129) are stage-1 *training* code and out of scope -- they raise
+NotImplementedError; get_soft_codes (:371-400) runs natively."""
 from typing import Iterable
 
 import numpy as np
@@ -186,5 +186,15 @@ class RQBottleneck(nn.Module):
             raise NotImplementedError(f"{decode_type} is not implemented in partial decoding")
         return self.to_latent_shape(embeds)
 
+    @torch.no_grad()
     def get_soft_codes(self, x, temp=1.0, stochastic=False):
-        raise NotImplementedError('soft codes are RQ-Transformer training targets (quantizations.py:371-400): out of scope')
+        """quantizations.py:371-400 -> (soft_code (B,h,w,depth,K) fp32, code (B,h,w,depth) int64)"""
+        x = self.to_code_shape(x)
+        B, h, w, embed_dim = x.shape
+        flat = x.detach().reshape(-1, embed_dim).to(torch.float32).contiguous()
+        seed, offset = 0, 0
+        if stochastic:
+            from ..rqtransformer.transformers import RQTransformer
+            seed, offset = RQTransformer._draw_rng(x.device, 4 * len(self.codebooks))
+        soft, codes = _native.rq_soft_codes(flat, self.codebook_list(), self._norm_list(), temp, stochastic, seed, offset)
+        return soft.reshape(B, h, w, soft.shape[1], soft.shape[2]), codes.reshape(B, h, w, -1)

@@ -107,7 +107,10 @@ class RQVAE(Stage1Model):
 
     @torch.no_grad()
     def get_soft_codes(self, xs, temp=1.0, stochastic=False):
-        raise NotImplementedError('soft codes are RQ-Transformer training targets: out of scope')
+        """rqvae.py:97-103"""
+        assert hasattr(self.quantizer, 'get_soft_codes')
+        z_e = self.encode(xs)
+        return self.quantizer.get_soft_codes(z_e, temp=temp, stochastic=stochastic)
 
     @torch.no_grad()
     def decode_code(self, code):

@@ -110,6 +110,12 @@ def gen_rq():
             arrs.update(x=x, codebook=cb, quant_list=np.stack([q.numpy() for q in quant_list]),
                         embed_with_depth=embd.numpy())
         save(f'rq_{tag}.npz', **arrs)
+        if tag == 'small':      # soft codes: reference get_soft_codes on the first image, temp 2.0
+            soft, scode = rq.get_soft_codes(torch.from_numpy(x[:1]), temp=2.0, stochastic=False)
+            osoft, ocode = oracle.rq_soft_codes(x[:1], [cb] * 4, temp=2.0)
+            print(f'  rq[soft] oracle vs ref: soft codes {np.abs(osoft - soft.numpy()).max():.2e}, codes equal {(ocode == scode.numpy()).all()}')
+            assert torch.equal(scode, codes[:1])
+            save('rq_soft.npz', seed=seed, temp=np.float32(2.0), soft=soft.numpy().astype(np.float32), codes=scode.numpy().astype(np.int32))
 
 
 # ------------------------------------------------------------------ 2. sampler filters

@@ -83,6 +83,24 @@ def test_emu_rq_quantize_codebook_split(nat):
     assert none is None and torch.equal(c2, codes)
 
 
+def test_emu_rq_soft_codes(nat, golden):
+    """RQBottleneck.get_soft_codes against the reference fixture: softmax(-d / temp) per depth and codes."""
+    g, gs = golden('rq_small.npz'), golden('rq_soft.npz')
+    x, cb = T(g['x'][:1].reshape(-1, 64)), T(g['codebook'])
+    norms = nat.rq_code_norms(cb)
+    soft, codes = nat.rq_soft_codes(x, [cb] * 4, [norms] * 4, temp=float(gs['temp']))
+    assert np.array_equal(codes.numpy().reshape(gs['codes'].shape), gs['codes'])
+    ref = gs['soft'].reshape(-1, 4, 500)
+    assert np.abs(soft.numpy() - ref).max() < 2e-5 and np.abs(soft.numpy().sum(-1) - 1).max() < 1e-5
+    # stochastic codes: a draw from each depth's soft code -- must be a code with non-negligible probability; seeded
+    s1, c1 = nat.rq_soft_codes(x, [cb] * 4, [norms] * 4, temp=200.0, stochastic=True, seed=5, offset=8)
+    s2, c2 = nat.rq_soft_codes(x, [cb] * 4, [norms] * 4, temp=200.0, stochastic=True, seed=5, offset=8)
+    assert torch.equal(c1, c2) and torch.equal(s1, s2)
+    p = torch.gather(s1, 2, c1.unsqueeze(-1)).squeeze(-1)
+    assert float(p.min()) > 1e-5 and not torch.equal(c1, codes)          # flat distribution at temp 200: draws differ from the argmin
+    assert torch.equal(c1[:, 0] == codes[:, 0], c1[:, 0] == codes[:, 0])
+
+
 @pytest.mark.parametrize('case', [3, 5, 6])
 def test_emu_sampler_filter(nat, golden, case):
     g = golden('sampler.npz')

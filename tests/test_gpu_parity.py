@@ -100,6 +100,25 @@ def test_rq_quantize_properties_large(nat):
     assert torch.equal(q2[0], cb[:640])
 
 
+def test_rq_soft_codes_golden(nat, golden):
+    """get_soft_codes vs the reference fixture (K=500) and vs the oracle at the ImageNet codebook size (K=16384, D=256)."""
+    g, gs = golden('rq_small.npz'), golden('rq_soft.npz')
+    x, cb = G(g['x'][:1].reshape(-1, 64)), G(g['codebook'])
+    soft, codes = nat.rq_soft_codes(x, [cb] * 4, [nat.rq_code_norms(cb)] * 4, temp=float(gs['temp']))
+    assert np.array_equal(N(codes).reshape(gs['codes'].shape), gs['codes'])
+    assert np.abs(N(soft) - gs['soft'].reshape(-1, 4, 500)).max() < 2e-5
+    rng = np.random.default_rng(4)
+    cbf = rng.standard_normal((16384, 256), dtype=np.float32)
+    xf = rng.standard_normal((128, 256), dtype=np.float32)
+    soft, codes = nat.rq_soft_codes(G(xf), [G(cbf)] * 4, [nat.rq_code_norms(G(cbf))] * 4, temp=8.0)
+    osoft, ocodes = oracle.rq_soft_codes(xf, [cbf] * 4, temp=8.0)
+    assert np.array_equal(N(codes), ocodes) and np.abs(N(soft) - osoft).max() < 5e-5
+    qc, _ = nat.rq_quantize(G(xf), [G(cbf)] * 4, want_quants=False)
+    assert torch.equal(qc, codes)                                       # same codes as quantize()
+    s1, c1 = nat.rq_soft_codes(G(xf), [G(cbf)] * 4, [nat.rq_code_norms(G(cbf))] * 4, temp=8.0, stochastic=True, seed=1, offset=0)
+    assert float(torch.gather(s1, 2, c1.unsqueeze(-1)).min()) > 0.0
+
+
 # ------------------------------------------------------------------------------------------------ sampler
 def test_sampler_filters_golden(nat, golden):
     g = golden('sampler.npz')
