@@ -123,6 +123,11 @@ typedef struct {
     int vocab_size_cond, block_size_cond;
     int H, W, D;              /* block_size */
     int gelu_v2;              /* attentions.py:25-36: 0 = exact erf GELU ('v1'), 1 = x*sigmoid(1.702x) */
+    /* stage-2 flags (transformers.py:60-99; every released config sets all five): 0 selects the primitives.py variants --
+     * learned token embeddings (nn.Embedding / TupleEmbedding "tok_emb") instead of the RQ-VAE codebook through
+     * input_mlp / head_mlp, no depth cumsum in the head context, one classifier matrix per depth (BatchLinear) */
+    int input_emb_vqvae, head_emb_vqvae, shared_tok_emb, shared_cls_emb, cumsum_depth_ctx;
+    int vocab_sizes[8];       /* per-depth vocabulary (all equal to vocab_size unless shared_* are off); vocab_size = max */
 } rqamd_rqt_config;
 
 int rqamd_rqt_create(const rqamd_rqt_config* cfg, rqamd_rqt** out);

@@ -60,6 +60,21 @@ RQT_XWIDE = rqt(2560, 40, 2, 1, 16384)
 RQT_TXT32 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=32)
 RQT_TXT64 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=64)
 
+# Variants of the stage-2 flags that no released config uses (primitives.py: TupleEmbedding / BatchLinear / LogitMask):
+def _variant(base, **kw):
+    c = copy.deepcopy(base)
+    c.update(kw)
+    return c
+
+
+# learned per-depth token embeddings instead of the RQ-VAE codebook, per-depth classifiers, per-depth vocabulary sizes
+RQT_TINY_TUPLE = _variant(RQT_TINY, input_emb_vqvae=False, head_emb_vqvae=False, shared_tok_emb=False, shared_cls_emb=False,
+                          vocab_size=[500, 400, 300, 200])
+# codebook embeddings without the depth cumsum in the head context
+RQT_TINY_NOCUMSUM = _variant(RQT_TINY, cumsum_depth_ctx=False)
+# codebook embeddings into the body, one shared learned embedding into the head
+RQT_TINY_MIXED = _variant(RQT_TINY, head_emb_vqvae=False)
+
 PARAM_COUNTS_M = {  # BASELINE.md §2 / reference README.md:38-47
     'RQT_FFHQ_355M': 355.4, 'RQT_IN_480M': 480.9, 'RQT_IN_821M': 820.9,
     'RQT_IN_1400M': 1387.5, 'RQT_IN_3800M': 3822.5, 'RQT_CC3M_654M': 654.1,

@@ -57,6 +57,15 @@ class RQTransformerOracle:
         self.n_head_body = cfg['body']['block']['n_head']
         self.n_head_head = cfg['head']['block']['n_head']
         self.gelu = cfg.get('gelu', 'v1')
+        # variant flags (transformers.py:60-99): all True in every released config
+        self.input_vq = cfg.get('input_emb_vqvae', True)
+        self.head_vq = cfg.get('head_emb_vqvae', True)
+        self.cumsum = cfg.get('cumsum_depth_ctx', True)
+        self.shared_cls = cfg.get('shared_cls_emb', True)
+        self.shared_tok = cfg.get('shared_tok_emb', True)
+        vs = cfg['vocab_size']
+        self.vocab_sizes = [vs] * self.D if isinstance(vs, int) else list(vs)
+        self.V = max(self.vocab_sizes)
         self.init_cache()
 
     # ------------------------------------------------------------------ blocks
@@ -107,10 +116,30 @@ class RQTransformerOracle:
             x, cache[i] = self._block(f'{name}.blocks.{i}', x, n_head, cache[i], True)
         return x
 
-    def _classifier(self, x):
+    def _tok(self, xs):
+        """tok_emb(xs): nn.Embedding (shared) or TupleEmbedding (primitives.py:25-75: per-depth tables + offsets); (...,D) -> (...,D,E)"""
+        w = self.p['tok_emb.weight']
+        if self.shared_tok:
+            return w[xs]
+        offs = np.cumsum([0] + self.vocab_sizes[:-1])
+        return w[xs + offs]
+
+    def _classifier(self, x, depth=None):
+        """classifier (transformers.py:90-99,278-285): LayerNorm -> Linear, or BatchLinear (primitives.py:96-165: one
+        (E, Vmax) matrix per depth) -> LogitMask (-inf beyond each depth's vocabulary).  x (..., D, E), or (..., E) with
+        `depth` given (cached step)."""
         p = self.p
         h = layer_norm(x, p['classifier.layer_norm.weight'], p['classifier.layer_norm.bias'])
-        return linear(h, p['classifier.linear.weight'], p['classifier.linear.bias'])
+        if self.shared_cls:
+            return linear(h, p['classifier.linear.weight'], p['classifier.linear.bias'])
+        W, b = p['classifier.linear.weight'], p['classifier.linear.bias']          # (D, E, Vmax), (D, Vmax)
+        # LogitMask (primitives.py:78-93) indexes `logits[:, idx, vocab_size:]`, which on forward()'s (B,H,W,D,V) tensor slices
+        # the W axis beyond its end -- a no-op: the reference's teacher-forced logits are NOT masked (all Vmax columns stay
+        # finite).  In cached_forward the same indexing raises for depth > 0 when the sizes differ, so masked sampling is
+        # undefined upstream; this path masks columns >= vocab_size[depth] when sampling (see engine_rqt.hip).
+        if depth is None:
+            return np.einsum('...ie,iek->...ik', h.astype(np.float32), W) + b
+        return h.astype(np.float32) @ W[depth] + b[depth]
 
     # ------------------------------------------------------------------ forward
     def forward(self, xs, codebooks, cond=None, return_cond_logits=False):
@@ -124,15 +153,18 @@ class RQTransformerOracle:
             cond = np.zeros((B, self.block_size_cond), np.int64)
         cond = np.asarray(cond).reshape(B, self.block_size_cond)
         seq_len, cond_len = xs.shape[1], cond.shape[1]
-        emb = rq_embed_code_with_depth(xs, codebooks)                     # (B,T,D,Din)
-        xs_emb = linear(emb, p['input_mlp.weight'], p['input_mlp.bias'])  # :141
+        emb = rq_embed_code_with_depth(xs, codebooks) if (self.input_vq or self.head_vq) else None   # (B,T,D,Din)
+        xs_emb = linear(emb, p['input_mlp.weight'], p['input_mlp.bias']) if self.input_vq else self._tok(xs)  # :139-143
         conds_emb = p['cond_emb.weight'][cond] + p['pos_emb_cond'][:, :cond_len]
         xs_emb = xs_emb.sum(-2) + p['pos_emb_hw'][:, :seq_len]
         latents = np.concatenate([conds_emb, xs_emb[:, :-1]], 1)
         latents = self._stack('body_transformer', latents, self.nb, self.n_head_body)
         spatial_ctx = latents[:, cond_len - 1:]
-        depth_ctx = linear(np.cumsum(emb, -2, dtype=np.float32),
-                           p['head_mlp.weight'], p['head_mlp.bias'])      # :157-162
+        if self.head_vq:
+            depth_ctx = linear(np.cumsum(emb, -2, dtype=np.float32) if self.cumsum else emb,
+                               p['head_mlp.weight'], p['head_mlp.bias'])      # :157-162
+        else:
+            depth_ctx = self._tok(xs)                                         # :163-164
         full = np.concatenate([spatial_ctx.reshape(B, seq_len, 1, -1), depth_ctx[:, :, :-1]], -2)
         full = full.reshape(B * seq_len, D, -1) + p['pos_emb_d'][:, :D]
         out = self._stack('head_transformer', full, self.nh_layers, self.n_head_head)

@@ -131,10 +131,20 @@ def rqt_param_shapes(cfg):
     d['pos_emb_hw'] = (1, H * W, E)
     d['pos_emb_d'] = (1, D, E)
     d['cond_emb.weight'] = (vc, E)
-    d['input_mlp.weight'] = (E, cfg['input_embed_dim'])
-    d['input_mlp.bias'] = (E,)
-    d['head_mlp.weight'] = (E, cfg['input_embed_dim'])
-    d['head_mlp.bias'] = (E,)
+    vs = [V] * D if isinstance(V, int) else list(V)
+    in_vq, head_vq = cfg.get('input_emb_vqvae', True), cfg.get('head_emb_vqvae', True)
+    if in_vq:
+        d['input_mlp.weight'] = (E, cfg['input_embed_dim'])
+        d['input_mlp.bias'] = (E,)
+    if head_vq:
+        d['head_mlp.weight'] = (E, cfg['input_embed_dim'])
+        d['head_mlp.bias'] = (E,)
+    if not (in_vq and head_vq):                      # transformers.py:66-70
+        if cfg.get('shared_tok_emb', True):
+            d['tok_emb.weight'] = (vs[0], E)
+        else:
+            d['tok_emb.weight'] = (sum(vs), E)
+            d['tok_emb.offsets'] = (D,)              # registered buffer of TupleEmbedding (primitives.py:60-61)
     for stack, nl in (('body_transformer', cfg['body']['n_layer']),
                       ('head_transformer', cfg['head']['n_layer'])):
         for i in range(nl):
@@ -149,8 +159,12 @@ def rqt_param_shapes(cfg):
             d[f'{p}.mlp.2.weight'] = (E, 4 * E)
             d[f'{p}.mlp.2.bias'] = (E,)
     _norm(d, 'classifier.layer_norm', E)
-    d['classifier.linear.weight'] = (V, E)
-    d['classifier.linear.bias'] = (V,)
+    if cfg.get('shared_cls_emb', True):
+        d['classifier.linear.weight'] = (vs[0], E)
+        d['classifier.linear.bias'] = (vs[0],)
+    else:                                            # BatchLinear (primitives.py:96-125): (n_vectors, in, out)
+        d['classifier.linear.weight'] = (D, E, max(vs))
+        d['classifier.linear.bias'] = (D, max(vs))
     if cfg.get('block_size_cond', 0) > 1:
         _norm(d, 'cond_classifier.layer_norm', E)
         d['cond_classifier.linear.weight'] = (vc, E)
@@ -179,6 +193,10 @@ def make_tensor(name, shape, seed):
         if leaf == 'embed_ema':
             return r0.standard_normal(shape, dtype=np.float32)
         return np.zeros(shape, np.float32)                                     # cluster_size_ema
+    if name == 'tok_emb.offsets':
+        raise KeyError('tok_emb.offsets is derived from the vocabulary sizes, not drawn')
+    if name == 'tok_emb.weight':
+        return (0.5 * rng.standard_normal(shape)).astype(np.float32)
     if name.startswith('pos_emb'):
         return (0.02 * rng.standard_normal(shape)).astype(np.float32)
     if name == 'cond_emb.weight':
@@ -188,10 +206,17 @@ def make_tensor(name, shape, seed):
         return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
     if leaf == 'bias':
         return (0.05 * rng.standard_normal(shape)).astype(np.float32)
-    fan_in = int(np.prod(shape[1:]))
+    fan_in = int(np.prod(shape[1:])) if len(shape) != 3 else shape[1]      # BatchLinear weight is (n_vectors, in, out)
     b = 1.0 / np.sqrt(fan_in)
     return rng.uniform(-b, b, size=shape).astype(np.float32)
 
 
-def make_params(shapes, seed):
-    return OrderedDict((k, make_tensor(k, s, seed)) for k, s in shapes.items())
+def make_params(shapes, seed, cfg=None):
+    out = OrderedDict()
+    for k, s in shapes.items():
+        if k == 'tok_emb.offsets':
+            vs = cfg['vocab_size']
+            out[k] = np.cumsum([0] + list(vs)[:-1]).astype(np.int64)
+        else:
+            out[k] = make_tensor(k, s, seed)
+    return out

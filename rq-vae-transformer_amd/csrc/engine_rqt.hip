@@ -48,6 +48,10 @@ struct rqamd_rqt {
     float *b_ccls = nullptr, *ccls_lnw = nullptr, *ccls_lnb = nullptr;
     int n_ccls_seen = 0;
     float *cond_emb, *pos_cond, *pos_hw, *pos_d;
+    float* tok_emb = nullptr;      // learned token embeddings (variants with input_emb_vqvae / head_emb_vqvae off), fp32 [sum V][E]
+    int tok_offs[8] = {}, Vd[8] = {};
+    long tok_rows = 0;
+    bool in_vq = true, head_vq = true, shared_cls = true, cumsum = true;
     float *body_in_bias, *head_in_bias;   // [HW][E], [D][E] derived tables
     bool tables_dirty = true;
     std::vector<std::string> seen;
@@ -108,6 +112,22 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     size_t total = per_layer * (c->n_layer_body + c->n_layer_head) + 2 * al(E * Din * 2) + al(V * E * 2) + 4 * al(E * 4) + al(V * 4)
                    + al(vc * E * 4) + al(h->cond_len * E * 4) + 2 * al(h->HW * E * 4) + 2 * al(h->D * E * 4);
     if (h->cond_len > 1) total += al((size_t)vc * E * 2) + al((size_t)vc * 4) + 2 * al(E * 4);
+    // stage-2 flag variants (a struct zero-filled by an old caller means "all on", i.e. the released configuration)
+    const bool legacy = c->vocab_sizes[0] == 0;
+    h->in_vq = legacy || c->input_emb_vqvae; h->head_vq = legacy || c->head_emb_vqvae;
+    h->shared_cls = legacy || c->shared_cls_emb; h->cumsum = legacy || c->cumsum_depth_ctx;
+    for (int d = 0; d < c->D; ++d) {
+        h->Vd[d] = legacy ? c->vocab_size : c->vocab_sizes[d];
+        if (h->Vd[d] < 1 || h->Vd[d] > c->vocab_size) { delete h; return rq_fail(RQAMD_ERR_INVALID, "rqt_create: vocab_sizes[%d] = %d not in 1..vocab_size", d, h->Vd[d]); }
+    }
+    if (!(h->in_vq && h->head_vq)) {
+        const bool shared_tok = legacy || c->shared_tok_emb;
+        long rows = 0;
+        for (int d = 0; d < c->D; ++d) { h->tok_offs[d] = shared_tok ? 0 : (int)rows; rows += h->Vd[d]; }
+        h->tok_rows = shared_tok ? h->Vd[0] : rows;
+        total += al((size_t)h->tok_rows * E * 4);
+    }
+    if (!h->shared_cls) total += al((size_t)c->D * V * E * 2) + al((size_t)c->D * V * 4);
     if (h->arena.reserve(total) != RQAMD_OK) { delete h; return RQAMD_ERR_HIP; }
     char* p = (char*)h->arena.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
@@ -124,9 +144,11 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     };
     mk(h->body, c->n_layer_body);
     mk(h->head, c->n_layer_head);
-    h->w_in = (bf16_t*)take(E * Din * 2); h->w_headin = (bf16_t*)take(E * Din * 2); h->w_cls = (bf16_t*)take(V * E * 2);
+    h->w_in = (bf16_t*)take(E * Din * 2); h->w_headin = (bf16_t*)take(E * Din * 2);
+    h->w_cls = (bf16_t*)take((h->shared_cls ? 1 : (size_t)c->D) * V * E * 2);
     h->b_in = (float*)take(E * 4); h->b_headin = (float*)take(E * 4); h->cls_lnw = (float*)take(E * 4); h->cls_lnb = (float*)take(E * 4);
-    h->b_cls = (float*)take(V * 4);
+    h->b_cls = (float*)take((h->shared_cls ? 1 : (size_t)c->D) * V * 4);
+    if (h->tok_rows) h->tok_emb = (float*)take((size_t)h->tok_rows * E * 4);
     h->cond_emb = (float*)take(vc * E * 4); h->pos_cond = (float*)take(h->cond_len * E * 4);
     h->pos_hw = (float*)take(h->HW * E * 4); h->body_in_bias = (float*)take(h->HW * E * 4);
     h->pos_d = (float*)take(h->D * E * 4); h->head_in_bias = (float*)take(h->D * E * 4);
@@ -135,7 +157,8 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
         h->ccls_lnw = (float*)take(E * 4); h->ccls_lnb = (float*)take(E * 4);
     }
     h->n_required = 4 + 4 + 4 + 12 * 2 * 0;   // filled below
-    h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + 4 /*mlps*/ + 4 /*classifier*/ + (size_t)16 * (c->n_layer_body + c->n_layer_head);
+    h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + (h->in_vq ? 2 : 0) + (h->head_vq ? 2 : 0) + (h->tok_rows ? 1 : 0) + 4 /*classifier*/
+                    + (size_t)16 * (c->n_layer_body + c->n_layer_head);
     *out = h;
     return RQAMD_OK;
 }
@@ -180,14 +203,28 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
     else if (s == "pos_emb_hw") rc = f32copy(h->pos_hw, h->HW * E);
     else if (s == "pos_emb_d") rc = f32copy(h->pos_d, h->D * E);
     else if (s == "cond_emb.weight") rc = f32copy(h->cond_emb, vc * E);
+    else if ((s.rfind("input_mlp.", 0) == 0 && !h->in_vq) || (s.rfind("head_mlp.", 0) == 0 && !h->head_vq)) return RQAMD_OK;
     else if (s == "input_mlp.weight") rc = bf16copy(h->w_in, E * h->Din);
     else if (s == "input_mlp.bias") rc = f32copy(h->b_in, E);
     else if (s == "head_mlp.weight") rc = bf16copy(h->w_headin, E * h->Din);
     else if (s == "head_mlp.bias") rc = f32copy(h->b_headin, E);
     else if (s == "classifier.layer_norm.weight") rc = f32copy(h->cls_lnw, E);
     else if (s == "classifier.layer_norm.bias") rc = f32copy(h->cls_lnb, E);
-    else if (s == "classifier.linear.weight") rc = bf16copy(h->w_cls, (long)h->V * E);
-    else if (s == "classifier.linear.bias") rc = f32copy(h->b_cls, h->V);
+    else if (s == "classifier.linear.weight") {
+        if (h->shared_cls) rc = bf16copy(h->w_cls, (long)h->V * E);
+        else {      // BatchLinear (primitives.py:96-125): (depth, in = E, out = V) -> per depth [V][E] bf16
+            RQ_TRY(expect((long)h->D * E * h->V));
+            if (ndim != 3) return rq_fail(RQAMD_ERR_INVALID, "rqt_set_param(%s): BatchLinear weight must be (depth, in, out)", name);
+            for (int d = 0; d < h->D && rc == RQAMD_OK; ++d)
+                rc = rq_launch_cvt_bf16_transpose(src + (long)d * E * h->V, h->w_cls + (long)d * h->V * E, (int)E, h->V, st);
+        }
+    }
+    else if (s == "classifier.linear.bias") rc = f32copy(h->b_cls, (h->shared_cls ? 1 : (long)h->D) * h->V);
+    else if (s == "tok_emb.weight") {
+        if (!h->tok_rows) return RQAMD_OK;
+        rc = f32copy(h->tok_emb, h->tok_rows * E);
+    }
+    else if (s == "tok_emb.offsets") return RQAMD_OK;                  // derived from the vocabulary sizes
     else if (s.rfind("cond_classifier.", 0) == 0) {                    // forward()-only head (transformers.py:150-153)
         if (h->cond_len <= 1) return RQAMD_OK;
         if (s == "cond_classifier.layer_norm.weight") rc = f32copy(h->ccls_lnw, E);
@@ -389,15 +426,25 @@ static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, int
     return RQAMD_OK;
 }
 
-static int embed_gemm(rqamd_rqt* h, const StepCtx& c, int pos_off, int n_depth, const bf16_t* W, const float* bias_tab,
+static int embed_gemm(rqamd_rqt* h, const StepCtx& c, int pos_off, int depth_lo, int n_depth, const bf16_t* W, const float* bias_tab,
                       int bias_row_off, bool bias_by_pos, float* out, hipStream_t st) {
     EmbedTokArgs e{};
-    e.xs = h->xs; e.pos = h->st; e.pos_off = pos_off; e.n_depth = n_depth; e.rows = c.B; e.HW = h->HW; e.D = h->D; e.dim = h->Din;
+    e.xs = h->xs; e.pos = h->st; e.pos_off = pos_off; e.depth_lo = depth_lo; e.n_depth = n_depth; e.rows = c.B; e.HW = h->HW; e.D = h->D; e.dim = h->Din;
     e.out = h->ain;
-    for (int d = 0; d < h->D; ++d) { e.cb[d] = c.codebooks[d]; e.K[d] = h->V; }
+    for (int d = 0; d < h->D; ++d) { e.cb[d] = c.codebooks[d]; e.K[d] = h->Vd[d]; }
     RQ_TRY(rq_launch_embed_tokens(e, st));
     return step_gemm(h, h->ain, h->Din, W, c.B, h->E, h->Din, EPI_F32, bias_tab + (long)bias_row_off * h->E,
                      bias_by_pos ? h->st : nullptr, h->E, out, h->E, nullptr, st);
+}
+
+// learned token embeddings (tok_emb) summed over depths [d_lo, d_hi) of the codes at position *st + pos_off, + a positional row
+static int tok_embed(rqamd_rqt* h, const StepCtx& c, int pos_off, int d_lo, int d_hi, const float* add, bool add_by_pos, int add_row,
+                     float* out, hipStream_t st) {
+    TokEmbedArgs t{};
+    t.xs = h->xs; t.table = h->tok_emb; t.pos = h->st; t.pos_off = pos_off; t.d_lo = d_lo; t.d_hi = d_hi; t.add = add;
+    t.add_by_pos = add_by_pos ? 1 : 0; t.add_row = add_row; t.rows = c.B; t.HW = h->HW; t.D = h->D; t.E = h->E; t.out = out;
+    for (int d = 0; d < h->D; ++d) { t.offs[d] = h->tok_offs[d]; t.V[d] = h->Vd[d]; }
+    return rq_launch_tok_embed(t, st);
 }
 
 // everything that happens at one spatial position >= 1 (position read from h->st[0] on the device)
@@ -408,8 +455,9 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, h->cond_len - 1, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
                                     h->pos_cond, h->x, B, E, st));
     } else {
-        // token = sum_d input_mlp(e_d) + pos_emb_hw[pos-1]  (transformers.py:218-225)
-        RQ_TRY(embed_gemm(h, c, -1, h->D, h->w_in, h->body_in_bias, -1, true, h->x, st));
+        // token = sum_d input_mlp(e_d) + pos_emb_hw[pos-1]  (transformers.py:218-225), or sum_d tok_emb(code_d) + pos_emb_hw[pos-1]
+        if (h->in_vq) RQ_TRY(embed_gemm(h, c, -1, 0, h->D, h->w_in, h->body_in_bias, -1, true, h->x, st));
+        else RQ_TRY(tok_embed(h, c, -1, 0, h->D, h->pos_hw, true, -1, h->x, st));
     }
     // a captured graph serves every position of the same 8-key bucket: bound t by the bucket's last position
     RQ_TRY(body_stack(h, B, h->st, h->cond_len - 1, ((host_pos + h->cond_len - 1) | 7), pend, st));
@@ -425,8 +473,10 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
             // head token 0 = spatial context + pos_emb_d[0]; the context is body x + last fc2 (+bias)
             hp = pend; addvec = h->pos_d; x_in = h->x;
         } else {
-            // head token d = head_mlp(cumsum_{j<d} e_j) + pos_emb_d[d]  (transformers.py:249-267)
-            RQ_TRY(embed_gemm(h, c, 0, d, h->w_headin, h->head_in_bias, d, false, h->xh, st));
+            // head token d = head_mlp(cumsum_{j<d} e_j) + pos_emb_d[d]  (transformers.py:249-267); without cumsum_depth_ctx only
+            // e_{d-1}; with head_emb_vqvae off tok_emb(code_{d-1}) + pos_emb_d[d]
+            if (h->head_vq) RQ_TRY(embed_gemm(h, c, 0, h->cumsum ? 0 : d - 1, d, h->w_headin, h->head_in_bias, d, false, h->xh, st));
+            else RQ_TRY(tok_embed(h, c, 0, d - 1, d, h->pos_d, false, d, h->xh, st));
             hp = Pending{nullptr, 0, nullptr};
         }
         for (size_t li = 0; li < h->head.size(); ++li) {
@@ -437,8 +487,13 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         if (h->head.empty()) { r.x_in = x_in; r.addvec = addvec; }     // no head stack: the classifier sees the head token itself
         r.gamma = h->cls_lnw; r.beta = h->cls_lnb; r.y = h->y; r.rows = B; r.E = E; r.eps = 1e-5f;
         RQ_TRY(rq_launch_resid_ln(r, st));
-        RQ_TRY(step_gemm(h, h->y, E, h->w_cls, B, h->V, E, EPI_F32, h->b_cls, nullptr, 0, h->logits, h->V, nullptr, st));
+        // shared classifier, or BatchLinear's matrix of this depth
+        const long cls_off = h->shared_cls ? 0 : (long)d * h->V;
+        RQ_TRY(step_gemm(h, h->y, E, h->w_cls + cls_off * E, B, h->V, E, EPI_F32, h->b_cls + cls_off, nullptr, 0, h->logits, h->V, nullptr, st));
         if (c.sample) {
+            // LogitMask (primitives.py:78-93): codes beyond this depth's vocabulary cannot be drawn.  (The reference's teacher-
+            // forced logits are NOT masked -- its mask indexes the wrong axis there -- so rqamd_rqt_logits leaves them alone.)
+            if (h->Vd[d] < h->V) RQ_TRY(rq_launch_mask_logits(h->logits, B, h->V, h->Vd[d], st));
             SampleArgs s{};
             s.logits = h->logits; s.rows = B; s.V = h->V; s.temperature = c.temperature; s.top_k = c.top_k[d]; s.top_p = c.top_p[d];
             s.redo = h->smp_redo; s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;

@@ -55,7 +55,8 @@ struct EmbedTokArgs {
     int K[8];
     const int* pos;         // device-side spatial position
     int pos_off;            // position read = *pos + pos_off
-    int n_depth;            // sum over depths [0, n_depth)
+    int depth_lo;           // sum over depths [depth_lo, n_depth) (0: the depth cumsum; n_depth - 1: cumsum_depth_ctx off)
+    int n_depth;
     int rows, HW, D, dim;
     bf16_t* out;            // [rows][dim]
 };
@@ -86,6 +87,26 @@ int rq_launch_cond_embed_multi(const int64_t* cond, int cond_stride, int n_tok, 
 int rq_launch_cond_embed(const int64_t* cond, int cond_stride, int cond_idx, const float* cond_emb, int vocab_cond,
                          const float* pos_emb_cond, float* x, int rows, int E, hipStream_t s);
 int rq_launch_sample(const SampleArgs& a, hipStream_t s);
+// learned token embeddings (tok_emb: nn.Embedding, or TupleEmbedding = per-depth tables at row offsets offs[d], primitives.py:25-75):
+// x[b][:] = sum_{d in [d_lo, d_hi)} table[offs[d] + code[b][pos][d]][:] + add[row][:], row = (pos_dev ? *pos_dev : 0) + add_row
+struct TokEmbedArgs {
+    const int64_t* xs;      // [rows][HW][D] codes
+    const float* table;     // [sum V][E] fp32
+    int offs[8], V[8];
+    const int* pos;         // device-side spatial position (or null)
+    int pos_off;            // code position = *pos + pos_off
+    int d_lo, d_hi;
+    const float* add;       // [*][E] positional table
+    int add_by_pos;         // 1: row = *pos + add_row, 0: row = add_row
+    int add_row;
+    int rows, HW, D, E;
+    float* out;             // [rows][E] fp32
+};
+int rq_launch_tok_embed(const TokEmbedArgs& a, hipStream_t s);
+// logits[:, v_lo:V] = -inf (per-depth vocabularies smaller than the classifier's width)
+int rq_launch_mask_logits(float* logits, int rows, int V, int v_lo, hipStream_t s);
 int rq_launch_cvt_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
+// dst[c][r] = bf16(src[r][c]): BatchLinear's (in, out) matrices into the GEMM's K-contiguous weight layout
+int rq_launch_cvt_bf16_transpose(const float* src, bf16_t* dst, int R, int Cc, hipStream_t s);
 int rq_launch_set_int(int* p, int v, hipStream_t s);
 int rq_launch_add_int(int* p, int v, hipStream_t s);

@@ -565,7 +565,7 @@ __global__ void embed_tokens_kernel(EmbedTokArgs p) {
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int d = 0; d < p.n_depth; ++d) {
+    for (int d = p.depth_lo; d < p.n_depth; ++d) {
         long code = codes[d];
         if (code < 0 || code >= p.K[d]) continue;                  // padding row (index K) embeds to zero
         const float* src = p.cb[d] + code * p.dim + c * 8;
@@ -584,6 +584,41 @@ int rq_launch_embed_tokens(const EmbedTokArgs& a, hipStream_t s) {
     const long n = (long)a.rows * (a.dim / 8);
     RQ_LAUNCH(embed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return rq_check_launch("embed_tokens_kernel");
+}
+
+__global__ void tok_embed_kernel(TokEmbedArgs p) {
+    const int per_row = p.E / 4;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)p.rows * per_row) return;
+    const int b = (int)(gid / per_row), c = (int)(gid - (long)b * per_row);
+    const int pv = p.pos ? *p.pos : 0;
+    const int64_t* codes = p.xs + ((long)b * p.HW + pv + p.pos_off) * p.D;
+    const int arow = (p.add_by_pos ? pv : 0) + p.add_row;
+    f32x4 acc = *(const f32x4*)(p.add + (long)arow * p.E + c * 4);
+    for (int d = p.d_lo; d < p.d_hi; ++d) {
+        long code = codes[d];
+        if (code < 0 || code >= p.V[d]) rq_trap();          // index error in the reference (nn.Embedding)
+        acc = acc + *(const f32x4*)(p.table + ((long)p.offs[d] + code) * p.E + c * 4);
+    }
+    *(f32x4*)(p.out + (long)b * p.E + c * 4) = acc;
+}
+int rq_launch_tok_embed(const TokEmbedArgs& a, hipStream_t s) {
+    const long n = (long)a.rows * (a.E / 4);
+    RQ_LAUNCH(tok_embed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return rq_check_launch("tok_embed_kernel");
+}
+__global__ void mask_logits_kernel(float* logits, int rows, int V, int v_lo) {
+    const int w = V - v_lo;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)rows * w) return;
+    const int r = (int)(gid / w), c = (int)(gid - (long)r * w);
+    logits[(long)r * V + v_lo + c] = -__int_as_float(0x7f800000);
+}
+int rq_launch_mask_logits(float* logits, int rows, int V, int v_lo, hipStream_t s) {
+    if (v_lo >= V) return RQAMD_OK;
+    const long n = (long)rows * (V - v_lo);
+    RQ_LAUNCH(mask_logits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logits, rows, V, v_lo);
+    return rq_check_launch("mask_logits_kernel");
 }
 
 __global__ void cond_embed_kernel(const int64_t* cond, int cond_stride, int cond_idx, const float* cond_emb, int vocab_cond,
@@ -645,6 +680,17 @@ int rq_launch_cvt_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
     const long nt = (n + 3) / 4;
     RQ_LAUNCH(cvt_bf16_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, src, dst, n);
     return rq_check_launch("cvt_bf16_kernel");
+}
+__global__ void cvt_bf16_transpose_kernel(const float* src, bf16_t* dst, int R, int Cc) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)R * Cc) return;
+    const int c = (int)(gid / R), r = (int)(gid - (long)c * R);           // consecutive threads write consecutive dst elements
+    dst[gid] = f32_to_bf16(src[(long)r * Cc + c]);
+}
+int rq_launch_cvt_bf16_transpose(const float* src, bf16_t* dst, int R, int Cc, hipStream_t s) {
+    const long n = (long)R * Cc;
+    RQ_LAUNCH(cvt_bf16_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, R, Cc);
+    return rq_check_launch("cvt_bf16_transpose_kernel");
 }
 __global__ void set_int_kernel(int* p, int v) { if (threadIdx.x == 0) *p = v; }
 __global__ void add_int_kernel(int* p, int v) { if (threadIdx.x == 0) *p += v; }

@@ -29,7 +29,9 @@ class VaeConfig(C.Structure):
 class RqtConfig(C.Structure):
     _fields_ = [('embed_dim', C.c_int), ('n_head', C.c_int), ('n_layer_body', C.c_int), ('n_layer_head', C.c_int),
                 ('vocab_size', C.c_int), ('input_embed_dim', C.c_int), ('vocab_size_cond', C.c_int),
-                ('block_size_cond', C.c_int), ('H', C.c_int), ('W', C.c_int), ('D', C.c_int), ('gelu_v2', C.c_int)]
+                ('block_size_cond', C.c_int), ('H', C.c_int), ('W', C.c_int), ('D', C.c_int), ('gelu_v2', C.c_int),
+                ('input_emb_vqvae', C.c_int), ('head_emb_vqvae', C.c_int), ('shared_tok_emb', C.c_int), ('shared_cls_emb', C.c_int),
+                ('cumsum_depth_ctx', C.c_int), ('vocab_sizes', C.c_int * 8)]
 
 
 _SIGS = {
@@ -392,9 +394,14 @@ class RqtEngine(_Engine):
     _create, _destroy, _set = 'rqamd_rqt_create', 'rqamd_rqt_destroy', 'rqamd_rqt_set_param'
 
     def __init__(self, *, embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
-                 block_size_cond, block_size, gelu_v2=False, device='cuda'):
+                 block_size_cond, block_size, gelu_v2=False, device='cuda', input_emb_vqvae=True, head_emb_vqvae=True,
+                 shared_tok_emb=True, shared_cls_emb=True, cumsum_depth_ctx=True, vocab_sizes=None):
         c = RqtConfig(embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
-                      block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2))
+                      block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2), int(bool(input_emb_vqvae)),
+                      int(bool(head_emb_vqvae)), int(bool(shared_tok_emb)), int(bool(shared_cls_emb)), int(bool(cumsum_depth_ctx)))
+        vs = list(vocab_sizes) if vocab_sizes is not None else [vocab_size] * block_size[2]
+        for i, v in enumerate(vs[:8]):
+            c.vocab_sizes[i] = int(v)
         self.cfg = c
         super().__init__(c, device)
 
@@ -406,9 +413,10 @@ class RqtEngine(_Engine):
             raise ValueError(f'cond of shape {tuple(cond.shape)}; expected ({codes.shape[0]}, {max(c.block_size_cond, 1)})')
         if len(codebooks) < c.D:
             raise ValueError(f'{len(codebooks)} codebooks for depth {c.D}')
-        for cb in codebooks[:c.D]:
-            if cb.dim() != 2 or cb.shape[0] < c.vocab_size or cb.shape[1] != c.input_embed_dim:
-                raise ValueError(f'codebook of shape {tuple(cb.shape)}; expected (>= {c.vocab_size}, {c.input_embed_dim})')
+        if c.input_emb_vqvae or c.head_emb_vqvae:
+            for d, cb in enumerate(codebooks[:c.D]):
+                if cb.dim() != 2 or cb.shape[0] < c.vocab_sizes[d] or cb.shape[1] != c.input_embed_dim:
+                    raise ValueError(f'codebook of shape {tuple(cb.shape)}; expected (>= {c.vocab_sizes[d]}, {c.input_embed_dim})')
         self._on_my_device(codes, cond, *codebooks[:c.D])
 
     def sample(self, partial, cond, codebooks, start_loc, temperature, top_k, top_p, seed, offset, use_graph):

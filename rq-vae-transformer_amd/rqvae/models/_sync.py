@@ -16,8 +16,8 @@ def signature(module):
 def push_all(module, engine, skip_prefixes=()):
     with torch.no_grad():
         for k, v in module.state_dict(keep_vars=True).items():
-            if any(k.startswith(p) for p in skip_prefixes):
-                continue
+            if any(k.startswith(p) for p in skip_prefixes) or not v.is_floating_point():
+                continue                                  # integer buffers (TupleEmbedding.offsets) are derived from the config
             engine.set_param(k, v)
 
 

@@ -19,6 +19,7 @@ from .._sync import SideStream, push_all, signature
 from ..interfaces import Stage2Model
 from .attentions import AttentionStack
 from .configs import resolve
+from .primitives import BatchLinear, LogitMask, TupleEmbedding
 
 
 class _AttrView(dict):
@@ -47,18 +48,23 @@ class RQTransformer(Stage2Model):
             assert [cfg['vocab_size'][0]] * len(cfg['vocab_size']) == list(cfg['vocab_size'])
         self.config = _attr(cfg)
         self.vocab_size = list(cfg['vocab_size'])
-        if not (cfg['input_emb_vqvae'] and cfg['head_emb_vqvae'] and cfg['shared_cls_emb'] and cfg['cumsum_depth_ctx']):
-            # every released config sets these (configs/**/stage2/*.yaml:13-18); TupleEmbedding / BatchLinear
-            # variants (primitives.py) are not part of the accelerated path
-            raise NotImplementedError('RQTransformer without input_emb_vqvae/head_emb_vqvae/shared_cls_emb/cumsum_depth_ctx')
+        # every released config sets input_emb_vqvae / head_emb_vqvae / shared_cls_emb / cumsum_depth_ctx
+        # (configs/**/stage2/*.yaml:13-18); the other combinations (primitives.py) are supported by the engine as well
         E = cfg['embed_dim']
         self.vocab_size_cond = max(cfg['vocab_size_cond'], 1)
         self.block_size_cond = max(cfg['block_size_cond'], 1)
         assert not (self.block_size_cond > 1 and self.vocab_size_cond == 1)
         self.cond_emb = nn.Embedding(self.vocab_size_cond, E)
-        self.tok_emb = None
-        self.input_mlp = nn.Linear(cfg['input_embed_dim'], E)
-        self.head_mlp = nn.Linear(cfg['input_embed_dim'], E)
+        self.tok_emb, self.input_mlp, self.head_mlp = None, None, None          # transformers.py:60-70
+        if cfg['input_emb_vqvae']:
+            self.input_mlp = nn.Linear(cfg['input_embed_dim'], E)
+        if cfg['head_emb_vqvae']:
+            self.head_mlp = nn.Linear(cfg['input_embed_dim'], E)
+        if not (cfg['input_emb_vqvae'] and cfg['head_emb_vqvae']):
+            if cfg['shared_tok_emb']:
+                self.tok_emb = nn.Embedding(cfg['vocab_size'][0], E)
+            else:
+                self.tok_emb = TupleEmbedding(cfg['vocab_size'], E)
         self.pos_emb_cond = nn.Parameter(torch.zeros(1, self.block_size_cond, E))
         self.pos_emb_hw = nn.Parameter(torch.zeros(1, self.block_size[0] * self.block_size[1], E))
         self.pos_emb_d = nn.Parameter(torch.zeros(1, self.block_size[2], E))
@@ -70,7 +76,9 @@ class RQTransformer(Stage2Model):
         self.head_transformer = AttentionStack(cfg['head'])
         self.classifier = nn.Sequential(OrderedDict([
             ('layer_norm', nn.LayerNorm(E)),
-            ('linear', nn.Linear(E, cfg['vocab_size'][0])),
+            ('linear', nn.Linear(E, cfg['vocab_size'][0]) if cfg['shared_cls_emb']
+             else BatchLinear(cfg['block_size'][2], E, max(cfg['vocab_size']))),
+            ('logit_mask', LogitMask(cfg['vocab_size'], value=-1e6)),
         ]))
         if cfg['block_size_cond'] > 1:
             self.cond_classifier = nn.Sequential(OrderedDict([
@@ -98,9 +106,11 @@ class RQTransformer(Stage2Model):
                     raise NotImplementedError('different head counts in body and head')
                 self._engine = _native.RqtEngine(
                     embed_dim=c.embed_dim, n_head=c.body.block.n_head, n_layer_body=c.body.n_layer, n_layer_head=c.head.n_layer,
-                    vocab_size=self.vocab_size[0], input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
+                    vocab_size=max(self.vocab_size), input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
                     block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=c.body.block.gelu == 'v2',
-                    device=self.pos_emb_hw.device)
+                    device=self.pos_emb_hw.device, input_emb_vqvae=c.input_emb_vqvae, head_emb_vqvae=c.head_emb_vqvae,
+                    shared_tok_emb=c.shared_tok_emb, shared_cls_emb=c.shared_cls_emb, cumsum_depth_ctx=c.cumsum_depth_ctx,
+                    vocab_sizes=self.vocab_size)
             push_all(self, self._engine)
             self._engine_sig = sig
         return self._engine
@@ -116,8 +126,10 @@ class RQTransformer(Stage2Model):
     def _checked_codebooks(self, model_aux):
         """the engine gathers rows `code` < vocab_size of width input_embed_dim from these tables: anything else would read
         out of bounds, so the shapes are checked here (the reference would fail in F.embedding / input_mlp)"""
-        cbs = self._codebooks(model_aux)
         D = self.block_size[2]
+        if not (self.config.input_emb_vqvae or self.config.head_emb_vqvae):
+            return [self.tok_emb.weight.detach()] * D      # learned embeddings only: model_aux is not consulted (placeholders)
+        cbs = self._codebooks(model_aux)
         if len(cbs) < D:
             raise ValueError(f'model_aux has {len(cbs)} codebooks, the transformer needs {D}')
         for d in range(D):

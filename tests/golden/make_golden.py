@@ -69,7 +69,7 @@ def ref_rqt(cfg, seed):
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     mine = oracle.rqt_param_shapes(cfg)
     assert shapes == {k: tuple(v) for k, v in mine.items()}, 'rqt key/shape table mismatch'
-    params = oracle.make_params(mine, seed)
+    params = oracle.make_params(mine, seed, cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
     return m, params
 
@@ -276,6 +276,27 @@ def gen_rqt_big(only=None):
         del m, params
 
 
+def gen_rqt_variants():
+    """Stage-2 flag variants that no released config uses (TupleEmbedding / BatchLinear / LogitMask, primitives.py:25-165;
+    cumsum_depth_ctx off; shared learned head embedding): reference forward() logits on the tiny shape."""
+    hps, dd = C.VAE_TINY
+    vae, vparams = ref_rqvae(hps, dd, seed=31)
+    cb = vparams['quantizer.codebooks.0.weight'][:-1]
+    for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED)):
+        m, params = ref_rqt(cfg, seed=47)
+        H, W, D = cfg['block_size']
+        vs = cfg['vocab_size'] if isinstance(cfg['vocab_size'], list) else [cfg['vocab_size']] * D
+        rng = np.random.default_rng(48)
+        codes = np.stack([rng.integers(0, v, (2, H, W)) for v in vs], -1)
+        cond = rng.integers(0, cfg['vocab_size_cond'], (2, 1))
+        logits = m(torch.from_numpy(codes), vae, cond=torch.from_numpy(cond)).numpy()
+        ol = oracle.RQTransformerOracle(cfg, params).forward(codes, [cb] * D, cond)
+        fin = np.isfinite(logits)
+        assert np.array_equal(fin, np.isfinite(ol))
+        print(f'  rqt[{tag}] oracle forward vs ref: {np.abs(ol[fin] - logits[fin]).max():.2e}; -inf entries {int((~fin).sum())}')
+        save(f'rqt_var_{tag}.npz', seed=47, vae_seed=31, codes=codes.astype(np.int32), cond=cond.astype(np.int32), logits=logits)
+
+
 def gen_param_counts():
     counts = {}
     for name in C.PARAM_COUNTS_M:
@@ -292,11 +313,11 @@ def gen_param_counts():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'counts']
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'rqt_var', 'counts']
     for w in which:
         print(f'[{w}]')
         if w.startswith('rqt_big:'):                      # e.g. rqt_big:txt32,txt64
             gen_rqt_big(w.split(':', 1)[1].split(','))
             continue
-        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big,
+        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
          'counts': gen_param_counts}[w]()

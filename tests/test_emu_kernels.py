@@ -237,6 +237,30 @@ def test_emu_rqt_long_prefix(nat):
     assert e1 < 0.06 and e2 < 0.06
 
 
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed'])
+def test_emu_rqt_flag_variants(nat, golden, tag):
+    """primitives.py variants (TupleEmbedding + BatchLinear + per-depth vocabularies; cumsum_depth_ctx off; learned head
+    embedding) through the mirror classes and the engine, against the reference's forward() logits."""
+    from rqvae.models.rqtransformer import RQTransformer
+    from rqvae.models.rqvae import RQVAE
+    g = golden(f'rqt_var_{tag}.npz')
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED}[tag]
+    hps, dd = C.VAE_TINY
+    vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
+    vae.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed'])).items()})
+    ar = RQTransformer(cfg).eval()
+    ar.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']), cfg).items()}, strict=True)
+    codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
+    logits = ar(codes, vae if tag != 'tuple' else None, cond=cond).numpy()
+    err = np.abs(logits - g['logits'])
+    print(f'emu rqt variant {tag}: max err {err.max():.4f} mean {err.mean():.5f}')
+    assert err.max() < 0.06 and err.mean() < 0.01
+    ar.use_graph = False
+    out = ar.sample(torch.zeros_like(codes), vae if tag != 'tuple' else None, cond=cond, top_k=50, top_p=0.9)
+    vs = ar.vocab_size
+    assert all(int(out[..., d].max()) < vs[d] and int(out[..., d].min()) >= 0 for d in range(4))      # LogitMask: never beyond a depth's vocabulary
+
+
 def test_emu_rqt_depth1_no_head_stack(nat):
     """head.n_layer = 0 with depth-1 codes: the "VQ-GAN" transformer shapes of the throughput script
     (measure_throughput/__main__.py:166-210); the classifier reads the body output + pos_emb_d directly."""

@@ -323,6 +323,31 @@ def test_rqt_text_conditioned(nat, golden):
     assert torch.equal(a, b) and int(a.max()) < 500
 
 
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed'])
+def test_rqt_flag_variants(nat, golden, tag):
+    """primitives.py variants (TupleEmbedding / BatchLinear / LogitMask, cumsum_depth_ctx off, learned head embedding):
+    teacher-forced logits vs the reference's forward(), sampling inside each depth's vocabulary, graph == eager."""
+    g = golden(f'rqt_var_{tag}.npz')
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED}[tag]
+    vae, _, _, _ = _models(C.VAE_TINY, None, int(g['vae_seed']), 0)
+    from rqvae.models.rqtransformer import RQTransformer
+    ar = RQTransformer(cfg)
+    ar.load_state_dict({k: torch.from_numpy(v) for k, v in oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']), cfg).items()}, strict=True)
+    ar = ar.to(DEV).eval()
+    aux = vae if tag != 'tuple' else None
+    codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    err = np.abs(N(ar(codes, aux, cond=cond)) - g['logits'])
+    print(f'rqt variant {tag}: logits max err {err.max():.4f} mean {err.mean():.5f}')
+    assert err.max() < 0.06 and err.mean() < 0.01
+    res = []
+    for graph in (True, False):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(9)
+        res.append(ar.sample(torch.zeros_like(codes), aux, cond=cond, top_k=100, top_p=0.95))
+    assert torch.equal(res[0], res[1])
+    assert all(int(res[0][..., d].max()) < ar.vocab_size[d] for d in range(4))
+
+
 def test_rqt_batch_invariance(nat, golden):
     """rows are independent: logits of a row do not depend on which batch it sits in (tile placement)."""
     g = golden('rqt_tiny.npz')
