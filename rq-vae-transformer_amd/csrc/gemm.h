@@ -1015,6 +1015,113 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0);
 }
 
+// -------------------------------------------------------------------------------------------------
+// Skinny GEMM for the small-batch decode steps (M <= 64 rows: BASELINE configs[3]'s per-GPU share of 64 images):
+// out[M, N] = x[M, K] . W[N, K]^T is one pass over W at HBM speed with almost no arithmetic, and what bounded the tiled
+// kernels there was the 24-step K chain of a workgroup (barrier + LDS round trip per step: 10 us for 14 MB of weights).
+// Here nothing goes through LDS until the end: a workgroup owns 32 weight rows, its EIGHT wavefronts each take one eighth of
+// the K range (in-workgroup split-K), every wavefront issues ALL its loads up front -- W fragments straight from HBM (each
+// lane 64 contiguous bytes of one row per 64-wide step; a lane pair covers a full 128-byte line), x fragments from L2 (x is
+// <= 200 KB) -- runs its MFMAs (transposed tile D[n][m]), and the eight partial tiles are summed through LDS by all 512
+// threads, which apply bias / GELU and write row-contiguous 8- or 16-byte pieces.  The k-order inside an MFMA is permuted
+// identically for both operands (lane group g of step s feeds k = 32 g + 8 i .. + 7 to k-step i), which a dot product ignores.
+// blockIdx.z = global split-K slice (fp32 partial slabs, residual-producing GEMMs only).  Needs (K / splitk) % 512 == 0.
+template <int UNUSED = 0>      // (a template only so that the header may be included by several translation units)
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs p) {
+    constexpr int CH = 3;                         // 64-wide steps loaded per batch (36 x 16 bytes per lane in flight)
+    RQ_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rq_uniform(tid >> 6);
+    const int n0 = blockIdx.x * 32;
+    const int Kz = p.K / p.splitk, Kw = Kz >> 3;          // K range of this workgroup / of one wavefront
+    const int kbeg = blockIdx.z * Kz + wave * Kw;
+    const int steps = Kw >> 6;
+    const int fr = lane & 31, kg = lane >> 5;
+    int n = n0 + fr;
+    n = n < p.N - 1 ? n : p.N - 1;
+    int m_a = fr < p.M - 1 ? fr : p.M - 1, m_b = fr + 32 < p.M - 1 ? fr + 32 : p.M - 1;
+    const char* wp = (const char*)p.W + ((size_t)n * p.K + kbeg + kg * 32) * 2;
+    const char* xa = (const char*)p.A + ((size_t)m_a * p.lda + kbeg + kg * 32) * 2;
+    const char* xb = (const char*)p.A + ((size_t)m_b * p.lda + kbeg + kg * 32) * 2;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int s0 = 0; s0 < steps; s0 += CH) {
+        rq_u128 wf[CH][4], xf0[CH][4], xf1[CH][4];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int so = (s0 + s < steps ? s0 + s : steps - 1) * 128;          // past the end: reload the last step (not used)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[s][i] = ld128(wp + so + i * 16);
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int so = (s0 + s < steps ? s0 + s : steps - 1) * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xf0[s][i] = ld128(xa + so + i * 16); xf1[s][i] = ld128(xb + so + i * 16); }
+        }
+        rq_sched_barrier();          // every load of the batch is in flight before the first MFMA waits for one (memory-level
+                                     // parallelism, not instruction order, is what this kernel lives on)
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (s0 + s < steps) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = rq_mfma_32x32x16_bf16(as_bf16x8(wf[s][i]), as_bf16x8(xf0[s][i]), acc0);
+                    acc1 = rq_mfma_32x32x16_bf16(as_bf16x8(wf[s][i]), as_bf16x8(xf1[s][i]), acc1);
+                }
+            }
+        }
+    }
+    // ---- partial tiles -> LDS [wave][m 64][n 32 (+4 pad)] fp32.  C/D map of the transposed tile: column = lane & 31 = m,
+    // rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = n: four groups of four consecutive n per lane
+    constexpr int LDP = 36;
+    float* sP = (float*)smem;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int nl = 8 * g + 4 * kg;
+        *(f32x4*)(sP + ((wave * 64 + fr) * LDP + nl)) = (f32x4){acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+        *(f32x4*)(sP + ((wave * 64 + 32 + fr) * LDP + nl)) = (f32x4){acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+    }
+    rq_syncthreads();
+    const int m = tid >> 3, nq = (tid & 7) * 4;
+    f32x4 v = *(const f32x4*)(sP + (m * LDP + nq));
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v = v + *(const f32x4*)(sP + ((w * 64 + m) * LDP + nq));
+    const int nn = n0 + nq;
+    if (m >= p.M || nn >= p.N) return;
+    const int epi = p.epi;
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const bool full4 = nn + 3 < p.N && (p.ldo & 3) == 0;
+    if (bias && epi != EPI_F32_PARTIAL) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (nn + e < p.N) v[e] += bias[nn + e];
+    }
+    if (epi == EPI_BF16_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+    }
+    if (epi <= EPI_BF16_RESID) {
+        bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + nn;
+        if (epi == EPI_BF16_RESID) {
+            for (int e = 0; e < 4 && nn + e < p.N; ++e) v[e] += bf16_to_f32(p.resid[(long)m * p.ldr + nn + e]);
+        }
+        if (full4) {
+            struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
+            w2.a = pack_bf16x2(v[0], v[1]);
+            w2.b = pack_bf16x2(v[2], v[3]);
+            *(u64*)o = w2;
+        } else {
+            for (int e = 0; e < 4 && nn + e < p.N; ++e) o[e] = f32_to_bf16(v[e]);
+        }
+    } else {
+        float* o = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + nn;
+        if (full4) *(f32x4*)o = v;
+        else for (int e = 0; e < 4 && nn + e < p.N; ++e) o[e] = v[e];
+    }
+}
+
 // host-side launcher (gemm.hip)
 int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 // picks (BM, BN, splitk) for a weight-streaming decode GEMM; returns splitk actually used via args

@@ -130,6 +130,16 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     }
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
+    if (bm == 64 && bn == 32) {       // skinny kernel (M <= 64): 32 weight rows per workgroup, in-workgroup split-K over 8 wavefronts
+        if (a.conv || a.M > 64 || a.K % a.splitk != 0 || (a.K / a.splitk) % 512 != 0)
+            return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm skinny: dense operands, M <= 64 and (K / splitk) %% 512 == 0 needed");
+        const size_t smem = (size_t)8 * 64 * 36 * 4;
+        static RqDeviceOnce attr_once;
+        if (attr_once.first())
+            (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        RQ_LAUNCH(gemm_skinny_kernel<0>, dim3((a.N + 31) / 32, 1, a.splitk), dim3(512), smem, stream, a);
+        return rq_check_launch("gemm_skinny_kernel");
+    }
     if (bm == 256 && bn == 256) {     // eight-phase kernel
         const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
         if (a.conv || ktiles < 2 || (a.K / 64) % a.splitk != 0)
@@ -180,6 +190,16 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     static const bool no_glds = getenv("RQAMD_NO_GLDS") != nullptr;
     static const bool no_p8 = getenv("RQAMD_NO_P8") != nullptr;        // A/B switch
     if (glds) *glds = 0;
+    // skinny kernel (gemm_skinny_kernel): M <= 64 rows, one pass over W with every load in flight at once.  Residual-producing
+    // GEMMs with a long K split it over blockIdx.z until ~192 workgroups exist (fc2: K = 6144 -> 4 x 1536).
+    static const bool no_skinny = getenv("RQAMD_NO_SKINNY") != nullptr;      // A/B switch
+    if (!no_skinny && M_rows <= 64 && K % 512 == 0 && N >= 256) {
+        int sk = 1;
+        if (allow_splitk)
+            while (sk < 8 && (long)((N + 31) / 32) * sk < 160 && (K / (sk * 2)) % 512 == 0) sk *= 2;
+        *bm = 64; *bn = 32; *splitk = sk;
+        return;
+    }
     // 256 x 256 eight-phase kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how well the tile count fills
     // rounds of 256 CUs.  From the interleaved A/B on MI355X (profiles/r02_gemm_p8_ab.txt): it wins whenever the last round is
     // >= ~85 % full or there are >= 4 rounds; residual-producing GEMMs may split K to reach ~192-256 workgroups (M = 4096 fc2:

@@ -377,6 +377,24 @@ def test_emu_gemm_256x256_eight_phase(nat):
             a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
 
 
+def test_emu_gemm_skinny(nat):
+    """M <= 64 skinny kernel: k-permuted operand fragments, in-workgroup split-K over eight wavefronts, LDS reduction, global
+    split-K slabs, ragged M / N, every epilogue family."""
+    rng = np.random.default_rng(19)
+    for (M, N, K) in ((64, 96, 512), (37, 70, 1024), (1, 64, 512)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+        out = nat.dbg_gemm(a, w, bias, epi=3, bm=64, bn=32, splitk=1).numpy()
+        assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
+        out = nat.dbg_gemm(a, w, bias, epi=0, bm=64, bn=32, splitk=1).float().numpy()
+        assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max(), (M, N, K)
+        if K >= 1024:
+            out = nat.dbg_gemm(a, w, None, epi=4, bm=64, bn=32, splitk=2).numpy().sum(0)
+            assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
+
+
 def test_emu_conv_halo(nat):
     """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual;
     against the oracle's conv2d / silu on the bf16-rounded operands."""
