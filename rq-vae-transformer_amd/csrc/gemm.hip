@@ -190,14 +190,14 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     static const bool no_glds = getenv("RQAMD_NO_GLDS") != nullptr;
     static const bool no_p8 = getenv("RQAMD_NO_P8") != nullptr;        // A/B switch
     if (glds) *glds = 0;
-    // skinny kernel (gemm_skinny_kernel): M <= 64 rows, one pass over W with every load in flight at once.  Residual-producing
-    // GEMMs with a long K split it over blockIdx.z until ~192 workgroups exist (fc2: K = 6144 -> 4 x 1536).
+    // skinny kernel (gemm_skinny_kernel): one pass over W with every load in flight at once.  Measured against the tiled kernels
+    // with rotating weights (profiles/r02_gemm_skinny_ab.txt): it wins only for the bf16-output GEMMs at <= 32 rows (M = 8: qkv
+    // 7.8 vs 10.2 us, fc1 7.9 vs 13.6; M = 32: 8.8 vs 10.5, 9.4 vs 12.6) and ties or loses elsewhere (M = 64: qkv 11.2 vs 11.0;
+    // split-K slab GEMMs 11.1 vs 7.8) -- at this size a launch is ~7 us of fixed cost around 2-3 us of streaming, whatever the
+    // kernel, so the small-batch regime stays launch-latency bound.
     static const bool no_skinny = getenv("RQAMD_NO_SKINNY") != nullptr;      // A/B switch
-    if (!no_skinny && M_rows <= 64 && K % 512 == 0 && N >= 256) {
-        int sk = 1;
-        if (allow_splitk)
-            while (sk < 8 && (long)((N + 31) / 32) * sk < 160 && (K / (sk * 2)) % 512 == 0) sk *= 2;
-        *bm = 64; *bn = 32; *splitk = sk;
+    if (!no_skinny && !allow_splitk && (long)M_rows * g_rq_row_scale <= 32 && K % 512 == 0 && N >= 256 && N < 16384) {
+        *bm = 64; *bn = 32; *splitk = 1;
         return;
     }
     // 256 x 256 eight-phase kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how well the tile count fills
