@@ -88,13 +88,31 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+GATHER_BUDGET_BYTES = 16 << 30
+
+
+def gather_pixels(distenv, pixels):
+    """main_sampling_fid.py:226: every rank receives all ranks' pixels, rank-major (rqvae.utils.dist.all_gather_cat = one
+    RCCL all_gather_into_tensor).  At the bench batch the gathered fp32 tensor is world x 8.4 GB -- next to a 180 GB KV cache
+    it does not fit 288 GB for world = 8 -- so above GATHER_BUDGET_BYTES the same collective runs over slices of the local batch
+    (same bytes over xGMI, same rank-major order per slice) and each gathered slice is released before the next."""
+    from rqvae.utils.dist import all_gather_cat
+    per_img = pixels[0].numel() * pixels.element_size()
+    if distenv.world_size * pixels.shape[0] * per_img <= GATHER_BUDGET_BYTES:
+        return all_gather_cat(distenv, pixels)
+    step = max(1, GATHER_BUDGET_BYTES // (distenv.world_size * per_img))
+    last = None
+    for s0 in range(0, pixels.shape[0], step):
+        last = all_gather_cat(distenv, pixels[s0:s0 + step])
+    return last
+
+
 def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=top_k, top_p=top_p)
     pixels = vae.decode_code(codes)
-    pixels.mul_(0.5).add_(0.5).clamp_(0, 1)             # in place: 6.4 GB per temporary at B = 8192
+    pixels.mul_(0.5).add_(0.5).clamp_(0, 1)             # in place: 8.4 GB per temporary at B = 10752
     if distenv is not None and distenv.world_size > 1:
-        from rqvae.utils.dist import all_gather_cat
-        pixels = all_gather_cat(distenv, pixels)
+        pixels = gather_pixels(distenv, pixels)
     return codes, pixels
 
 
@@ -362,8 +380,7 @@ def main(argv=None):
                     pixels = vae.decode_code(prev[0])
                     pixels.mul_(0.5).add_(0.5).clamp_(0, 1)
                     if distenv is not None:
-                        from rqvae.utils.dist import all_gather_cat
-                        pixels = all_gather_cat(distenv, pixels)
+                        pixels = gather_pixels(distenv, pixels)
                     pixels.record_stream(s_dec)
                     del pixels
             prev = cur
@@ -375,8 +392,7 @@ def main(argv=None):
         pixels = vae.decode_code(codes)
         pixels.mul_(0.5).add_(0.5).clamp_(0, 1)
         if distenv is not None:
-            from rqvae.utils.dist import all_gather_cat
-            pixels = all_gather_cat(distenv, pixels)
+            pixels = gather_pixels(distenv, pixels)
         ev[2].record()
         ev[2].synchronize()
         t_ar += ev[0].elapsed_time(ev[1])
