@@ -954,7 +954,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         rq_sched_barrier();
         rq_wait_lgkmcnt<0>();
         rq_sched_barrier();            // keeps the register-only MFMAs below the wait (hipcc hoists them past inline-asm waits)
-        rq_setprio(1);
+        if (!(p.dbg & 32)) rq_setprio(1);      // (dbg bit 5: A/B without the priority raise)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll

@@ -290,8 +290,9 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
     int flags = 0, glds = 0;
+    if (epi >= 256) { flags |= 32; epi -= 256; }              // epi + 256: eight-phase kernel without s_setprio (A/B)
     if (epi >= 64) { glds = epi / 32; epi -= glds * 32; }      // epi + 32 * stages: LDS-DMA operand staging (2 or 3 stages)
-    if (epi >= 16) { flags = 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
+    if (epi >= 16) { flags |= 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
     a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags; a.glds = glds;
