@@ -427,6 +427,372 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 }
 
 // -------------------------------------------------------------------------------------------------
+// Persistent form of the 8-row kernel above (round 2).  A tile is short (20-27 us) and its phases are serial inside the
+// one workgroup a CU holds: first loads of the patch / weights (~2.5 us of exposed latency), 18 taps, epilogue (~4.4 us,
+// most of it waiting for the stores to be accepted before the workgroup may retire and the next one may start).  Here a
+// workgroup stays on its CU and walks every 32nd slot of its XCD's band of tiles; during the LAST chunk of a tile it stages
+// the NEXT tile's first patch (into the other patch buffer) and weight tiles exactly as it stages the next chunk inside a
+// tile, so that the next tile's first tap follows the epilogue with no load in between, and the epilogue's global stores
+// drain while that tile's MFMAs run (nothing waits for them until a younger load is needed, two taps later).
+// LDS (all 160 KB): [ W0 W1 | P0 | spare | P1 ].  The epilogue tile (68 KB) must not touch the buffer that already holds the
+// next tile's patch: it lies over the OTHER patch buffer and the spare region next to it (P0 + spare, or spare + P1).
+constexpr int PK_SMEM = 160 * 1024;
+constexpr int PK_PATCH = (HT_H + 2) * HP_W * 128;                  // 43 520
+constexpr int PK_P0 = 2 * HW_BYTES;                                // 32 768
+constexpr int PK_P1 = PK_SMEM - PK_PATCH;                          // 120 320
+constexpr int PK_PSTRIDE = PK_P1 - PK_P0;
+constexpr int PK_LDR = H_BN * 2 + 16;
+constexpr int PK_TILE = HT_H * HT_W * PK_LDR;                      // 69 632
+constexpr int PK_RED = 8 * 16 * 4 * 4;                             // statistics scratch behind the tile
+static_assert(PK_P0 + PK_PATCH + PK_TILE + PK_RED <= PK_SMEM, "epilogue tile over spare + P1");
+static_assert(PK_P0 + PK_TILE + PK_RED <= PK_P1, "epilogue tile over P0 + spare");
+
+struct HaloTile { int img, ty0, tx0, n0, trem; };
+
+template <int FUSE_GN, int UPS>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p, int wpx) {
+    constexpr int TH = HT_H, NTH = 512, RPW = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3;
+    static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
+    constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
+    constexpr int HP_N = PW * PH;
+    constexpr int H_IT = (HP_N * 8 + NTH - 1) / NTH;
+    constexpr int RTAP = 5;                         // tap of the last chunk at which the residual tile is fetched
+    RQ_DYN_SMEM(smem);
+    char* sW = (char*)smem;                         // [2][HW_BYTES]
+    char* sH = (char*)smem + PK_P0;                 // patch buffer b at b * PK_PSTRIDE
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- this workgroup's tiles: slots w, w + wpx, ... of its XCD's contiguous band (neighbours share halo rows in that L2)
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
+    const int n_mt = p.B * tiles_y * tiles_x;
+    const int xcd = blockIdx.x & 7, w0 = blockIdx.x >> 3;
+    const int per = (n_mt + 7) >> 3, nslot = per * NT;
+    auto slot_ok = [&](int s) { return s < nslot && xcd * per + s / NT < n_mt; };
+    auto decode = [&](int s) {
+        HaloTile t;
+        const int mtile = xcd * per + s / NT;
+        t.n0 = (s - (s / NT) * NT) * H_BN;
+        t.img = mtile / (tiles_y * tiles_x);
+        t.trem = mtile - t.img * (tiles_y * tiles_x);
+        t.ty0 = (t.trem / tiles_x) * TH;
+        t.tx0 = (t.trem - (t.trem / tiles_x) * tiles_x) * HT_W;
+        return t;
+    };
+    int slot = w0;
+    if (!slot_ok(slot)) return;
+
+    // ---- staging state: the tile whose patch is being loaded (the current tile, or the next one during the last chunk)
+    unsigned hd[H_IT];
+    unsigned x_img = 0;
+    const float* gn = nullptr;
+    const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;
+    auto set_staging = [&](const HaloTile& t) {
+        int tid_s = tid;                            // opaque: keeps the tile-independent half of this out of loop-carried registers
+        asm volatile("" : "+v"(tid_s));
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            const int q = tid_s + NTH * it;
+            const int hp = q >> 3, c8 = q & 7;
+            const bool in = hp < HP_N;
+            const int hy = hp / PW, hx = hp - hy * PW;
+            const int gy = (UPS ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS ? t.tx0 >> 1 : t.tx0) + hx - 1;
+            const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
+            const unsigned loff16 = in ? halo_lds_off<PW>(hy, hx, c8) >> 4 : 0u;
+            hd[it] = (unsigned)(cy * Ws + cx) | (loff16 << 16) | (ok ? 1u << 29 : 0u) | (in ? 1u << 30 : 0u);
+        }
+        x_img = (unsigned)((long)t.img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);
+        if (FUSE_GN) gn = p.gn + (long)t.img * p.Cin * 2;
+    };
+    const unsigned cin2 = (unsigned)p.Cin * 2u;
+    auto h_in = [&](int it) { return (hd[it] >> 30) & 1u; };
+    auto h_ok = [&](int it) { return (hd[it] >> 29) & 1u; };
+    auto h_loff = [&](int it) { return ((hd[it] >> 16) & 0x1fffu) << 4; };
+    auto h_goff = [&](int it) { return x_img + (hd[it] & 0xffffu) * cin2; };
+    const int w_row = tid >> 3, w_c8 = tid & 7;
+    unsigned w_goff[W_IT], w_loff[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int r = w_row + (NTH / 8) * i;
+        w_goff[i] = (unsigned)(((long)r * 9 * p.Cin + w_c8 * 8) * 2);
+        w_loff[i] = (unsigned)(r * 128 + ((w_c8 ^ ((r >> 1) & 7)) << 4));
+    }
+    const unsigned w_per_n = 9u * (unsigned)p.Cin * 2u;            // bytes per output channel
+    const char* gX = (const char*)p.x;
+    const char* gWt = (const char*)p.w;
+
+    f32x4 gs[4];
+    auto load_halo = [&](int c, rq_u128* rh) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u));
+        if (FUSE_GN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
+        }
+    };
+    auto halo_piece_value = [&](const rq_u128* rh, int it) -> rq_u128 {
+        rq_u128 v = rh[it];
+        if (FUSE_GN) {
+            float f[8];
+            f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+            f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+            f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+            f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x4 ss = gs[e >> 1];
+                const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
+                f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
+                f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+            }
+            v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
+            v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
+        }
+        if (!h_ok(it)) v = zero128();
+        return v;
+    };
+    auto load_w = [&](unsigned nbase, int c, int tap, rq_u128* rw) {
+        const unsigned kb = nbase + (unsigned)(tap * p.Cin + c * 64) * 2u;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
+    };
+    auto store_w = [&](int buf, const rq_u128* rw) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) st128(sW + buf * HW_BYTES + w_loff[i], rw[i]);
+    };
+
+    const int ftx = lane & 31, fk = lane >> 5;
+    const unsigned rd_w0 = (unsigned)((wn * 64 + ftx) * 128 + ((fk ^ ((ftx >> 1) & 7)) << 4));
+    unsigned rd_h0[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
+
+    f32x16 acc[RPW][2];
+    auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
+        const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * PK_PSTRIDE);
+        const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[RPW], bfr[2];
+            const char* hb = sH + (ha ^ (unsigned)(ks << 5));
+            const char* wb = sW + (wa ^ (unsigned)(ks << 5));
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);
+        }
+    };
+
+    const int NC = p.Cin / 64, last_c = NC - 1;
+    rq_u128 rh[H_IT], rw[W_SETS][W_IT];
+    constexpr int CPR = H_BN / 8;
+    constexpr int R_IT = TPX * CPR / NTH;          // 8
+    rq_u128 rr[R_IT];
+
+    // ---- first tile: the only exposed prologue
+    HaloTile cur = decode(slot), nxt = cur;
+    bool has_next = slot_ok(slot + wpx);
+    if (has_next) nxt = decode(slot + wpx);
+    unsigned wn_cur = (unsigned)cur.n0 * w_per_n, wn_nxt = (unsigned)nxt.n0 * w_per_n;
+    set_staging(cur);
+    load_halo(0, rh);
+    // weight units run on across tiles: unit (c, tap) of the tile, then (0, 0..) of the next one; always set tap % 3
+    auto load_unit = [&](int c, int tap, rq_u128* r) {
+        unsigned nb = wn_cur;
+        if (tap >= 9) { tap -= 9; ++c; }
+        if (c > last_c) {
+            if (has_next) { c = 0; nb = wn_nxt; }
+            else { c = last_c; tap = 8; }           // past the end of this workgroup's work: harmless reload
+        }
+        load_w(nb, c, tap, r);
+    };
+#pragma unroll
+    for (int u = 0; u < W_SETS; ++u) load_unit(0, u, rw[u]);
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it)
+        if (h_in(it)) st128(sH + h_loff(it), halo_piece_value(rh, it));
+    store_w(0, rw[0]);
+    rq_syncthreads();
+    int wbuf = 0, hbuf = 0;
+
+    int tid_o = tid;                               // opaque per-tile copy of the thread index (see the tile loop)
+    auto run_chunk = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // the last chunk stages the next tile's first patch; with no next tile the descriptors are cleared ("piece does not
+        // exist"), so that the staging code below stays branch-free inside the MFMA scheduling regions
+        if (LAST) {
+            if (has_next) set_staging(nxt);
+            else {
+#pragma unroll
+                for (int it = 0; it < H_IT; ++it) hd[it] = 0u;
+            }
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
+            if (tap == 0) load_halo(LAST ? 0 : c + 1, rh);
+            if (LAST && tap == RTAP && p.resid) {
+#pragma unroll
+                for (int k = 0; k < R_IT; ++k) {
+                    const int cidx = tid_o + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+                    const int ty = ml / HT_W, tx = ml - ty * HT_W;
+                    const long pix = ((long)cur.img * p.H + cur.ty0 + ty) * p.W + cur.tx0 + tx;
+                    rr[k] = ld128(p.resid + pix * p.Cout + cur.n0 + nl);
+                }
+            }
+            rq_sched_barrier();
+            constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
+            const bool ptap = tap >= FIRST;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int it = (tap - FIRST) * PPT + k;
+                if (ptap && it < H_IT) rh[it < H_IT ? it : 0] = halo_piece_value(rh, it < H_IT ? it : 0);
+            }
+            compute(hbuf, wbuf, ky, kx);
+            if (FUSE_GN && ptap) {
+#pragma unroll
+                for (int g = 0; g < 8 * RPW; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
+            }
+            store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int it = (tap - FIRST) * PPT + k;
+                if (!(ptap && it < H_IT)) continue;
+                if (h_in(it)) st128(sH + (hbuf ^ 1) * PK_PSTRIDE + h_loff(it), rh[it]);
+            }
+            rq_syncthreads();
+            wbuf ^= 1;
+        }
+        hbuf ^= 1;
+    };
+
+    for (;;) {
+        // the epilogue's addressing is the same for every tile; recomputed from an opaque copy of the thread index each
+        // round, or the compiler hoists ~100 registers of loop-invariant offsets across the main loop (and spills them)
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
+        run_chunk(NC - 1, std::true_type{});
+
+        // ---- epilogue of `cur` (hbuf now names the buffer holding the next tile's patch: keep clear of it)
+        char* sT = (char*)smem + PK_P0 + (hbuf == 0 ? PK_PATCH : 0);
+        const int lane_o = tid_o & 63, wave_o = tid_o >> 6, wm_o = wave_o >> 1, wn_o = wave_o & 1;
+        float* sred = (float*)(sT + PK_TILE);       // [8][16][4]
+        if (p.resid) {
+#pragma unroll
+            for (int k = 0; k < R_IT; ++k) {
+                const int cidx = tid_o + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+                st128(sT + ml * PK_LDR + nl * 2, rr[k]);
+            }
+            rq_syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int ty = wm_o * RPW + i, tx = lane_o & 31;
+            const int ml = ty * HT_W + tx;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn_o * 64 + j * 32 + 8 * q + 4 * (lane_o >> 5);
+                    const f32x4 bv = *(const f32x4*)(p.bias + cur.n0 + nl);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
+                    if (p.resid) {
+                        const uint32_t* rp = (const uint32_t*)(sT + ml * PK_LDR + nl * 2);
+                        const uint32_t r0 = rp[0], r1 = rp[1];
+                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                    }
+                    struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
+                    w2.a = pack_bf16x2(v[0], v[1]);
+                    w2.b = pack_bf16x2(v[2], v[3]);
+                    *(u64*)(sT + ml * PK_LDR + nl * 2) = w2;
+                }
+            }
+        }
+        rq_syncthreads();
+        float gs_[8], gq_[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
+#pragma unroll 4
+        for (int cidx = tid_o; cidx < TPX * CPR; cidx += NTH) {
+            const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+            const int ty = ml / HT_W, tx = ml - ty * HT_W;
+            const long pix = ((long)cur.img * p.H + cur.ty0 + ty) * p.W + cur.tx0 + tx;
+            const rq_u128 u = ld128(sT + ml * PK_LDR + nl * 2);
+            st128(p.out + pix * p.Cout + cur.n0 + nl, u);
+            if (p.stats) {
+                float f[8];
+                f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+                f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+                f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+                f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { gs_[e] += f[e]; gq_[e] = fmaf(f[e], f[e], gq_[e]); }
+            }
+        }
+        if (p.stats) {                              // uniform; same reduction as conv3x3_halo_kernel
+            const int gsz = p.Cout / 32;
+            float a0, q0, a1, q1;
+            if (gsz == 4) {
+                a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]); q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
+                a1 = (gs_[4] + gs_[5]) + (gs_[6] + gs_[7]); q1 = (gq_[4] + gq_[5]) + (gq_[6] + gq_[7]);
+            } else {
+                a0 = ((gs_[0] + gs_[1]) + (gs_[2] + gs_[3])) + ((gs_[4] + gs_[5]) + (gs_[6] + gs_[7]));
+                q0 = ((gq_[0] + gq_[1]) + (gq_[2] + gq_[3])) + ((gq_[4] + gq_[5]) + (gq_[6] + gq_[7]));
+                a1 = 0.f; q1 = 0.f;
+            }
+            a0 += rq_shfl_xor(a0, 16); q0 += rq_shfl_xor(q0, 16); a1 += rq_shfl_xor(a1, 16); q1 += rq_shfl_xor(q1, 16);
+            a0 += rq_shfl_xor(a0, 32); q0 += rq_shfl_xor(q0, 32); a1 += rq_shfl_xor(a1, 32); q1 += rq_shfl_xor(q1, 32);
+            if (lane_o < 16) {
+                float* o = sred + (wave_o * 16 + lane_o) * 4;
+                o[0] = a0; o[1] = q0; o[2] = a1; o[3] = q1;
+            }
+            rq_syncthreads();
+            if (wave_o == 0) {
+                const int chunk = (lane_o >> 1) & 15, pair = lane_o & 1;
+                float a = 0.f, q = 0.f;
+#pragma unroll
+                for (int w = 0; w < NTH / 64; ++w) { a += sred[(w * 16 + chunk) * 4 + pair * 2]; q += sred[(w * 16 + chunk) * 4 + pair * 2 + 1]; }
+                if (gsz == 16) {
+                    a += rq_shfl_xor(a, 2);
+                    q += rq_shfl_xor(q, 2);
+                }
+                const bool writer = gsz == 4 ? true : (gsz == 8 ? pair == 0 : (pair == 0 && (chunk & 1) == 0));
+                if (writer && lane_o < 32) {
+                    const int g = (cur.n0 + chunk * 8 + pair * 4) / gsz;
+                    const int tiles = tiles_x * tiles_y;
+                    float* o = p.stats + (((long)cur.img * tiles + cur.trem) * 32 + g) * 2;
+                    o[0] = a;
+                    o[1] = q;
+                }
+            }
+        }
+        // ---- next tile: its first patch and weight tile are already in LDS, units 1, 2 wait in their register sets
+        if (!has_next) break;
+        slot += wpx;
+        cur = nxt;
+        wn_cur = wn_nxt;
+        has_next = slot_ok(slot + wpx);
+        if (has_next) { nxt = decode(slot + wpx); wn_nxt = (unsigned)nxt.n0 * w_per_n; }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // Decoder.conv_out (modules.py:165-169 of the reference): Cin -> Cout <= 4 at full resolution, writes the NCHW
 // fp32 image.  Same halo idea, but the whole problem of a tile lives in LDS at once: a 4 x 32 pixel tile's
 // (4+2) x (32+2) patch of ALL input channels (52 KB at Cin = 128) plus every tap of the (bf16) weights, so there
@@ -759,6 +1125,12 @@ bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
 
 int rq_conv_halo_stat_tiles(int H, int W) { return (H / halo_th()) * (W / HT_W); }
 static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a tile height
+static int g_conv_halo_dbg_pk = 0;          // diagnostics entry only: +1 / -1 force the persistent / per-tile form of the 8-row kernel
+static int g_conv_halo_dbg_wpx = 0;         // diagnostics entry only: workgroups per XCD of the persistent form
+static bool halo_persistent() {
+    static const int env = getenv("RQAMD_HALO_PERSIST") ? atoi(getenv("RQAMD_HALO_PERSIST")) : 1;
+    return g_conv_halo_dbg_pk ? g_conv_halo_dbg_pk > 0 : env != 0;
+}
 
 template <int TH>
 static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
@@ -774,6 +1146,28 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
+    if (TH == 8 && halo_persistent()) {
+        // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
+        static RqDeviceOnce pk_once;
+        static int cus_per_xcd[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (pk_once.first()) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+            cus_per_xcd[dev & 15] = cus / 8;
+        }
+        const int slots = ((n_mt + 7) / 8) * NT;
+        int wpx = g_conv_halo_dbg_wpx > 0 ? g_conv_halo_dbg_wpx : cus_per_xcd[dev & 15];
+        if (wpx > slots) wpx = slots;
+        if (ups) RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 1>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        else if (a.gn) RQ_LAUNCH((conv3x3_halo_pk_kernel<1, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        else RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        return rq_check_launch("conv3x3_halo_pk_kernel");
+    }
     if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
     else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
     else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
@@ -806,9 +1200,13 @@ extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const floa
                                         int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
     g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : (ups & 8) ? 16 : 0;      // ups bits 1 / 2 / 3: force the 8- / 4- / 16-row tile variant
+    g_conv_halo_dbg_pk = (ups & 16) ? 1 : (ups & 32) ? -1 : 0;                    // bits 4 / 5: persistent / per-tile form of the 8-row kernel
+    g_conv_halo_dbg_wpx = (ups >> 8) & 0xff;                                      // bits 8..15: workgroups per XCD (0 = one per CU)
     const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
                                        Cin, Cout, ups & 1, (hipStream_t)stream);
     g_conv_halo_dbg_th = 0;
+    g_conv_halo_dbg_pk = 0;
+    g_conv_halo_dbg_wpx = 0;
     return rc;
 }
 

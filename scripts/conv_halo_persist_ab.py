@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""A/B of the persistent form of the 8-row halo conv against the per-tile form (interleaved repetitions, bitwise equality)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
+import torch
+from rqvae import _native
+
+dev = 'cuda'
+
+
+def timed(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def ab(fa, fb, reps=8, rounds=5):
+    fa(); fb()
+    ta, tb = [], []
+    for _ in range(rounds):
+        ta.append(timed(fa, reps)); tb.append(timed(fb, reps))
+    return min(ta), min(tb)
+
+
+shapes = ((8, 256, 128, 128, 0), (32, 256, 128, 128, 0), (8, 128, 128, 128, 0), (8, 128, 256, 128, 0), (8, 64, 256, 256, 0), (32, 64, 256, 256, 0),
+          (8, 128, 256, 256, 0), (8, 256, 128, 128, 1), (8, 128, 256, 256, 1))
+for B, H, Cin, Cout, ups in shapes:
+    Hs = H // 2 if ups else H
+    x = torch.randn((B, Hs, Hs, Cin), device=dev).to(torch.bfloat16)
+    w = (torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05).to(torch.bfloat16)
+    bias = torch.randn((Cout,), device=dev)
+    resid = torch.randn((B, H, H, Cout), device=dev).to(torch.bfloat16)
+    gn = torch.stack([1 + 0.2 * torch.randn((B, Cin), device=dev), 0.3 * torch.randn((B, Cin), device=dev)], -1).contiguous()
+    nt = (H // 8) * (H // 32)
+    fl = 2.0 * B * H * H * Cout * 9 * Cin / 1e6
+    o_a, o_b = torch.empty_like(resid), torch.empty_like(resid)
+    s_a, s_b = torch.zeros((B, nt, 32, 2), device=dev), torch.zeros((B, nt, 32, 2), device=dev)
+    line = f'B{B} {Cin}->{Cout}@{H}{" ups" if ups else ""}:'
+    cases = (('plain', {}),) if ups else (('plain', {}), ('GN+resid+stats', dict(gn=gn, resid=resid, st=True)), ('GN+stats', dict(gn=gn, st=True)),
+                                         ('resid', dict(resid=resid)))
+    for name, kw in cases:
+        st = kw.pop('st', False)
+        fa = lambda: _native.dbg_conv_halo(x, w, bias, out=o_a, stats=s_a if st else None, ups=bool(ups), tile_h=8, persistent=False, **kw)
+        fb = lambda: _native.dbg_conv_halo(x, w, bias, out=o_b, stats=s_b if st else None, ups=bool(ups), tile_h=8, persistent=True, **kw)
+        ta, tb = ab(fa, fb)
+        same = torch.equal(o_a, o_b) and (not st or torch.equal(s_a, s_b))
+        # race screen: repeated launches of the persistent form must be bitwise stable
+        ref = o_b.clone()
+        stable = True
+        for _ in range(6):
+            fb()
+            stable = stable and torch.equal(ref, o_b)
+        line += f' | {name}: {ta:7.1f} -> {tb:7.1f} us ({fl / ta:5.0f} -> {fl / tb:5.0f} TF) {"same" if same else "DIFF"}{"" if stable else " UNSTABLE"}'
+    print(line, flush=True)

@@ -282,6 +282,8 @@ static inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
 static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 template <typename F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return 0; }
+#define hipDeviceAttributeMultiprocessorCount 63
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }

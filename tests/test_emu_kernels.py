@@ -434,6 +434,45 @@ def test_emu_conv_halo(nat):
         assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), th
 
 
+def test_emu_conv_halo_persistent(nat):
+    """persistent form of the 8-row halo conv: a workgroup walks several tiles, staging the next tile's patch / weights during
+    the last chunk of the current one (cross-tile prefetch, epilogue tile placed clear of the staged patch).  One, three and
+    "one per CU" workgroups per XCD; two channel chunks, two cout tiles (the weight base switches between consecutive slots);
+    must equal the per-tile kernel bit for bit."""
+    rng = np.random.default_rng(14)
+
+    def bf(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+    for (B, H, W, Cin, Cout) in ((1, 64, 64, 64, 128), (2, 64, 32, 128, 256)):
+        x = bf(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+        w = bf((0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+        bias = T(rng.standard_normal(Cout).astype(np.float32))
+        resid = bf(rng.standard_normal((B, H, W, Cout)).astype(np.float32))
+        gn = T(np.stack([1.0 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], -1).astype(np.float32))
+        nt = (H // 8) * (W // 32)
+        ref_plain = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=False)
+        st_ref = torch.zeros((B, nt, 32, 2), dtype=torch.float32)
+        ref_fused = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st_ref, tile_h=8, persistent=False)
+        for wpx in (1, 3, 0):
+            out = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=True, wpx=wpx)
+            assert torch.equal(out, ref_plain), (Cin, Cout, wpx)
+            st = torch.zeros_like(st_ref)
+            out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st, tile_h=8, persistent=True, wpx=wpx)
+            assert torch.equal(out, ref_fused), (Cin, Cout, wpx)
+            assert torch.equal(st, st_ref), (Cin, Cout, wpx)
+        # no residual, no statistics through the fused kernel (conv1 of a ResnetBlock)
+        a = nat.dbg_conv_halo(x, w, bias, gn=gn, tile_h=8, persistent=False)
+        b = nat.dbg_conv_halo(x, w, bias, gn=gn, tile_h=8, persistent=True, wpx=1)
+        assert torch.equal(a, b)
+    xs = bf(rng.standard_normal((1, 32, 32, 128)).astype(np.float32))
+    w = bf((0.05 * rng.standard_normal((128, 3, 3, 128))).astype(np.float32))
+    bias = T(rng.standard_normal(128).astype(np.float32))
+    a = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=False)
+    for wpx in (1, 0):
+        b = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=True, wpx=wpx)
+        assert torch.equal(a, b), wpx
+
+
 def test_emu_conv_in_mfma(nat):
     """Encoder.conv_in as an MFMA kernel: NCHW fp32 image -> NHWC bf16, K = 27 padded to 32, image borders."""
     from oracle.vae import conv2d
