@@ -6,6 +6,7 @@
 #   bench [args]     python bench.py  (RQ_BENCH_ARGS="--steps 2 ..." for arguments)
 #   trace            rocprofv3 --kernel-trace --stats of one bench step -> <TAG>_kernel_stats.md
 #   pmc              FETCH_SIZE / WRITE_SIZE of the decode GEMM shapes at RQ_M rows (separate passes) -> <TAG>_gemm_traffic_m<M>.json
+#   sqpmc            SQ counters (three passes) of "$RQ_PMC_CMD", kernels matching $RQ_PMC_FILTER -> <TAG>_sqpmc.txt
 #   gemm             scripts/gemm_bench.py (RQ_MS=4096,8192 ...)
 #   cmd              run "$RQ_CMD"
 export TMPDIR=/tmp
@@ -54,6 +55,20 @@ pmc)
   cd $R; grep algorithmic gpurun_out/pmc_FETCH_SIZE.log
   python scripts/summarize_traffic.py $M gpurun_out/${TAG}_gemm_traffic_m$M.json
   rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE ;;
+sqpmc)
+  # SQ counters of "$RQ_PMC_CMD" (kernels matching $RQ_PMC_FILTER), two passes -> <TAG>_sqpmc.txt
+  cd /tmp; : > $R/gpurun_out/${TAG}_sqpmc.txt
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+             "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU" \
+             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
+    i=$((i+1))
+    timeout 600 rocprofv3 --pmc $set --kernel-trace -d $R/gpurun_out/sqpmc_$i -o pmc --output-format csv -- $RQ_PMC_CMD > $R/gpurun_out/sqpmc_$i.log 2>&1
+    echo "pass $i exit $?"
+    python $R/scripts/pmc_summary.py $R/gpurun_out/sqpmc_$i "${RQ_PMC_FILTER:-gemm}" >> $R/gpurun_out/${TAG}_sqpmc.txt
+    rm -rf $R/gpurun_out/sqpmc_$i
+  done
+  cd $R; cat gpurun_out/${TAG}_sqpmc.txt ;;
 gemm)
   timeout 900 python scripts/gemm_bench.py > gpurun_out/${TAG}_gemm_bench.txt 2>&1; cat gpurun_out/${TAG}_gemm_bench.txt ;;
 cmd)
