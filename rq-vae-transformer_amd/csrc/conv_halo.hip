@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;
     auto set_staging = [&](const HaloTile& t) {
         int tid_s = tid;                            // opaque: keeps the tile-independent half of this out of loop-carried registers
-        asm volatile("" : "+v"(tid_s));
+        rq_opaque(tid_s);
 #pragma unroll
         for (int it = 0; it < H_IT; ++it) {
             const int q = tid_s + NTH * it;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     for (;;) {
         // the epilogue's addressing is the same for every tile; recomputed from an opaque copy of the thread index each
         // round, or the compiler hoists ~100 registers of loop-invariant offsets across the main loop (and spills them)
-        asm volatile("" : "+v"(tid_o));
+        rq_opaque(tid_o);
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
@@ -1135,9 +1135,14 @@ static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a t
 static int g_conv_halo_dbg_pk = 0;          // diagnostics entry only: +1 / -1 force the persistent / per-tile form of the 8-row kernel
 static int g_conv_halo_dbg_w4 = 0;          // diagnostics entry only: +1 four-wavefront form of the 16-row tile
 static int g_conv_halo_dbg_wpx = 0;         // diagnostics entry only: workgroups per XCD of the persistent form
-static bool halo_persistent() {
-    static const int env = getenv("RQAMD_HALO_PERSIST") ? atoi(getenv("RQAMD_HALO_PERSIST")) : 1;
-    return g_conv_halo_dbg_pk ? g_conv_halo_dbg_pk > 0 : env != 0;
+// Measured (profiles/r02_conv_halo_variants.txt): the persistent form gains 4-7 % where the tile is short and carries no fused
+// GroupNorm (the upsample convs), nothing or -3 % on the fused ResnetBlock convs (their epilogue is bound by store ISSUE, which
+// blocks the issuing wavefront whether or not a next tile waits behind it) -- so by default only the upsample convs use it.
+// RQAMD_HALO_PERSIST=1 / 0: every / no 8-row conv.
+static bool halo_persistent(int ups) {
+    static const int env = getenv("RQAMD_HALO_PERSIST") ? atoi(getenv("RQAMD_HALO_PERSIST")) : -1;
+    if (g_conv_halo_dbg_pk) return g_conv_halo_dbg_pk > 0;
+    return env < 0 ? ups != 0 : env != 0;
 }
 
 template <int TH, int W4 = 0>
@@ -1154,7 +1159,7 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (TH == 8 && halo_persistent()) {
+    if (TH == 8 && halo_persistent(ups)) {
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
         static int cus_per_xcd[16];

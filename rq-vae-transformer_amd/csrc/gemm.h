@@ -59,16 +59,45 @@ struct GemmArgs {
 };
 
 // GELU of the transformer MLP (attentions.py:17-22 of the reference): v1 = x * Phi(x), v2 = x * sigmoid(1.702 x).
-// Phi through erfc's rational form (Abramowitz & Stegun 7.1.26, |error| < 1.5e-7, no cancellation in the negative
-// tail): one v_rcp + one v_exp + 9 FMAs instead of libm erff's ~36 instructions -- the fc1 epilogue applies it to
-// 25 M elements per launch with no MFMA running.  The result is rounded to bf16 (2^-9) right after.
+// Phi(x) = (1 + erf(x / sqrt 2)) / 2 with erf(z) = z * P(z^2), P of degree 8 fitted on |z| <= 3 (|error| < 1.7e-5; beyond,
+// z * P(z^2) grows monotonically past 1 and is clamped, |1 - erf| < 2.3e-5 there): |GELU error| < 5e-5 absolute, against
+// 2^-9 relative for the bf16 rounding that follows.  No transcendental, and every step is an fma / mul that exists in packed
+// form (v_pk_fma_f32, two elements per issue slot): the fc1 epilogue applies it to 66 M elements per launch with no MFMA
+// running, where the previous form (Abramowitz-Stegun 7.1.26: v_rcp + v_exp + 12 VALU per element) cost as much as the
+// stores (9.1 of 19 us per round of tiles, profiles/r02_gemm_p8_epilogue_ablation.txt).  T = float or f32x2: the same operation
+// sequence per element, so scalar and packed call sites (and every kernel variant) round identically.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float rq_clamp_unit(float v) { return rq_med3(v, -1.0f, 1.0f); }
+static __device__ __forceinline__ f32x2 rq_clamp_unit(f32x2 v) { return (f32x2){rq_med3(v.x, -1.0f, 1.0f), rq_med3(v.y, -1.0f, 1.0f)}; }
+template <typename T> static __device__ __forceinline__ T rq_gelu_erf(T x) {
+    const T z = x * 0.70710678118654752440f;
+    const T t = z * z;
+    T p = (T)(4.074052874e-08f);
+    p = __builtin_elementwise_fma(p, t, (T)(-1.944763019e-06f));
+    p = __builtin_elementwise_fma(p, t, (T)(4.105959529e-05f));
+    p = __builtin_elementwise_fma(p, t, (T)(-5.110292166e-04f));
+    p = __builtin_elementwise_fma(p, t, (T)(4.235391654e-03f));
+    p = __builtin_elementwise_fma(p, t, (T)(-2.510276678e-02f));
+    p = __builtin_elementwise_fma(p, t, (T)(1.110792036e-01f));
+    p = __builtin_elementwise_fma(p, t, (T)(-3.753147936e-01f));
+    p = __builtin_elementwise_fma(p, t, (T)(1.128268411e+00f));
+    const T e = rq_clamp_unit(z * p);
+    const T hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
+}
 static __device__ __forceinline__ float rq_gelu(float x, int v2) {
     if (v2) return x * rq_fast_rcp(1.0f + rq_fast_exp2(-1.702f * 1.4426950408889634f * x));
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = rq_fast_rcp(fmaf(0.3275911f, z, 1.0f));
-    const float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
-    const float h = 0.5f * poly * rq_fast_exp2(-1.4426950408889634f * z * z);      // Phi(-|x|)
-    return x * (x < 0.f ? h : 1.0f - h);
+    return rq_gelu_erf<float>(x);
+}
+// four consecutive outputs of one lane (the epilogues' unit of work), as two packed pairs
+static __device__ __forceinline__ void rq_gelu4(float (&v)[4], int v2) {
+    if (v2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], 1);
+        return;
+    }
+    const f32x2 a = rq_gelu_erf<f32x2>((f32x2){v[0], v[1]}), b = rq_gelu_erf<f32x2>((f32x2){v[2], v[3]});
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
 static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element offset in a [rows][64] bf16 tile
@@ -136,8 +165,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                         }
                     }
                     if (epi == EPI_BF16_GELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                        rq_gelu4(v, p.gelu_v2);
                     }
                     if (epi == EPI_BF16_RESID) {
                         // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
@@ -210,8 +238,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                     }
                 }
                 if (epi == EPI_BF16_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+                    rq_gelu4(v, p.gelu_v2);
                 }
                 if (epi <= EPI_BF16_RESID) {
                     bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
@@ -1099,8 +1126,9 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(GemmArgs p) {
         for (int e = 0; e < 4; ++e) if (nn + e < p.N) v[e] += bias[nn + e];
     }
     if (epi == EPI_BF16_GELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rq_gelu(v[e], p.gelu_v2);
+        float g[4] = {v[0], v[1], v[2], v[3]};
+        rq_gelu4(g, p.gelu_v2);
+        v = (f32x4){g[0], g[1], g[2], g[3]};
     }
     if (epi <= EPI_BF16_RESID) {
         bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + nn;

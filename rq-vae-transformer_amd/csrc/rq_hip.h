@@ -128,6 +128,7 @@ static __device__ __forceinline__ int rq_readlane_i(int v, int lane) { return __
 static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v"(x)); }
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+static __device__ __forceinline__ float rq_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }   // median: clamp in one op
 static __device__ __forceinline__ float rq_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #define RQ_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #define RQ_LAUNCH(kern, grid, block, smem, stream, ...) \
