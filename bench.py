@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
+    ap.add_argument('--overlap-prio', type=int, default=0, help='with --overlap: 1 = sampling stream at high priority, 2 = decode stream at high priority')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU/gloo rehearsal of the launcher, sharding, gather and timing logic with synthetic pixels (no kernels run; tests only)')
     args = ap.parse_args(argv)
@@ -364,7 +365,8 @@ def main(argv=None):
     t0 = time.perf_counter()
     if args.overlap:
         # experiment (not the default): batch i is decoded on a second stream while batch i+1 is being sampled
-        s_ar, s_dec = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        s_ar = torch.cuda.Stream(device, priority=-1 if args.overlap_prio == 1 else 0)
+        s_dec = torch.cuda.Stream(device, priority=-1 if args.overlap_prio == 2 else 0)
         prev = None
         for i in range(args.steps + 1):
             cur = None
