@@ -439,14 +439,14 @@ def test_emu_conv_halo(nat):
 
 def test_emu_conv_halo_persistent(nat):
     """persistent form of the 8-row halo conv: a workgroup walks several tiles, staging the next tile's patch / weights during
-    the last chunk of the current one (cross-tile prefetch, epilogue tile placed clear of the staged patch).  One, three and
-    "one per CU" workgroups per XCD; two channel chunks, two cout tiles (the weight base switches between consecutive slots);
-    must equal the per-tile kernel bit for bit."""
+    the last chunk of the current one (cross-tile prefetch, epilogue tile placed clear of the staged patch).  One and three
+    workgroups per XCD (four slots each: 4 tiles per workgroup, and 2 / 1 / 1); two channel chunks, two cout tiles (the weight
+    base switches between consecutive slots); must equal the per-tile kernel bit for bit."""
     rng = np.random.default_rng(14)
 
     def bf(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
-    for (B, H, W, Cin, Cout) in ((1, 64, 64, 64, 128), (2, 64, 32, 128, 256)):
+    for (B, H, W, Cin, Cout) in ((2, 64, 32, 128, 256),):
         x = bf(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
         w = bf((0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
         bias = T(rng.standard_normal(Cout).astype(np.float32))
@@ -456,7 +456,7 @@ def test_emu_conv_halo_persistent(nat):
         ref_plain = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=False)
         st_ref = torch.zeros((B, nt, 32, 2), dtype=torch.float32)
         ref_fused = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st_ref, tile_h=8, persistent=False)
-        for wpx in (1, 3, 0):
+        for wpx in (1, 3):
             out = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=True, wpx=wpx)
             assert torch.equal(out, ref_plain), (Cin, Cout, wpx)
             st = torch.zeros_like(st_ref)
