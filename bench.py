@@ -117,29 +117,33 @@ def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     return codes, pixels
 
 
-def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=2):
-    """Oracle (numpy restatement, kind 'port') on the host cores: `n_pos` spatial positions (n_pos body
-    steps + 4*n_pos head/sampler steps) of a batch-`batch` sample, scaled to the 64 positions of an image,
-    plus one full decode_code of one image."""
+def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):
+    """Oracle (restatement of the reference, kind 'port') on the host cores, its heavy primitives on PyTorch's CPU kernels --
+    the kernels the reference itself runs on a CPU (oracle/backend.py): `n_pos` spatial positions (n_pos body steps +
+    4*n_pos head/sampler steps) of a batch-`batch` sample, scaled to the 64 positions of an image, plus one full decode_code
+    of `n_dec` images.  Bounded to ~10-30 s of CPU work."""
     import oracle
-    import threadpoolctl
     aparams = {k: v.detach().float().cpu().numpy() for k, v in ar.state_dict().items()}
     vparams = {k: v.detach().float().cpu().numpy() for k, v in vae.state_dict().items()}
     orc = oracle.RQTransformerOracle(cfg, aparams)
     ov = oracle.RQVAEOracle(vcfg['hparams'], vcfg['ddconfig'], vparams)
     H, W, D = cfg['block_size']
-    cores = max(i['num_threads'] for i in threadpoolctl.threadpool_info() if i.get('user_api') == 'blas')
     part = np.zeros((batch, H, W, D), np.int64)
     cl = max(cfg.get('block_size_cond', 1), 1)
-    t0 = time.time()
-    xs = orc.sample(part, ov.codebooks, cond=np.zeros((batch, cl), np.int64), max_steps=n_pos * D)
-    t_ar = (time.time() - t0) * (H * W / n_pos) / batch            # seconds per image
-    t0 = time.time()
-    ov.decode_code(xs[:1])
-    t_dec = time.time() - t0
-    return {'value': 1.0 / (t_ar + t_dec), 'unit': 'images/sec', 'cores': int(cores), 'kind': 'port',
-            'sample': f'numpy oracle, fp32: {n_pos} of {H * W} spatial positions at batch {batch} (scaled x{H * W / n_pos:.1f}) '
-                      f'= {t_ar:.1f} s/img AR + one full 256x256 decode_code = {t_dec:.1f} s/img'}
+    oracle.backend.use_torch(True)
+    try:
+        t0 = time.time()
+        xs = orc.sample(part, ov.codebooks, cond=np.zeros((batch, cl), np.int64), max_steps=n_pos * D)
+        t_ar = (time.time() - t0) * (H * W / n_pos) / batch            # seconds per image
+        t0 = time.time()
+        ov.decode_code(xs[:n_dec])
+        t_dec = (time.time() - t0) / n_dec
+    finally:
+        oracle.backend.use_torch(False)
+    return {'value': 1.0 / (t_ar + t_dec), 'unit': 'images/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': f'oracle (numpy restatement, heavy primitives on torch-CPU kernels), fp32: {n_pos} of {H * W} spatial positions at '
+                      f'batch {batch} (scaled x{H * W / n_pos:.1f}) = {t_ar:.2f} s/img AR + full 256x256 decode_code of {n_dec} images = '
+                      f'{t_dec:.2f} s/img'}
 
 
 def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model, B):

@@ -12,6 +12,7 @@ oracle is pinned against outputs of the reference itself, imported on CPU in the
 build container by ``tests/golden/make_golden.py`` (fixtures committed under
 ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks them on every run).
 """
+from . import backend  # noqa: F401
 from .weights import make_params, rqvae_param_shapes, rqt_param_shapes  # noqa: F401
 from .rq import (compute_distances, rq_quantize, rq_embed_code,  # noqa: F401
                  rq_embed_code_with_depth, rq_quantize_margins, rq_soft_codes)

@@ -14,6 +14,7 @@ Restates the reference's stage-2 model for the released flag set
 import numpy as np
 from scipy.special import erf
 
+from . import backend
 from .rq import rq_embed_code_with_depth
 from .sampler import filtered_probs
 
@@ -27,12 +28,22 @@ def layer_norm(x, w, b, eps=1e-5):
 
 
 def linear(x, w, b=None):
+    if backend.torch_on():
+        import torch
+        import torch.nn.functional as F
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        return F.linear(t(x), t(w), None if b is None else t(b)).numpy()
     y = x.astype(np.float32) @ w.T
     return y if b is None else y + b
 
 
 def gelu(x, version='v1'):
     """attentions.py:25-36"""
+    if backend.torch_on():
+        import torch
+        import torch.nn.functional as F
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return (F.gelu(t) if version == 'v1' else t * torch.sigmoid(1.702 * t)).numpy()
     if version == 'v1':
         return (0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))).astype(np.float32)
     return (x / (1.0 + np.exp(-1.702 * x))).astype(np.float32)

@@ -11,16 +11,29 @@ Restates the reference's stage-1 model:
 """
 import numpy as np
 
+from . import backend
 from .rq import rq_quantize, rq_embed_code
 
 
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
 def silu(x):
+    if backend.torch_on():
+        import torch.nn.functional as F
+        return F.silu(_t(x)).numpy()
     return x / (1.0 + np.exp(-x))
 
 
 def group_norm(x, w, b, groups=32, eps=1e-6):
     """x NHWC.  layers.py:16-17"""
     B, H, W, C = x.shape
+    if backend.torch_on():
+        import torch.nn.functional as F
+        y = F.group_norm(_t(x).permute(0, 3, 1, 2), groups, _t(w), _t(b), eps)
+        return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
     g = x.reshape(B, H * W, groups, C // groups).astype(np.float32)
     mu = g.mean((1, 3), keepdims=True, dtype=np.float32)
     xc = g - mu
@@ -33,6 +46,11 @@ def conv2d(x, w, b, stride=1, pad=(1, 1, 1, 1)):
     """x NHWC fp32, w (Cout,Cin,kh,kw) torch layout, pad = (top, bottom, left, right)."""
     B, H, W, C = x.shape
     co, ci, kh, kw = w.shape
+    if backend.torch_on():
+        import torch.nn.functional as F
+        xt = F.pad(_t(x).permute(0, 3, 1, 2), (pad[2], pad[3], pad[0], pad[1]))
+        y = F.conv2d(xt, _t(w), _t(b), stride=stride)
+        return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
     xp = np.pad(x, ((0, 0), (pad[0], pad[1]), (pad[2], pad[3]), (0, 0)))
     Ho = (H + pad[0] + pad[1] - kh) // stride + 1
     Wo = (W + pad[2] + pad[3] - kw) // stride + 1

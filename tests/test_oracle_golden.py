@@ -142,3 +142,26 @@ def test_param_counts():
     n = sum(int(np.prod(s)) for k, s in shapes.items()
             if 'ema' not in k and not any(k.startswith(f'quantizer.codebooks.{i}.') for i in (1, 2, 3)))
     assert abs(n / 1e6 - 104.4) < 0.06
+
+
+def test_torch_backend_agrees_with_numpy_forms():
+    """oracle/backend.py: the torch-CPU forms of the heavy primitives (used only by bench.py's cpu_baseline leg) compute what
+    the pinned numpy forms compute."""
+    from oracle import backend, vae as ovae, transformer as otr
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 8, 8, 64)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((32, 64, 3, 3))).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    g, be = rng.standard_normal(64).astype(np.float32), rng.standard_normal(64).astype(np.float32)
+    lw = rng.standard_normal((48, 64)).astype(np.float32)
+    want = [ovae.conv2d(x, w, b), ovae.conv2d(x, w, b, stride=2, pad=(0, 1, 0, 1)), ovae.group_norm(x, g, be), ovae.silu(x),
+            otr.linear(x, lw, b[:1].repeat(48)), otr.gelu(x), otr.gelu(x, 'v2')]
+    backend.use_torch(True)
+    try:
+        got = [ovae.conv2d(x, w, b), ovae.conv2d(x, w, b, stride=2, pad=(0, 1, 0, 1)), ovae.group_norm(x, g, be), ovae.silu(x),
+               otr.linear(x, lw, b[:1].repeat(48)), otr.gelu(x), otr.gelu(x, 'v2')]
+    finally:
+        backend.use_torch(False)
+    for a, c in zip(want, got):
+        assert a.shape == c.shape
+        assert np.abs(a - c).max() <= 2e-5 * max(1.0, np.abs(a).max())
