@@ -63,17 +63,16 @@ static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) 
 // acc[4][2], 0.75 KB of LDS fragment reads per MFMA instead of 1 KB, 32 MFMAs per wavefront between barriers instead of 16,
 // a (16+2) x 34 patch = 1.20x the interior (1.33x at 8 rows) and every weight tile staged for twice the pixels.  The patch
 // (78 KB per 64-channel chunk) is single-buffered: the next chunk's pieces wait, already normalised, in their registers.
-template <int FUSE_GN, int UPS, int TH, int W4 = 0>
-__global__ __launch_bounds__(W4 ? 256 : (TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
-    static_assert(!W4 || TH == 16, "the four-wavefront form is a 16-row tile");
-    constexpr int NTH = W4 ? 256 : (TH == 16 ? 8 : TH) * 64;  // threads: one wavefront per (row group, cout half)
-    constexpr int NJ = W4 ? 4 : 2;                 // 32-channel blocks per wavefront: 128 x 128 wave tiles in the four-wavefront form
+template <int FUSE_GN, int UPS, int TH>
+__global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    constexpr int NTH = (TH == 16 ? 8 : TH) * 64;  // threads: one wavefront per (row group, cout half)
+    constexpr int NJ = 2;                          // 32-channel blocks per wavefront
     constexpr int RPW = TH == 16 ? 4 : 2;          // tile rows per wavefront
     constexpr int NB_H = TH == 8 ? 2 : 1;          // patch buffers
     constexpr int W_IT = 1024 / NTH;               // 16-byte chunks of a weight tile per thread
     constexpr int TPX = TH * HT_W;                 // pixels per tile
     // with two workgroups per CU the other one covers global latency: shallow prefetch, fewer registers (<= 256 needed)
-    constexpr int W_SETS = (TH == 8 || W4) ? 3 : 1;   // weight tiles in flight (register sets)
+    constexpr int W_SETS = TH == 8 ? 3 : 1;   // weight tiles in flight (register sets)
     constexpr bool RPRE = TH == 8;                 // residual tile prefetched into registers during the last taps
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
     constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(W4 ? 256 : (TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 
     char* sH = (char*)smem;                        // [2][HALO_BYTES]
     char* sW = sH + NB_H * HALO_BYTES;             // [2][HW_BYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = W4 ? wave : wave >> 1, wn = W4 ? 0 : wave & 1;   // (TH/RPW) x 2 wavefronts: rows (groups of RPW tile rows) x cout halves
+    const int wm = wave >> 1, wn = wave & 1;       // (TH/RPW) x 2 wavefronts: rows (groups of RPW tile rows) x cout halves
 
     // ---- tile decode: contiguous band of tiles per XCD (neighbouring tiles share halo rows in that L2)
     const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(W4 ? 256 : (TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 
                 for (int j = 0; j < NJ; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);   // transposed tile
             // 128 accumulator registers leave room for two k-steps of fragments (48 registers), not for the four the
             // scheduler would like to hoist: fence every k-step (the co-resident wavefront covers the LDS latency)
-            if (RPW == 4 && !W4) rq_sched_barrier();
+            if (RPW == 4) rq_sched_barrier();
         }
     };
 
@@ -291,7 +290,7 @@ __global__ __launch_bounds__(W4 ? 256 : (TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 
             if (FUSE_GN && ptap) {
                 // pipeline: each MFMA (8 passes) carries a slice of the pieces' ~100 VALU instructions each
 #pragma unroll
-                for (int g = 0; g < 4 * RPW * NJ; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, W4 ? 5 : 7); }
+                for (int g = 0; g < 4 * RPW * NJ; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
             }
             store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
 #pragma unroll
@@ -1115,14 +1114,11 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
 // chunk waits in registers: +3..5 % on the plain conv (978 vs 929 TF at 128->128 @256^2), but with GroupNorm+SiLU fused the
 // ten patch pieces + 128 accumulators + scale/shift registers exceed 256 VGPRs and the spills cost 4-11 %
 // (profiles/r02_conv_halo_tile_height.txt) -- every ResnetBlock conv of the decoder is a fused one, so 8 stays the default.
-// RQAMD_HALO_W4=1: the 16-row tile on FOUR wavefronts (one per SIMD, 128 pixels x 128 channels each, 512 registers per lane)
-static bool halo_w4_env() {
-    static const int env = getenv("RQAMD_HALO_W4") ? atoi(getenv("RQAMD_HALO_W4")) : 0;
-    return env != 0;
-}
+// (The same 16-row tile on FOUR wavefronts -- 128 x 128 wave tiles, accumulators in AGPRs, half the LDS reads per MFMA -- was 20 %
+// slower: with one wavefront per SIMD nothing overlaps the compiler-scheduled stream; profiles/r02_conv_halo_variants.txt, removed.)
 static int halo_th() {
     static const int env = getenv("RQAMD_HALO_TH") ? atoi(getenv("RQAMD_HALO_TH")) : 0;
-    static const int th = (env == 4 || env == 16) ? env : halo_w4_env() ? 16 : 8;
+    static const int th = (env == 4 || env == 16) ? env : 8;
     return th;
 }
 
@@ -1133,7 +1129,6 @@ bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
 int rq_conv_halo_stat_tiles(int H, int W) { return (H / halo_th()) * (W / HT_W); }
 static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a tile height
 static int g_conv_halo_dbg_pk = 0;          // diagnostics entry only: +1 / -1 force the persistent / per-tile form of the 8-row kernel
-static int g_conv_halo_dbg_w4 = 0;          // diagnostics entry only: +1 four-wavefront form of the 16-row tile
 static int g_conv_halo_dbg_wpx = 0;         // diagnostics entry only: workgroups per XCD of the persistent form
 // Measured (profiles/r02_conv_halo_variants.txt): the persistent form gains 4-7 % where the tile is short and carries no fused
 // GroupNorm (the upsample convs), nothing or -3 % on the fused ResnetBlock convs (their epilogue is bound by store ISSUE, which
@@ -1145,17 +1140,17 @@ static bool halo_persistent(int ups) {
     return env < 0 ? ups != 0 : env != 0;
 }
 
-template <int TH, int W4 = 0>
+template <int TH>
 static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     constexpr size_t patch = (size_t)(TH + 2) * HP_W * 128, stage = (TH == 8 ? 2 : 1) * patch + 2 * HW_BYTES;
-    constexpr int NTHR = W4 ? 256 : (TH == 16 ? 8 : TH) * 64;
+    constexpr int NTHR = (TH == 16 ? 8 : TH) * 64;
     constexpr size_t epi = (size_t)TH * HT_W * (H_BN * 2 + 16);
     const size_t smem = stage > epi ? stage : epi;
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, TH, W4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, TH, W4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, TH, W4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
@@ -1181,9 +1176,9 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
         else RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
         return rq_check_launch("conv3x3_halo_pk_kernel");
     }
-    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH, W4>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH, W4>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH, W4>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
     return rq_check_launch("conv3x3_halo_kernel");
 }
 
@@ -1196,8 +1191,6 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const int th = g_conv_halo_dbg_th ? g_conv_halo_dbg_th : halo_th();
-    const bool w4 = g_conv_halo_dbg_w4 ? g_conv_halo_dbg_w4 > 0 : (g_conv_halo_dbg_th == 0 && halo_w4_env());
-    if (th == 16 && w4) return launch_conv_halo_th<16, 1>(a, ups, s);
     return th == 16 ? launch_conv_halo_th<16>(a, ups, s) : th == 8 ? launch_conv_halo_th<8>(a, ups, s) : launch_conv_halo_th<4>(a, ups, s);
 }
 
@@ -1216,13 +1209,11 @@ extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const floa
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
     g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : (ups & 8) ? 16 : 0;      // ups bits 1 / 2 / 3: force the 8- / 4- / 16-row tile variant
     g_conv_halo_dbg_pk = (ups & 16) ? 1 : (ups & 32) ? -1 : 0;                    // bits 4 / 5: persistent / per-tile form of the 8-row kernel
-    g_conv_halo_dbg_w4 = (ups & 64) ? 1 : (g_conv_halo_dbg_th ? -1 : 0);          // bit 6 (with bit 3): four-wavefront form
     g_conv_halo_dbg_wpx = (ups >> 8) & 0xff;                                      // bits 8..15: workgroups per XCD (0 = one per CU)
     const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
                                        Cin, Cout, ups & 1, (hipStream_t)stream);
     g_conv_halo_dbg_th = 0;
     g_conv_halo_dbg_pk = 0;
-    g_conv_halo_dbg_w4 = 0;
     g_conv_halo_dbg_wpx = 0;
     return rc;
 }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Interleaved timing of the halo-conv variants: 8-row per-tile (baseline), 8-row persistent, 16-row on 8 wavefronts, 16-row on 4."""
+"""Interleaved timing of the halo-conv variants: 8-row per-tile (baseline), 8-row persistent, 16-row on 8 wavefronts.
+(profiles/r02_conv_halo_variants.txt also has the removed 16-row / 4-wavefront form, "w4".)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
@@ -7,8 +8,7 @@ import torch
 from rqvae import _native
 
 dev = 'cuda'
-VARIANTS = (('th8', dict(tile_h=8, persistent=False)), ('th8p', dict(tile_h=8, persistent=True)), ('th16', dict(tile_h=16)),
-            ('w4', dict(tile_h=16, w4=True)))
+VARIANTS = (('th8', dict(tile_h=8, persistent=False)), ('th8p', dict(tile_h=8, persistent=True)), ('th16', dict(tile_h=16)))
 
 
 def timed(fn, reps):

@@ -414,14 +414,11 @@ def test_emu_conv_halo(nat):
     xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
     xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
-    # 16 x 32 tiles (4 rows per wave, single buffer; 17 = the same tile on four wavefronts of 128 x 128), 8 x 32 (double-buffered
-    # patch), 4 x 32 (4 waves)
-    for th in (17, 16, 8, 4):
-        w4, th = th == 17, min(th, 16)
-        out = nat.dbg_conv_halo(x, w, bias, tile_h=th, w4=w4).float().numpy()
+    for th in (16, 8, 4):        # 16 x 32 tiles (4 rows per wave, single buffer), 8 x 32 (double-buffered patch), 4 x 32 (4 waves)
+        out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float().numpy()
         assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max(), th
         stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), dtype=torch.float32)
-        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats, tile_h=th, w4=w4).float().numpy()
+        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats, tile_h=th).float().numpy()
         assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max(), th
         # epilogue statistics: per (th x 32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
         t = out.reshape(B, H // th, th, W // 32, 32, 32, Cout // 32).astype(np.float64)
@@ -431,8 +428,8 @@ def test_emu_conv_halo(nat):
     xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
     xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
     ref_up = conv2d(xu, wf, bias.numpy())
-    for th in (17, 16, 8, 4):
-        out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=min(th, 16), w4=th == 17).float().numpy()
+    for th in (16, 8, 4):
+        out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float().numpy()
         assert out.shape == (B, H, W, Cout)
         assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), th
 

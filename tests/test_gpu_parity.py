@@ -481,6 +481,10 @@ def test_conv_kernels_vs_torch(nat):
             t = out.double().reshape(B, H // th, th, W // 32, 32, 32, Cout // 32)
             want = torch.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
             assert float((stats.double() - want).abs().max()) < 1e-3 * float(want.abs().max()), th
+        # persistent form of the 8-row kernel (a workgroup walks its tiles with cross-tile prefetch): bit-identical to the per-tile form
+        a = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, tile_h=8, persistent=False)
+        for wpx in (0, 1):
+            assert torch.equal(a, nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, tile_h=8, persistent=True, wpx=wpx)), wpx
         # the same conv through a folded nearest 2x upsample (Upsample.forward)
         xs = rn(B, H // 2, W // 2, Cin).to(torch.bfloat16)
         xu = F.interpolate(xs.float().permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest')
@@ -488,6 +492,8 @@ def test_conv_kernels_vs_torch(nat):
         for th in (16, 8, 4):
             out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float()
             assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max()), th
+        assert torch.equal(nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=False),
+                           nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=True))
     # MFMA Encoder.conv_in: NCHW fp32 image -> NHWC bf16
     x = rn(2, 3, 256, 256).clamp(-1, 1)
     w = rn(128, 3, 3, 3, scale=0.2)
