@@ -63,6 +63,13 @@ static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) 
 // acc[4][2], 0.75 KB of LDS fragment reads per MFMA instead of 1 KB, 32 MFMAs per wavefront between barriers instead of 16,
 // a (16+2) x 34 patch = 1.20x the interior (1.33x at 8 rows) and every weight tile staged for twice the pixels.  The patch
 // (78 KB per 64-channel chunk) is single-buffered: the next chunk's pieces wait, already normalised, in their registers.
+#ifdef RQ_CONV_TRACE
+// Diagnostics build only (scripts/conv_trace.sh): shader-clock stamps of one workgroup's barrier arrivals / releases.
+__device__ unsigned long long g_conv_trace[8 * 64];
+#define RQ_CT(slot) do { if (blockIdx.x == RQ_CONV_TRACE && lane == 0 && (slot) < 64) g_conv_trace[wave * 64 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RQ_CT(slot) do { } while (0)
+#endif
 template <int FUSE_GN, int UPS, int TH>
 __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     constexpr int NTH = (TH == 16 ? 8 : TH) * 64;  // threads: one wavefront per (row group, cout half)
@@ -138,13 +145,17 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7), loaded
     // with the patch so that no global-load latency sits between the taps
     f32x4 gs[4];
-    auto load_halo = [&](int c, rq_u128* rh) {
-#pragma unroll
-        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u));
+    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
+    auto load_gs = [&](int c) {
         if (FUSE_GN) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
         }
+    };
+    auto load_halo = [&](int c, rq_u128* rh) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) load_halo_piece(c, rh, it);
+        load_gs(c);
     };
     // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS.  The fused form is spread over
     // the taps of a chunk (one piece per tap) so that its VALU / transcendental work issues under the MFMAs;
@@ -190,13 +201,19 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
         for (int i = 0; i < W_IT; ++i) st128(sW + buf * HW_BYTES + w_loff[i], rw[i]);
     };
 
+    // the accumulators start from the bias (transposed tile: register 4q+e of block j is output channel
+    // wn*64 + j*32 + 8q + 4*(lane>>5) + e): its loads hide under the patch prologue instead of opening the epilogue
     f32x16 acc[RPW][NJ];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *(const f32x4*)(p.bias + n0 + wn * (NJ * 32) + j * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bv[e];
+        }
 
     const int ftx = lane & 31, fk = lane >> 5;
     // fragment base addresses for k-step 0: weights row = wn*64 + ftx (+32 j); patch pixel (wm*RPW, ftx + kx)
@@ -243,9 +260,11 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     load_halo(0, rh);
 #pragma unroll
     for (int u = 0; u < W_SETS; ++u) load_unit(0, u, rw[u]);
+    RQ_CT(0);
     store_halo(0, 0, rh);
     store_w(0, rw[0]);
     rq_syncthreads();
+    RQ_CT(1);
     int wbuf = 0;
     // residual tile (epilogue operand): its 8 pieces per thread are fetched during the LAST chunk's taps, where the
     // patch registers would otherwise reload a chunk nobody needs, so the epilogue starts with the data in hand
@@ -258,15 +277,29 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int hbuf = NB_H == 2 ? c & 1 : 0;
+        constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             // prefetch: unit g+3 into the set unit g just left; next chunk's halo patch once, a few taps ahead
-            load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
-            if (!LAST && tap == 0) load_halo(c + 1, rh);
-            if (RPRE && LAST && tap == 2 && p.resid) {     // uniform; one conservative vmcnt drain per workgroup at worst
+            // Global loads are spread over the taps (every workgroup of a launch is in the same phase: eight residual pieces or six
+            // patch pieces per thread issued in ONE tap are a 16-MB chip-wide request burst that stalled the issuing wavefronts for
+            // ~1800 cycles, profiles/r02_conv_halo_barrier_timeline.txt): the weight tile three units ahead; patch piece `it` of the
+            // next chunk three taps before the tap that normalises and stores it; one residual piece per tap of the last chunk.
+            // (The last chunk's taps 6..8 have no weight tile left to fetch, and its last tap none to stage.)
+            if (!(LAST && tap + W_SETS >= 9)) load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
+            if (!LAST) {
+                if (tap == 0) load_gs(c + 1);
 #pragma unroll
-                for (int k = 0; k < R_IT; ++k) {
+                for (int it = 0; it < H_IT; ++it) {
+                    const int t_use = FIRST + it / PPT, t_load = t_use >= 3 ? t_use - 3 : 0;
+                    if (t_load == tap) load_halo_piece(c + 1, rh, it);
+                }
+            }
+            if (RPRE && LAST && tap >= 1 && p.resid) {     // uniform
+                constexpr int RPT = (R_IT + 7) / 8;        // residual pieces per tap
+#pragma unroll
+                for (int k = (tap - 1) * RPT; k < tap * RPT && k < R_IT; ++k) {
                     const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
                     const int ty = ml / HT_W, tx = ml - ty * HT_W;
                     const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
@@ -278,7 +311,6 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
             // loads were issued three taps earlier; 16 rows: two pieces per tap in taps 4..8).  The fused GroupNorm+SiLU
             // arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no fence in between) so that its
             // VALU / transcendental instructions issue in the MFMAs' shadow.
-            constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
             const bool ptap = !LAST && tap >= FIRST;
             // (the finished piece replaces the raw one in its register: no second copy)
 #pragma unroll
@@ -292,7 +324,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 #pragma unroll
                 for (int g = 0; g < 4 * RPW * NJ; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
             }
-            store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
+            if (!(LAST && tap == 8)) store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
                 const int it = (tap - FIRST) * PPT + k;
@@ -300,7 +332,9 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
                 if (NB_H == 2) { if (h_in(it)) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff(it), rh[it]); }
                 // single buffer: the finished piece waits in its register until the chunk's last tap has been read
             }
+            RQ_CT(2 + (c * 9 + tap) * 2);
             rq_syncthreads();
+            RQ_CT(3 + (c * 9 + tap) * 2);
             wbuf ^= 1;
         }
         if (NB_H == 1 && !LAST) {                          // every wave is past its reads of this chunk: refill the buffer
@@ -345,11 +379,9 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = wn * (NJ * 32) + j * 32 + 8 * q + 4 * (lane >> 5);
-                const int n = n0 + nl;
-                const f32x4 bv = *(const f32x4*)(p.bias + n);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (p.resid) {
                     const uint32_t* rp = (const uint32_t*)(sT + ml * LDR + nl * 2);
                     const uint32_t r0 = rp[0], r1 = rp[1];
@@ -364,6 +396,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
         }
     }
     rq_syncthreads();
+    RQ_CT(61);
     // Thread tid streams chunk (tid & 15) of pixels (tid >> 4) + 32 k.  The GroupNorm statistics of the NEXT layer are
     // taken here from the rounded bf16 values on their way out (what a separate gn_stats pass would read back from
     // HBM: ~30 us per image over the decoder): per-thread (sum, sumsq) over its 8 pixels, folded to the 1-2 groups
@@ -425,6 +458,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
             }
         }
     }
+    RQ_CT(63);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -457,7 +491,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
     constexpr int HP_N = PW * PH;
     constexpr int H_IT = (HP_N * 8 + NTH - 1) / NTH;
-    constexpr int RTAP = 5;                         // tap of the last chunk at which the residual tile is fetched
     RQ_DYN_SMEM(smem);
     char* sW = (char*)smem;                         // [2][HW_BYTES]
     char* sH = (char*)smem + PK_P0;                 // patch buffer b at b * PK_PSTRIDE
@@ -506,6 +539,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         x_img = (unsigned)((long)t.img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);
         if (FUSE_GN) gn = p.gn + (long)t.img * p.Cin * 2;
     };
+    // the same for a later tile, from the descriptors already in registers: a piece's patch position is recovered from its LDS
+    // offset (tile-independent), so the full derivation above is paid once per workgroup, not once per tile (it cost ~1800
+    // cycles of VALU per tile when every tile recomputed it, profiles/r02_conv_halo_barrier_timeline.txt)
+    auto restage = [&](const HaloTile& t) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            const unsigned in = (hd[it] >> 30) & 1u, lo = hd[it] & 0x1fff0000u;
+            const int hp = (int)(lo >> 19);
+            const int hy = hp / PW, hx = hp - hy * PW;
+            const int gy = (UPS ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS ? t.tx0 >> 1 : t.tx0) + hx - 1;
+            const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
+            hd[it] = (unsigned)(cy * Ws + cx) | lo | (ok ? 1u << 29 : 0u) | (in << 30);
+        }
+        x_img = (unsigned)((long)t.img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);
+        if (FUSE_GN) gn = p.gn + (long)t.img * p.Cin * 2;
+    };
     const unsigned cin2 = (unsigned)p.Cin * 2u;
     auto h_in = [&](int it) { return (hd[it] >> 30) & 1u; };
     auto h_ok = [&](int it) { return (hd[it] >> 29) & 1u; };
@@ -524,13 +574,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     const char* gWt = (const char*)p.w;
 
     f32x4 gs[4];
-    auto load_halo = [&](int c, rq_u128* rh) {
-#pragma unroll
-        for (int it = 0; it < H_IT; ++it) rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u));
+    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
+    auto load_gs = [&](int c) {
         if (FUSE_GN) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
         }
+    };
+    auto load_halo = [&](int c, rq_u128* rh) {
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) load_halo_piece(c, rh, it);
+        load_gs(c);
     };
     auto halo_piece_value = [&](const rq_u128* rh, int it) -> rq_u128 {
         rq_u128 v = rh[it];
@@ -571,6 +625,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
 
     f32x16 acc[RPW][2];
+    // accumulators start from the bias of the tile's output channels (as in conv3x3_halo_kernel)
+    auto acc_from_bias = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *(const f32x4*)(p.bias + n0 + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5));
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bv[e];
+            }
+    };
     auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
         const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * PK_PSTRIDE);
         const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
@@ -602,6 +669,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     if (has_next) nxt = decode(slot + wpx);
     unsigned wn_cur = (unsigned)cur.n0 * w_per_n, wn_nxt = (unsigned)nxt.n0 * w_per_n;
     set_staging(cur);
+    acc_from_bias(cur.n0);
     load_halo(0, rh);
     // weight units run on across tiles: unit (c, tap) of the tile, then (0, 0..) of the next one; always set tap % 3
     auto load_unit = [&](int c, int tap, rq_u128* r) {
@@ -623,25 +691,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     int wbuf = 0, hbuf = 0;
 
     int tid_o = tid;                               // opaque per-tile copy of the thread index (see the tile loop)
+#ifdef RQ_CONV_TRACE
+    int trace_tile = 0;
+#define RQ_CTP(slot) do { if (blockIdx.x == (RQ_CONV_TRACE & 255) && trace_tile == 2 && lane == 0 && (slot) < 64) g_conv_trace[wave * 64 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RQ_CTP(slot) do { } while (0)
+#endif
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         // the last chunk stages the next tile's first patch; with no next tile the descriptors are cleared ("piece does not
         // exist"), so that the staging code below stays branch-free inside the MFMA scheduling regions
         if (LAST) {
-            if (has_next) set_staging(nxt);
+            if (has_next) restage(nxt);
             else {
 #pragma unroll
                 for (int it = 0; it < H_IT; ++it) hd[it] = 0u;
             }
         }
+        constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
+        static_assert(R_IT <= 8, "one residual piece per tap");
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
+            // loads spread over the taps as in conv3x3_halo_kernel: weight tile three units ahead, patch piece `it` three taps
+            // before the tap that normalises and stores it, one residual piece per tap of the last chunk
             load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
-            if (tap == 0) load_halo(LAST ? 0 : c + 1, rh);
-            if (LAST && tap == RTAP && p.resid) {
+            if (tap == 0) load_gs(LAST ? 0 : c + 1);
 #pragma unroll
-                for (int k = 0; k < R_IT; ++k) {
+            for (int it = 0; it < H_IT; ++it) {
+                const int t_use = FIRST + it / PPT, t_load = t_use >= 3 ? t_use - 3 : 0;
+                if (t_load == tap) load_halo_piece(LAST ? 0 : c + 1, rh, it);
+            }
+            if (LAST && tap >= 1 && p.resid) {
+#pragma unroll
+                for (int k = tap - 1; k < tap && k < R_IT; ++k) {
                     const int cidx = tid_o + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
                     const int ty = ml / HT_W, tx = ml - ty * HT_W;
                     const long pix = ((long)cur.img * p.H + cur.ty0 + ty) * p.W + cur.tx0 + tx;
@@ -649,7 +732,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 }
             }
             rq_sched_barrier();
-            constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
             const bool ptap = tap >= FIRST;
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -668,7 +750,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 if (!(ptap && it < H_IT)) continue;
                 if (h_in(it)) st128(sH + (hbuf ^ 1) * PK_PSTRIDE + h_loff(it), rh[it]);
             }
+            RQ_CTP(2 + (c * 9 + tap) * 2);
             rq_syncthreads();
+            RQ_CTP(3 + (c * 9 + tap) * 2);
             wbuf ^= 1;
         }
         hbuf ^= 1;
@@ -678,12 +762,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         // the epilogue's addressing is the same for every tile; recomputed from an opaque copy of the thread index each
         // round, or the compiler hoists ~100 registers of loop-invariant offsets across the main loop (and spills them)
         rq_opaque(tid_o);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        RQ_CTP(1);
         for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
         run_chunk(NC - 1, std::true_type{});
 
@@ -708,10 +787,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int nl = wn_o * 64 + j * 32 + 8 * q + 4 * (lane_o >> 5);
-                    const f32x4 bv = *(const f32x4*)(p.bias + cur.n0 + nl);
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bv[e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                     if (p.resid) {
                         const uint32_t* rp = (const uint32_t*)(sT + ml * PK_LDR + nl * 2);
                         const uint32_t r0 = rp[0], r1 = rp[1];
@@ -725,7 +803,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 }
             }
         }
+        // the accumulators are free: fetch the next tile's bias into them now, under the tile's stores
+        if (has_next) acc_from_bias(nxt.n0);
         rq_syncthreads();
+        RQ_CTP(61);
         float gs_[8], gq_[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
@@ -783,8 +864,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 }
             }
         }
+        RQ_CTP(63);
+#ifdef RQ_CONV_TRACE
+        ++trace_tile;
+#endif
         // ---- next tile: its first patch and weight tile are already in LDS, units 1, 2 wait in their register sets
         if (!has_next) break;
+        // Loads and stores share one in-flight counter whose returns are ordered only within each kind, so the first use of a
+        // pending load after this tile's stores makes the compiler wait for everything outstanding.  Have that wait HERE, where
+        // only the stores and long-issued loads (the next tile's weight tiles 1, 2 and bias) are in flight -- at the next tile's
+        // first tap it would also cover that tap's fresh prefetches (6400 instead of 1650 cycles for the tap,
+        // profiles/r02_conv_halo_barrier_timeline.txt).
+        rq_use(rw[1][0].x, rw[1][1].x, rw[2][0].x, rw[2][1].x);
+        rq_use(acc[0][0][0], acc[RPW - 1][1][15]);
         slot += wpx;
         cur = nxt;
         wn_cur = wn_nxt;
@@ -1229,3 +1321,10 @@ extern "C" int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const floa
     if (!rq_conv_in_mfma_supported(H, W, 3, CI_COUT)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "dbg_conv_in: shape %dx%d", H, W);
     return rq_launch_conv_in_mfma(x, w, bias, (bf16_t*)y, B, H, W, (hipStream_t)stream);
 }
+
+#ifdef RQ_CONV_TRACE
+extern "C" int rqamd_dbg_conv_trace(unsigned long long* out_host) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_conv_trace), sizeof(g_conv_trace)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "conv_trace: copy failed");
+    return RQAMD_OK;
+}
+#endif

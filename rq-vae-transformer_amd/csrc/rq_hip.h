@@ -126,6 +126,9 @@ static __device__ __forceinline__ int rq_readlane_i(int v, int lane) { return __
 // makes `x` opaque to the optimiser at this point (keeps loop-invariant address arithmetic from being hoisted out of a
 // persistent tile loop, where it would hold dozens of registers across the whole main loop)
 static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v"(x)); }
+// "these values are needed now": makes the compiler place its wait for the loads that produce them here
+static __device__ __forceinline__ void rq_use(unsigned a, unsigned b, unsigned c, unsigned d) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); }
+static __device__ __forceinline__ void rq_use(float a, float b) { asm volatile("" :: "v"(a), "v"(b)); }
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }   // median: clamp in one op

@@ -147,6 +147,8 @@ static inline unsigned long long rq_ballot(bool pred) {
 static inline int rq_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 static inline void rq_threadfence_block() {}
 static inline void rq_opaque(int&) {}
+static inline void rq_use(unsigned, unsigned, unsigned, unsigned) {}
+static inline void rq_use(float, float) {}
 static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
 static inline float rq_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
