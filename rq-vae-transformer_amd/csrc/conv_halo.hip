@@ -37,7 +37,7 @@ constexpr int HP_W = HT_W + 2;                     // halo patch of the plain co
 constexpr int H_BN = 128;
 constexpr int H_NTH = 512;
 constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
-constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + 2 * HW_BYTES;     // both variants allocate the plain conv's 119 KB
+constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + 3 * HW_BYTES;     // two patch buffers + three weight slots = 135 KB (every variant)
 
 // LDS byte offset of 16-byte chunk c8 of patch pixel (hy, hx).  The XOR swizzle depends on the patch COLUMN
 // only, so a tap's row shift (and the fragment row i, and the double-buffer index) are plain multiples of 128
@@ -53,16 +53,20 @@ static __device__ __forceinline__ unsigned halo_lds_off(int hy, int hx, int c8) 
 // [B][H/2][W/2][Cin], output pixel (oy, ox) tap (ky, kx) reads source pixel ((oy+ky-1) >> 1, (ox+kx-1) >> 1).  The
 // patch of an 8 x 32 output tile is then only (4+2) x (16+2) source pixels; the fragment address of a lane becomes
 // row wm + ((i+ky+1) >> 1) (still an immediate) and column (lane + kx + 1) >> 1 (one base register per kx).
-// TH = tile height: 8 (eight wavefronts, 4 x 2; double-buffered patch, 119 KB of LDS, one workgroup per CU) or 4 (four
-// wavefronts, 2 x 2; single patch buffer, 58 KB, TWO workgroups per CU).  Within a workgroup the phases are serial --
-// staging, LDS reads + MFMA and the epilogue each wait for the workgroup's barriers (ablation: 85 + 95 + 50 us of a
-// 230 us launch, nearly additive) -- so two independent workgroups per CU let one's staging / epilogue run under the
-// other's MFMAs.  The price: a 6 x 34 patch per 4 x 32 tile (1.59x the interior instead of 1.33x), every weight tile
-// staged for half as many pixels, and an extra barrier per chunk (the patch buffer is refilled in place).
-// TH = 16 (round 2, optional): sixteen rows per tile with FOUR rows per wavefront -- wave tile 128 pixels x 64 channels =
-// acc[4][2], 0.75 KB of LDS fragment reads per MFMA instead of 1 KB, 32 MFMAs per wavefront between barriers instead of 16,
-// a (16+2) x 34 patch = 1.20x the interior (1.33x at 8 rows) and every weight tile staged for twice the pixels.  The patch
-// (78 KB per 64-channel chunk) is single-buffered: the next chunk's pieces wait, already normalised, in their registers.
+//
+// Pipeline of one tap (round 2; the barrier timeline that led to it is profiles/r02_conv_halo_barrier_timeline.txt -- a tap
+// took ~1580 cycles for 1024 cycles of MFMA per SIMD: after every barrier the pipe waited for the first LDS fragments, and
+// after its last MFMA a wavefront still had its staging stores to issue before it could arrive at the next barrier):
+//   * the weight tiles go through a ring of THREE LDS slots (unit g in slot g % 3): during tap t slot t % 3 is read, slot
+//     (t+1) % 3 is already published, and slot (t+2) % 3 -- last read in tap t-1 -- is written at the START of the tap
+//     from the registers that fetched unit t+2 three taps ago (five units are in flight: two in LDS, three in registers);
+//   * the fragments of the NEXT tap's first k-step are read BEFORE the barrier that ends the tap (their slot and patch were
+//     published one barrier earlier), so the first four MFMAs after a barrier need no LDS access, and the wait for those
+//     reads overlaps the tap's last MFMAs;
+//   * the normalised patch pieces of the next chunk are stored in taps 2..7, one barrier before the first fragment read
+//     (end of tap 8) that touches them.
+// Tile heights of 4 and 16 rows (two workgroups per CU / 128 x 64 wave tiles) were measured in rounds 1-2 and removed
+// (profiles/r02_conv_halo_tile_height.txt, profiles/r02_conv_halo_variants.txt).
 #ifdef RQ_CONV_TRACE
 // Diagnostics build only (scripts/conv_trace.sh): shader-clock stamps of one workgroup's barrier arrivals / releases.
 __device__ unsigned long long g_conv_trace[8 * 64];
@@ -70,17 +74,9 @@ __device__ unsigned long long g_conv_trace[8 * 64];
 #else
 #define RQ_CT(slot) do { } while (0)
 #endif
-template <int FUSE_GN, int UPS, int TH>
-__global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
-    constexpr int NTH = (TH == 16 ? 8 : TH) * 64;  // threads: one wavefront per (row group, cout half)
-    constexpr int NJ = 2;                          // 32-channel blocks per wavefront
-    constexpr int RPW = TH == 16 ? 4 : 2;          // tile rows per wavefront
-    constexpr int NB_H = TH == 8 ? 2 : 1;          // patch buffers
-    constexpr int W_IT = 1024 / NTH;               // 16-byte chunks of a weight tile per thread
-    constexpr int TPX = TH * HT_W;                 // pixels per tile
-    // with two workgroups per CU the other one covers global latency: shallow prefetch, fewer registers (<= 256 needed)
-    constexpr int W_SETS = TH == 8 ? 3 : 1;   // weight tiles in flight (register sets)
-    constexpr bool RPRE = TH == 8;                 // residual tile prefetched into registers during the last taps
+template <int FUSE_GN, int UPS>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
+    constexpr int TH = HT_H, NTH = 512, RPW = 2, NJ = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3, W_SLOTS = 3;
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
     constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
     constexpr int HP_N = PW * PH;                  // patch pixels: 340, or 108 through the upsample
@@ -88,9 +84,12 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     constexpr int H_IT = (HP_N * 8 + NTH - 1) / NTH;
     RQ_DYN_SMEM(smem);
     char* sH = (char*)smem;                        // [2][HALO_BYTES]
-    char* sW = sH + NB_H * HALO_BYTES;             // [2][HW_BYTES]
+    char* sW = sH + 2 * HALO_BYTES;                // [3][HW_BYTES]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;       // (TH/RPW) x 2 wavefronts: rows (groups of RPW tile rows) x cout halves
+    const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 wavefronts: row pairs x cout halves
+#ifdef RQ_CONV_TRACE
+    if (blockIdx.x == RQ_CONV_TRACE && lane == 0) g_conv_trace[wave * 64 + 58] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- tile decode: contiguous band of tiles per XCD (neighbouring tiles share halo rows in that L2)
     const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
@@ -107,8 +106,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 
     // ---- halo staging bookkeeping (loop-invariant), ONE packed register per piece: source pixel index inside the image
     // (16 bits: H * W <= 65536, clamped into the image so that every load is readable), LDS offset in 16-byte units
-    // (13 bits), "inside the image" (bit 29: else the piece is stored as zeros) and "piece exists" (bit 30).  Kept packed
-    // because the 16-row variant has 10 pieces per thread next to 128 accumulator registers.
+    // (13 bits), "inside the image" (bit 29: else the piece is stored as zeros) and "piece exists" (bit 30)
     unsigned hd[H_IT];
     const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;                       // source image
 #pragma unroll
@@ -142,8 +140,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     const char* gWt = (const char*)p.w;
     const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
 
-    // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7), loaded
-    // with the patch so that no global-load latency sits between the taps
+    // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7)
     f32x4 gs[4];
     auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
     auto load_gs = [&](int c) {
@@ -151,11 +148,6 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 #pragma unroll
             for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
         }
-    };
-    auto load_halo = [&](int c, rq_u128* rh) {
-#pragma unroll
-        for (int it = 0; it < H_IT; ++it) load_halo_piece(c, rh, it);
-        load_gs(c);
     };
     // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS.  The fused form is spread over
     // the taps of a chunk (one piece per tap) so that its VALU / transcendental work issues under the MFMAs;
@@ -182,23 +174,25 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
         if (!h_ok(it)) v = zero128();              // zero padding of the (normalised) input
         return v;
     };
-    // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS
-    auto store_halo_piece = [&](int c, int buf, const rq_u128* rh, int it) {
-        if (!h_in(it)) return;
-        st128(sH + buf * HALO_BYTES + h_loff(it), halo_piece_value(rh, it));
-    };
-    auto store_halo = [&](int c, int buf, const rq_u128* rh) {
-#pragma unroll
-        for (int it = 0; it < H_IT; ++it) store_halo_piece(c, buf, rh, it);
+    // a quarter of that: channels 2e, 2e+1 of piece `it` (one 32-bit word), for the k-step regions of the tap loop
+    auto halo_piece_word = [&](rq_u128* rh, int it, int e) {
+        uint32_t& w = e == 0 ? rh[it].x : e == 1 ? rh[it].y : e == 2 ? rh[it].z : rh[it].w;
+        if (FUSE_GN) {
+            const f32x4 ss = gs[e];                                       // (scale, shift) x 2 channels
+            const float a = fmaf(__uint_as_float(w << 16), ss[0], ss[1]), b = fmaf(__uint_as_float(w & 0xffff0000u), ss[2], ss[3]);
+            w = pack_bf16x2(a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a)),
+                            b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b)));
+        }
+        if (!h_ok(it)) w = 0u;                     // zero padding of the (normalised) input
     };
     auto load_w = [&](int c, int tap, rq_u128* rw) {
         const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
     };
-    auto store_w = [&](int buf, const rq_u128* rw) {
+    auto store_w = [&](int wslot, const rq_u128* rw) {
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) st128(sW + buf * HW_BYTES + w_loff[i], rw[i]);
+        for (int i = 0; i < W_IT; ++i) st128(sW + wslot * HW_BYTES + w_loff[i], rw[i]);
     };
 
     // the accumulators start from the bias (transposed tile: register 4q+e of block j is output channel
@@ -223,131 +217,139 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     for (int kx = 0; kx < 3; ++kx)
         rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
 
-    auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
-        const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES);
-        const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
+    auto load_frags = [&](int hbuf, int wslot, int ky, int kx, int ks, bf16x8* af, bf16x8* bfr) {
+        const char* hb = sH + ((rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES)) ^ (unsigned)(ks << 5));
+        const char* wb = sW + ((rd_w0 + (unsigned)(wslot * HW_BYTES)) ^ (unsigned)(ks << 5));
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[RPW], bfr[NJ];
-            const char* hb = sH + (ha ^ (unsigned)(ks << 5));
-            const char* wb = sW + (wa ^ (unsigned)(ks << 5));
+        for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
+        for (int j = 0; j < NJ; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
+    };
+    // Two fragment sets in ping-pong: while the MFMAs of k-step ks run on set ks & 1, the reads of k-step ks + 1 fill the other
+    // (left to itself the compiler re-used ONE set -- read, wait, four MFMAs, read, wait ... -- and every k-step exposed the LDS
+    // latency: a tap took ~1500 cycles per SIMD for 1024 cycles of MFMA work, profiles/r02_conv_halo_barrier_timeline.txt).
+    // The tap's last k-step reads the NEXT tap's first fragments into set 0, before the barrier that ends the tap.
+    bf16x8 fa[2][RPW], fb[2][NJ];
+    auto mfma_step = [&](int set) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
-            for (int i = 0; i < RPW; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);   // transposed tile
-            // 128 accumulator registers leave room for two k-steps of fragments (48 registers), not for the four the
-            // scheduler would like to hoist: fence every k-step (the co-resident wavefront covers the LDS latency)
-            if (RPW == 4) rq_sched_barrier();
-        }
+            for (int j = 0; j < NJ; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j]);   // transposed tile
     };
 
-    // ---- main loop over (64-channel chunk, tap); weights double-buffered per tap, halo per chunk
-    const int NC = p.Cin / 64;
-    // Weight tiles are prefetched THREE (chunk, tap) units ahead through a rotating set of registers (unit g lives
-    // in set g % 3; 9 taps per chunk keep the rotation static under the unrolled tap loop): with a one-tap
-    // distance the L2 round trip (~1 us under load) was longer than a tap's 16 MFMAs and every tap stalled.
+    // ---- main loop over (64-channel chunk, tap).  Weight unit g = c * 9 + tap lives in register set g % 3 from the tap
+    // g - 5 that fetches it to the start of tap g - 2 that stores it into LDS slot g % 3 (9 taps per chunk keep both
+    // rotations static under the unrolled tap loop): the L2 round trip (~1 us under load) is longer than a tap.
+    const int NC = p.Cin / 64, last_c = NC - 1;
     rq_u128 rh[H_IT], rw[W_SETS][W_IT];
-    const int last_c = NC - 1;
-    auto load_unit = [&](int c, int tap, rq_u128* r) {      // (c, tap) may run past the end: clamp (harmless reload)
+    auto load_unit = [&](int c, int tap, rq_u128* r) {      // unit (c, tap), tap may run into the next chunk; false: past the end
         if (tap >= 9) { tap -= 9; ++c; }
-        if (c > last_c) { c = last_c; tap = 8; }
+        if (c > last_c) return false;
         load_w(c, tap, r);
+        return true;
     };
-    load_halo(0, rh);
+    // prologue: patch of chunk 0, weight units 0..4 (0, 1 go to LDS now; 2, 3, 4 wait in register sets 2, 0, 1)
+    {
+        rq_u128 r01[2][W_IT];
 #pragma unroll
-    for (int u = 0; u < W_SETS; ++u) load_unit(0, u, rw[u]);
-    RQ_CT(0);
-    store_halo(0, 0, rh);
-    store_w(0, rw[0]);
+        for (int it = 0; it < H_IT; ++it) load_halo_piece(0, rh, it);
+        load_gs(0);
+        load_w(0, 0, r01[0]);
+        load_w(0, 1, r01[1]);
+        load_w(0, 2, rw[2]);
+        load_w(0, 3, rw[0]);
+        load_w(0, 4, rw[1]);
+        RQ_CT(0);
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it)
+            if (h_in(it)) st128(sH + h_loff(it), halo_piece_value(rh, it));
+        store_w(0, r01[0]);
+        store_w(1, r01[1]);
+    }
     rq_syncthreads();
     RQ_CT(1);
-    int wbuf = 0;
-    // residual tile (epilogue operand): its 8 pieces per thread are fetched during the LAST chunk's taps, where the
-    // patch registers would otherwise reload a chunk nobody needs, so the epilogue starts with the data in hand
-    // (its global round trip was exposed: one workgroup per CU, nothing else to run meanwhile)
+    load_frags(0, 0, 0, 0, 0, fa[0], fb[0]);
+    // residual tile (epilogue operand): its 8 pieces per thread are fetched one per tap during the LAST chunk, where the
+    // patch registers are idle, so the epilogue starts with the data in hand
     constexpr int CPR = H_BN / 8;
     constexpr int R_IT = TPX * CPR / NTH;          // 8
-    rq_u128 rr[RPRE ? R_IT : 1];
+    static_assert(R_IT <= 8, "one residual piece per tap");
+    rq_u128 rr[R_IT];
     const bf16_t* rsrc = p.resid;
     // one chunk of the reduction; LAST (compile time): no next patch to stage -- fetch the residual instead
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const int hbuf = NB_H == 2 ? c & 1 : 0;
-        constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
+        const int hbuf = c & 1;
+        // next chunk's patch: one piece per tap, normalised and stored in taps FIRST.. (6 pieces: taps 2..7; through the
+        // upsample 2 pieces: taps 6, 7), fetched three taps earlier where the chunk is long enough
+        constexpr int NPT = H_IT, FIRST = 8 - NPT;
+        static_assert(FIRST >= 0, "one patch piece per tap");
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            // prefetch: unit g+3 into the set unit g just left; next chunk's halo patch once, a few taps ahead
-            // Global loads are spread over the taps (every workgroup of a launch is in the same phase: eight residual pieces or six
-            // patch pieces per thread issued in ONE tap are a 16-MB chip-wide request burst that stalled the issuing wavefronts for
-            // ~1800 cycles, profiles/r02_conv_halo_barrier_timeline.txt): the weight tile three units ahead; patch piece `it` of the
-            // next chunk three taps before the tap that normalises and stores it; one residual piece per tap of the last chunk.
-            // (The last chunk's taps 6..8 have no weight tile left to fetch, and its last tap none to stage.)
-            if (!(LAST && tap + W_SETS >= 9)) load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
+            // ---- stage: weight unit (c, tap + 2) from its registers into the slot tap t-1 just left
+            const bool have_w2 = !(LAST && tap + 2 >= 9);
+#ifndef RQ_CONV_ABLATE_STAGE        // diagnostics build: no weight staging stores (results are wrong)
+            if (have_w2) store_w((tap + 2) % W_SLOTS, rw[(tap + 2) % W_SETS]);
+#endif
+            // ---- global prefetches, spread over the taps (every workgroup of a launch is in the same phase: eight residual or
+            // six patch pieces per thread issued in ONE tap are a 16-MB chip-wide request burst that stalled the issuing
+            // wavefronts for ~1800 cycles): weight unit tap + 5 into the registers just stored; patch piece `it` of the next
+            // chunk three taps before the tap that normalises it; one residual piece per tap of the last chunk
+            if (have_w2) (void)load_unit(c, tap + 5, rw[(tap + 2) % W_SETS]);
             if (!LAST) {
                 if (tap == 0) load_gs(c + 1);
 #pragma unroll
                 for (int it = 0; it < H_IT; ++it) {
-                    const int t_use = FIRST + it / PPT, t_load = t_use >= 3 ? t_use - 3 : 0;
+                    const int t_use = FIRST + it, t_load = t_use >= 3 ? t_use - 3 : 0;
                     if (t_load == tap) load_halo_piece(c + 1, rh, it);
                 }
             }
-            if (RPRE && LAST && tap >= 1 && p.resid) {     // uniform
-                constexpr int RPT = (R_IT + 7) / 8;        // residual pieces per tap
-#pragma unroll
-                for (int k = (tap - 1) * RPT; k < tap * RPT && k < R_IT; ++k) {
-                    const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-                    const int ty = ml / HT_W, tx = ml - ty * HT_W;
-                    const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-                    rr[k] = ld128(rsrc + pix * p.Cout + n0 + nl);
-                }
+            if (LAST && tap >= 1 && p.resid) {             // uniform
+                const int k = tap - 1;
+                const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
+                const int ty = ml / HT_W, tx = ml - ty * HT_W;
+                const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
+                rr[k] = ld128(rsrc + pix * p.Cout + n0 + nl);
             }
             rq_sched_barrier();
-            // next chunk's patch: PPT pieces per tap over the last taps of the chunk (8 rows: pieces 0..5 in taps 3..8, the
-            // loads were issued three taps earlier; 16 rows: two pieces per tap in taps 4..8).  The fused GroupNorm+SiLU
-            // arithmetic of a piece sits in the same scheduling region as the tap's MFMAs (no fence in between) so that its
-            // VALU / transcendental instructions issue in the MFMAs' shadow.
-            const bool ptap = !LAST && tap >= FIRST;
-            // (the finished piece replaces the raw one in its register: no second copy)
+            // ---- four k-step regions: reads of the next k-step (the last one: of the coming tap's first k-step -- its slot and
+            // patch were published one barrier ago), four MFMAs, and a quarter of the fused GroupNorm+SiLU arithmetic of the tap's
+            // patch piece, whose VALU / transcendental instructions issue in the MFMAs' shadow
+            const int pit = tap - FIRST;
+            const bool ptap = !LAST && pit >= 0 && pit < H_IT;
+            const int pi = ptap ? pit : 0;
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int it = (tap - FIRST) * PPT + k;
-                if (ptap && it < H_IT) rh[it < H_IT ? it : 0] = halo_piece_value(rh, it < H_IT ? it : 0);
-            }
-            compute(hbuf, wbuf, ky, kx);
-            if (FUSE_GN && ptap) {
-                // pipeline: each MFMA (8 passes) carries a slice of the pieces' ~100 VALU instructions each
+            for (int ks = 0; ks < 4; ++ks) {
+#ifdef RQ_CONV_ABLATE_LDS          // diagnostics build: no fragment reads (the MFMAs reuse the prologue's fragments; results are wrong)
+                if (false) {}
+                else
+#endif
+                if (ks < 3) load_frags(hbuf, tap % W_SLOTS, ky, kx, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                else if (tap < 8) load_frags(hbuf, (tap + 1) % W_SLOTS, (tap + 1) / 3, (tap + 1) % 3, 0, fa[0], fb[0]);
+                else if (!LAST) load_frags(hbuf ^ 1, 0, 0, 0, 0, fa[0], fb[0]);
+                mfma_step(ks & 1);
+                if (ptap) halo_piece_word(rh, pi, ks);
+                // issue order inside the region: the fragment reads FIRST (a full k-step of MFMAs covers their latency), then the
+                // MFMAs, each carrying a slice of the piece's VALU work
+                rq_sched_group(0x100, RPW + NJ);
 #pragma unroll
-                for (int g = 0; g < 4 * RPW * NJ; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
+                for (int m = 0; m < RPW * NJ; ++m) {
+                    rq_sched_group(0x008, 1);
+                    if (FUSE_GN && ptap) rq_sched_group(0x002, 7);
+                }
+                rq_sched_barrier();
             }
-            if (!(LAST && tap == 8)) store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int it = (tap - FIRST) * PPT + k;
-                if (!(ptap && it < H_IT)) continue;
-                if (NB_H == 2) { if (h_in(it)) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff(it), rh[it]); }
-                // single buffer: the finished piece waits in its register until the chunk's last tap has been read
-            }
+            if (ptap) { if (h_in(pi)) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff(pi), rh[pi]); }
             RQ_CT(2 + (c * 9 + tap) * 2);
             rq_syncthreads();
             RQ_CT(3 + (c * 9 + tap) * 2);
-            wbuf ^= 1;
-        }
-        if (NB_H == 1 && !LAST) {                          // every wave is past its reads of this chunk: refill the buffer
-#pragma unroll
-            for (int it = 0; it < H_IT; ++it)
-                if (h_in(it)) st128(sH + h_loff(it), rh[it]);
-            rq_syncthreads();
         }
     };
     for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
     run_chunk(NC - 1, std::true_type{});
 
-    // ---- epilogue: bias (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
+    // ---- epilogue: (+ residual before the single rounding), packed bf16 tile in LDS, 16-byte stores
     constexpr int LDR = H_BN * 2 + 16;
     static_assert(TPX * LDR + 4096 <= 160 * 1024, "epilogue tile must fit the CU's LDS (the launcher allocates max(staging, epilogue))");
     char* sT = (char*)smem;
@@ -359,13 +361,7 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
 #pragma unroll
         for (int k = 0; k < R_IT; ++k) {
             const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-            if (RPRE) {
-                st128(sT + ml * LDR + nl * 2, rr[k]);
-            } else {
-                const int ty = ml / HT_W, tx = ml - ty * HT_W;
-                const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-                st128(sT + ml * LDR + nl * 2, ld128(p.resid + pix * p.Cout + n0 + nl));
-            }
+            st128(sT + ml * LDR + nl * 2, rr[k]);
         }
         rq_syncthreads();
     }
@@ -373,7 +369,6 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
     for (int i = 0; i < RPW; ++i) {
         const int ty = wm * RPW + i, tx = lane & 31;
         const int ml = ty * HT_W + tx;
-        const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -459,6 +454,9 @@ __global__ __launch_bounds__((TH == 16 ? 8 : TH) * 64, TH == 4 ? 2 : 1) void con
         }
     }
     RQ_CT(63);
+#ifdef RQ_CONV_TRACE
+    if (blockIdx.x == RQ_CONV_TRACE && lane == 0) g_conv_trace[wave * 64 + 59] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1198,28 +1196,11 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
     }
 }
 
-// tile height of the halo conv (see the kernel): 8 = one 8-wave workgroup per CU (default), 4 = two 4-wave workgroups.
-// Measured (profiles/r01_conv_halo_tile_height.txt): equal on the 128-channel 256^2 layers, the 4-row variant 10 %
-// slower on the 256-channel layers -- the expected overlap of one workgroup's staging / epilogue with the other's MFMAs
-// is eaten by the larger halo (1.59x vs 1.33x), twice the weight staging per pixel and the shallower prefetch.
-// 16 (round 2) = four rows per wavefront (128 x 64 wave tiles, 0.75 KB of LDS reads per MFMA), single-buffered patch whose next
-// chunk waits in registers: +3..5 % on the plain conv (978 vs 929 TF at 128->128 @256^2), but with GroupNorm+SiLU fused the
-// ten patch pieces + 128 accumulators + scale/shift registers exceed 256 VGPRs and the spills cost 4-11 %
-// (profiles/r02_conv_halo_tile_height.txt) -- every ResnetBlock conv of the decoder is a fused one, so 8 stays the default.
-// (The same 16-row tile on FOUR wavefronts -- 128 x 128 wave tiles, accumulators in AGPRs, half the LDS reads per MFMA -- was 20 %
-// slower: with one wavefront per SIMD nothing overlaps the compiler-scheduled stream; profiles/r02_conv_halo_variants.txt, removed.)
-static int halo_th() {
-    static const int env = getenv("RQAMD_HALO_TH") ? atoi(getenv("RQAMD_HALO_TH")) : 0;
-    static const int th = (env == 4 || env == 16) ? env : 8;
-    return th;
-}
-
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
-    return H % 16 == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64 && H * W <= 65536;
+    return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64 && H * W <= 65536;
 }
 
-int rq_conv_halo_stat_tiles(int H, int W) { return (H / halo_th()) * (W / HT_W); }
-static int g_conv_halo_dbg_th = 0;          // diagnostics entry only: force a tile height
+int rq_conv_halo_stat_tiles(int H, int W) { return (H / HT_H) * (W / HT_W); }
 static int g_conv_halo_dbg_pk = 0;          // diagnostics entry only: +1 / -1 force the persistent / per-tile form of the 8-row kernel
 static int g_conv_halo_dbg_wpx = 0;         // diagnostics entry only: workgroups per XCD of the persistent form
 // Measured (profiles/r02_conv_halo_variants.txt): the persistent form gains 4-7 % where the tile is short and carries no fused
@@ -1232,21 +1213,19 @@ static bool halo_persistent(int ups) {
     return env < 0 ? ups != 0 : env != 0;
 }
 
-template <int TH>
 static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
-    constexpr size_t patch = (size_t)(TH + 2) * HP_W * 128, stage = (TH == 8 ? 2 : 1) * patch + 2 * HW_BYTES;
-    constexpr int NTHR = (TH == 16 ? 8 : TH) * 64;
-    constexpr size_t epi = (size_t)TH * HT_W * (H_BN * 2 + 16);
-    const size_t smem = stage > epi ? stage : epi;
+    constexpr int TH = HT_H, NTHR = 512;
+    constexpr size_t smem = H_SMEM_BYTES;
+    static_assert((size_t)TH * HT_W * (H_BN * 2 + 16) + 4096 <= H_SMEM_BYTES, "the epilogue tile overlays the operand buffers");
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (TH == 8 && halo_persistent(ups)) {
+    if (halo_persistent(ups)) {
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
         static int cus_per_xcd[16];
@@ -1268,9 +1247,9 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
         else RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
         return rq_check_launch("conv3x3_halo_pk_kernel");
     }
-    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, TH>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
     return rq_check_launch("conv3x3_halo_kernel");
 }
 
@@ -1282,8 +1261,7 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    const int th = g_conv_halo_dbg_th ? g_conv_halo_dbg_th : halo_th();
-    return th == 16 ? launch_conv_halo_th<16>(a, ups, s) : th == 8 ? launch_conv_halo_th<8>(a, ups, s) : launch_conv_halo_th<4>(a, ups, s);
+    return launch_conv_halo_th(a, ups, s);
 }
 
 // nchunk_have > 0: `part` already holds that many partials per image (written by the producing conv's epilogue)
@@ -1299,12 +1277,10 @@ int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const 
 extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, const float* gn, const void* resid,
                                         int B, int H, int W, int Cin, int Cout, int ups, void* out, float* stats, void* stream) {
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
-    g_conv_halo_dbg_th = (ups & 2) ? 8 : (ups & 4) ? 4 : (ups & 8) ? 16 : 0;      // ups bits 1 / 2 / 3: force the 8- / 4- / 16-row tile variant
     g_conv_halo_dbg_pk = (ups & 16) ? 1 : (ups & 32) ? -1 : 0;                    // bits 4 / 5: persistent / per-tile form of the 8-row kernel
     g_conv_halo_dbg_wpx = (ups >> 8) & 0xff;                                      // bits 8..15: workgroups per XCD (0 = one per CU)
     const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
                                        Cin, Cout, ups & 1, (hipStream_t)stream);
-    g_conv_halo_dbg_th = 0;
     g_conv_halo_dbg_pk = 0;
     g_conv_halo_dbg_wpx = 0;
     return rc;

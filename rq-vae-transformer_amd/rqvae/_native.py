@@ -252,10 +252,10 @@ def dbg_conv(x, w, bias=None, resid=None, ksize=3, stride=1, ups=0, bm=0, bn=0, 
     return out
 
 
-def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=False, tile_h=0, persistent=None, wpx=0):
+def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=False, persistent=None, wpx=0):
     """diagnostics: halo-reuse 3x3 conv; x (B,H,W,Cin) bf16 (or (B,H/2,W/2,Cin) with ups), w (Cout,3,3,Cin) bf16, gn
     (B,Cin,2) fp32 or None; stats (B, (H/8)*(W/32), 32, 2) fp32 receives the per-tile GroupNorm partial sums.
-    persistent True / False forces the persistent / per-tile form of the 8-row kernel (None: the default), wpx its
+    persistent True / False forces the persistent / per-tile form of the kernel (None: the default), wpx the persistent form's
     workgroups per XCD (0: one per CU)."""
     B, H, W, Cin = x.shape
     if ups:
@@ -264,8 +264,8 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
     check(lib().rqamd_dbg_conv_halo_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias, torch.float32), ptr(gn), ptr(resid),
-                                         B, H, W, Cin, Cout, (1 if ups else 0) | (2 if tile_h == 8 else 4 if tile_h == 4 else 8 if tile_h == 16 else 0)
-                                         | (0 if persistent is None else 16 if persistent else 32) | ((int(wpx) & 0xff) << 8),
+                                         B, H, W, Cin, Cout,
+                                         (1 if ups else 0) | (0 if persistent is None else 16 if persistent else 32) | ((int(wpx) & 0xff) << 8),
                                          ptr(out), ptr(stats), stream_of(x)))
     return out
 

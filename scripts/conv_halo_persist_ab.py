@@ -44,8 +44,8 @@ for B, H, Cin, Cout, ups in shapes:
                                          ('resid', dict(resid=resid)))
     for name, kw in cases:
         st = kw.pop('st', False)
-        fa = lambda: _native.dbg_conv_halo(x, w, bias, out=o_a, stats=s_a if st else None, ups=bool(ups), tile_h=8, persistent=False, **kw)
-        fb = lambda: _native.dbg_conv_halo(x, w, bias, out=o_b, stats=s_b if st else None, ups=bool(ups), tile_h=8, persistent=True, **kw)
+        fa = lambda: _native.dbg_conv_halo(x, w, bias, out=o_a, stats=s_a if st else None, ups=bool(ups), persistent=False, **kw)
+        fb = lambda: _native.dbg_conv_halo(x, w, bias, out=o_b, stats=s_b if st else None, ups=bool(ups), persistent=True, **kw)
         ta, tb = ab(fa, fb)
         same = torch.equal(o_a, o_b) and (not st or torch.equal(s_a, s_b))
         # race screen: repeated launches of the persistent form must be bitwise stable

@@ -16,6 +16,6 @@ out = torch.empty_like(resid)
 st = torch.zeros((B, (H // 8) * (H // 32), 32, 2), device=dev)
 pers = os.environ.get('RQ_PERSIST', '0') == '1'
 for _ in range(4):
-    _native.dbg_conv_halo(x, w, bias, out=out, tile_h=8, persistent=pers)
-    _native.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st, out=out, tile_h=8, persistent=pers)
+    _native.dbg_conv_halo(x, w, bias, out=out, persistent=pers)
+    _native.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st, out=out, persistent=pers)
 torch.cuda.synchronize()

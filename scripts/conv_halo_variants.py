@@ -8,7 +8,7 @@ import torch
 from rqvae import _native
 
 dev = 'cuda'
-VARIANTS = (('th8', dict(tile_h=8, persistent=False)), ('th8p', dict(tile_h=8, persistent=True)), ('th16', dict(tile_h=16)))
+VARIANTS = (('th8', dict(persistent=False)), ('th8p', dict(persistent=True)))
 
 
 def timed(fn, reps):
@@ -38,7 +38,7 @@ for B, H, Cin, Cout, ups in shapes:
         st = kw.pop('st', False)
         fns = {}
         for vn, vk in VARIANTS:
-            th = vk['tile_h']
+            th = 8
             stats = torch.zeros((B, (H // th) * (H // 32), 32, 2), device=dev) if st else None
             fns[vn] = (lambda vk=vk, vn=vn, stats=stats: _native.dbg_conv_halo(x, w, bias, out=outs[vn], stats=stats, ups=bool(ups), **vk, **kw))
         for f in fns.values():

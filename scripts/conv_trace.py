@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch
 from rqvae import _native
-_native.LIB_PATH = os.path.join(ROOT, 'rq-vae-transformer_amd', 'librqamd_trace.so')
+_native.LIB_PATH = os.path.join(ROOT, 'rq-vae-transformer_amd', os.environ.get('RQ_TRACE_LIB', 'librqamd_trace.so'))
 lib = _native.lib()
 dev = 'cuda'
-B, H, Cin, Cout = 8, 256, 128, 128
+B, H, Cin, Cout = int(os.environ.get('RQ_B', 8)), int(os.environ.get('RQ_H', 256)), 128, 128
 x = torch.randn((B, H, H, Cin), device=dev).to(torch.bfloat16)
 w = (torch.randn((Cout, 3, 3, Cin), device=dev) * 0.05).to(torch.bfloat16)
 bias = torch.randn((Cout,), device=dev)
@@ -22,7 +22,7 @@ fn.argtypes = [C.POINTER(C.c_ulonglong)]
 PERS = os.environ.get('RQ_PERSIST', '0') == '1'
 for name, kw in (('plain', {}), ('GN+resid+stats', dict(gn=gn, resid=resid, stats=st))):
     for rep in range(3):
-        _native.dbg_conv_halo(x, w, bias, out=out, tile_h=8, persistent=PERS, **kw)
+        _native.dbg_conv_halo(x, w, bias, out=out, persistent=PERS, **kw)
     torch.cuda.synchronize()
     assert fn(buf) == 0
     t = [[buf[wv * 64 + i] for i in range(64)] for wv in range(8)]
@@ -39,5 +39,6 @@ for name, kw in (('plain', {}), ('GN+resid+stats', dict(gn=gn, resid=resid, stat
         line += ' taps: ' + ' '.join(f'{c}/{w_}' for c, w_ in zip(comp, wait))
         line += f' | epilogue: to pack barrier {r[61] - r[37]:6d}, to end {r[63] - r[37]:6d} | tile total {r[63] - r[0]:6d}'
         print(line)
+    print(f'   clock: {(t[0][63] - t[0][0]) / max(1, (t[0][59] - t[0][58])) * 100:.0f} MHz shader ticks (s_memtime) per 100 MHz s_memrealtime')
     print(f'   mean compute {sum(sum(t[wv][2 + 2 * k] - (t[wv][1] if k == 0 else t[wv][1 + 2 * k]) for k in range(18)) for wv in range(8)) / 144:.0f}'
           f' mean wait {sum(sum(t[wv][3 + 2 * k] - t[wv][2 + 2 * k] for k in range(18)) for wv in range(8)) / 144:.0f}')

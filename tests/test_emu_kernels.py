@@ -396,8 +396,8 @@ def test_emu_gemm_skinny(nat):
 
 
 def test_emu_conv_halo(nat):
-    """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual;
-    against the oracle's conv2d / silu on the bf16-rounded operands."""
+    """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual, one and two
+    channel chunks; against the oracle's conv2d / silu on the bf16-rounded operands."""
     from oracle.vae import conv2d, silu
     rng = np.random.default_rng(4)
     B, H, W, Cin, Cout = 1, 64, 64, 64, 128
@@ -414,24 +414,31 @@ def test_emu_conv_halo(nat):
     xn = silu(xf * gn.numpy()[:, None, None, :, 0] + gn.numpy()[:, None, None, :, 1])
     xn = bf(xn.astype(np.float32)).float().numpy()                     # the kernel rounds the activated input to bf16
     ref_gn = conv2d(xn, wf, bias.numpy()) + resid.float().numpy()
-    for th in (16, 8, 4):        # 16 x 32 tiles (4 rows per wave, single buffer), 8 x 32 (double-buffered patch), 4 x 32 (4 waves)
-        out = nat.dbg_conv_halo(x, w, bias, tile_h=th).float().numpy()
-        assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max(), th
-        stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), dtype=torch.float32)
-        out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats, tile_h=th).float().numpy()
-        assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max(), th
-        # epilogue statistics: per (th x 32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
-        t = out.reshape(B, H // th, th, W // 32, 32, 32, Cout // 32).astype(np.float64)
-        want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
-        assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max(), th
+    th = 8
+    out = nat.dbg_conv_halo(x, w, bias).float().numpy()
+    assert np.abs(out - ref_plain).max() < 0.02 * np.abs(ref_plain).max()
+    stats = torch.zeros((B, (H // th) * (W // 32), 32, 2), dtype=torch.float32)
+    out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=stats).float().numpy()
+    assert np.abs(out - ref_gn).max() < 0.02 * np.abs(ref_gn).max()
+    # epilogue statistics: per (8 x 32 tile, group of Cout/32 channels) sum and sum of squares of the bf16 output
+    t = out.reshape(B, H // th, th, W // 32, 32, 32, Cout // 32).astype(np.float64)
+    want = np.stack([t.sum((2, 4, 6)), (t * t).sum((2, 4, 6))], -1).reshape(B, -1, 32, 2)
+    assert np.abs(stats.numpy() - want).max() < 1e-3 * np.abs(want).max()
+    # two channel chunks (the patch double buffer and the weight ring wrap) and two cout tiles
+    x2 = bf(rng.standard_normal((1, 64, 32, 128)).astype(np.float32))
+    w2 = bf((0.05 * rng.standard_normal((256, 3, 3, 128))).astype(np.float32))
+    b2 = T(rng.standard_normal(256).astype(np.float32))
+    ref2 = conv2d(x2.float().numpy(), np.transpose(w2.float().numpy(), (0, 3, 1, 2)), b2.numpy())
+    out = nat.dbg_conv_halo(x2, w2, b2, persistent=False).float().numpy()
+    assert np.abs(out - ref2).max() < 0.02 * np.abs(ref2).max()
     # Upsample.conv (layers.py:31-35): nearest 2x folded into the patch staging; 32x32 source -> 64x64 output
     xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
     xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
     ref_up = conv2d(xu, wf, bias.numpy())
-    for th in (16, 8, 4):
-        out = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=th).float().numpy()
+    for pers in (False, True):
+        out = nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=pers).float().numpy()
         assert out.shape == (B, H, W, Cout)
-        assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), th
+        assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), pers
 
 
 def test_emu_conv_halo_persistent(nat):
@@ -450,26 +457,26 @@ def test_emu_conv_halo_persistent(nat):
         resid = bf(rng.standard_normal((B, H, W, Cout)).astype(np.float32))
         gn = T(np.stack([1.0 + 0.2 * rng.standard_normal((B, Cin)), 0.3 * rng.standard_normal((B, Cin))], -1).astype(np.float32))
         nt = (H // 8) * (W // 32)
-        ref_plain = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=False)
+        ref_plain = nat.dbg_conv_halo(x, w, bias, persistent=False)
         st_ref = torch.zeros((B, nt, 32, 2), dtype=torch.float32)
-        ref_fused = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st_ref, tile_h=8, persistent=False)
+        ref_fused = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st_ref, persistent=False)
         for wpx in (1, 3):
-            out = nat.dbg_conv_halo(x, w, bias, tile_h=8, persistent=True, wpx=wpx)
+            out = nat.dbg_conv_halo(x, w, bias, persistent=True, wpx=wpx)
             assert torch.equal(out, ref_plain), (Cin, Cout, wpx)
             st = torch.zeros_like(st_ref)
-            out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st, tile_h=8, persistent=True, wpx=wpx)
+            out = nat.dbg_conv_halo(x, w, bias, gn=gn, resid=resid, stats=st, persistent=True, wpx=wpx)
             assert torch.equal(out, ref_fused), (Cin, Cout, wpx)
             assert torch.equal(st, st_ref), (Cin, Cout, wpx)
         # no residual, no statistics through the fused kernel (conv1 of a ResnetBlock)
-        a = nat.dbg_conv_halo(x, w, bias, gn=gn, tile_h=8, persistent=False)
-        b = nat.dbg_conv_halo(x, w, bias, gn=gn, tile_h=8, persistent=True, wpx=1)
+        a = nat.dbg_conv_halo(x, w, bias, gn=gn, persistent=False)
+        b = nat.dbg_conv_halo(x, w, bias, gn=gn, persistent=True, wpx=1)
         assert torch.equal(a, b)
     xs = bf(rng.standard_normal((1, 32, 32, 128)).astype(np.float32))
     w = bf((0.05 * rng.standard_normal((128, 3, 3, 128))).astype(np.float32))
     bias = T(rng.standard_normal(128).astype(np.float32))
-    a = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=False)
+    a = nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=False)
     for wpx in (1, 0):
-        b = nat.dbg_conv_halo(xs, w, bias, ups=True, tile_h=8, persistent=True, wpx=wpx)
+        b = nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=True, wpx=wpx)
         assert torch.equal(a, b), wpx
 
 
