@@ -154,6 +154,23 @@ int rqamd_rqt_logits(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, in
  * when block_size_cond <= 1). */
 int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64_t* cond, int batch,
                       const float* const* codebooks, float* logits_out, float* cond_logits_out, void* stream);
+/* Stepping form of rqamd_rqt_sample for callers that draw the samples themselves -- e.g. torch.multinomial on the filtered
+ * probabilities, which consumes the device generator exactly as the reference's sample_from_logits does
+ * (rqvae/utils/utils.py:112; RQTransformer.sample transformers.py:346-364 is this loop):
+ *   step_begin     copies partial / cond into the handle, runs the conditioning prefix; codebooks as for rqamd_rqt_sample
+ *                  (the pointer ARRAY is copied, the codebooks must stay alive until step_end)
+ *   step_logits    logits (batch, vocab_size) fp32 of step (pos, d) given the codes written so far; steps must come in order
+ *                  (pos ascending, d = 0..D-1); d < 0 runs only the body stack of that position (positions before start_loc,
+ *                  whose codes are given: KV cache only).  *logits_dev points into the handle's workspace and is valid until
+ *                  the next call on the handle.  Columns >= vocab_sizes[d] are masked to -inf (LogitMask).
+ *   step_set_code  writes codes[batch] as code (pos, d) of every image
+ *   step_end       copies the codes (batch,H,W,D) out (codes_out may be NULL) and ends the sequence.
+ * Any other call on the handle ends a sequence in progress. */
+int rqamd_rqt_step_begin(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, int batch,
+                         const float* const* codebooks, void* stream);
+int rqamd_rqt_step_logits(rqamd_rqt* h, int pos, int d, const float** logits_dev, void* stream);
+int rqamd_rqt_step_set_code(rqamd_rqt* h, int pos, int d, const int64_t* codes, void* stream);
+int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream);
 /* timing hook for bench.py: average device time (ms) of the engine's weight-streaming GEMM launches
  * during the last rqamd_rqt_sample call is not observable from outside the stream, so the engine can
  * bracket every GEMM launch of one call with HIP events (profile != 0 disables graphs for that call). */

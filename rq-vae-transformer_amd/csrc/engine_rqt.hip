@@ -76,6 +76,14 @@ struct rqamd_rqt {
     bool gvalid = false;
 
     GemmProfile prof;
+
+    // stepping form (rqamd_rqt_step_*): one (position, depth) step per call, the caller draws the samples
+    bool step_on = false;
+    int step_B = 0, step_pos = 0, step_d = 0;      // next expected step
+    const float* step_cb[8] = {};
+    const float* step_pend_slabs = nullptr;        // the body's last fc2 partials, consumed by depth 0 of the same position
+    int step_pend_n = 0;
+    const float* step_pend_bias = nullptr;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -447,10 +455,10 @@ static int tok_embed(rqamd_rqt* h, const StepCtx& c, int pos_off, int d_lo, int 
     return rq_launch_tok_embed(t, st);
 }
 
-// everything that happens at one spatial position >= 1 (position read from h->st[0] on the device)
-static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, bool do_head, int host_pos, hipStream_t st) {
+// body half of one spatial position (position read from h->st[0] on the device): token embedding + body stack; the last
+// fc2 stays un-reduced in `pend`
+static int position_body(rqamd_rqt* h, const StepCtx& c, bool first_pos, int host_pos, Pending& pend, hipStream_t st) {
     const int E = h->E, B = c.B;
-    Pending pend;
     if (first_pos) {
         RQ_TRY(rq_launch_cond_embed(h->cond, h->cond_len, h->cond_len - 1, h->cond_emb, h->cfg.vocab_size_cond < 1 ? 1 : h->cfg.vocab_size_cond,
                                     h->pos_cond, h->x, B, E, st));
@@ -460,56 +468,68 @@ static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, boo
         else RQ_TRY(tok_embed(h, c, -1, 0, h->D, h->pos_hw, true, -1, h->x, st));
     }
     // a captured graph serves every position of the same 8-key bucket: bound t by the bucket's last position
-    RQ_TRY(body_stack(h, B, h->st, h->cond_len - 1, ((host_pos + h->cond_len - 1) | 7), pend, st));
-    if (!do_head) {
-        // keep the residual stream consistent is unnecessary: the next position overwrites h->x
-        return RQAMD_OK;
+    return body_stack(h, B, h->st, h->cond_len - 1, ((host_pos + h->cond_len - 1) | 7), pend, st);
+}
+
+// head half: depth d of the position -- head stack, classifier, then the sampler / the teacher-forced copy / nothing
+// (stepping form: the caller reads h->logits).  `pend`: the body's pending fc2 (used by d == 0 only).
+static int position_depth(rqamd_rqt* h, const StepCtx& c, int d, const Pending& pend, int host_pos, bool mask_only, hipStream_t st) {
+    const int E = h->E, B = c.B;
+    Pending hp;
+    const float* addvec = nullptr;
+    float* x_in = h->xh;
+    if (d == 0) {
+        // head token 0 = spatial context + pos_emb_d[0]; the context is body x + last fc2 (+bias)
+        hp = pend; addvec = h->pos_d; x_in = h->x;
+    } else {
+        // head token d = head_mlp(cumsum_{j<d} e_j) + pos_emb_d[d]  (transformers.py:249-267); without cumsum_depth_ctx only
+        // e_{d-1}; with head_emb_vqvae off tok_emb(code_{d-1}) + pos_emb_d[d]
+        if (h->head_vq) RQ_TRY(embed_gemm(h, c, 0, h->cumsum ? 0 : d - 1, d, h->w_headin, h->head_in_bias, d, false, h->xh, st));
+        else RQ_TRY(tok_embed(h, c, 0, d - 1, d, h->pos_d, false, d, h->xh, st));
+        hp = Pending{nullptr, 0, nullptr};
     }
-    for (int d = 0; d < h->D; ++d) {
-        Pending hp;
-        const float* addvec = nullptr;
-        float* x_in = h->xh;
-        if (d == 0) {
-            // head token 0 = spatial context + pos_emb_d[0]; the context is body x + last fc2 (+bias)
-            hp = pend; addvec = h->pos_d; x_in = h->x;
-        } else {
-            // head token d = head_mlp(cumsum_{j<d} e_j) + pos_emb_d[d]  (transformers.py:249-267); without cumsum_depth_ctx only
-            // e_{d-1}; with head_emb_vqvae off tok_emb(code_{d-1}) + pos_emb_d[d]
-            if (h->head_vq) RQ_TRY(embed_gemm(h, c, 0, h->cumsum ? 0 : d - 1, d, h->w_headin, h->head_in_bias, d, false, h->xh, st));
-            else RQ_TRY(tok_embed(h, c, 0, d - 1, d, h->pos_d, false, d, h->xh, st));
-            hp = Pending{nullptr, 0, nullptr};
-        }
-        for (size_t li = 0; li < h->head.size(); ++li) {
-            RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
-        }
-        ResidLnArgs r{};
-        r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
-        if (h->head.empty()) { r.x_in = x_in; r.addvec = addvec; }     // no head stack: the classifier sees the head token itself
-        r.gamma = h->cls_lnw; r.beta = h->cls_lnb; r.y = h->y; r.rows = B; r.E = E; r.eps = 1e-5f;
-        RQ_TRY(rq_launch_resid_ln(r, st));
-        // shared classifier, or BatchLinear's matrix of this depth
-        const long cls_off = h->shared_cls ? 0 : (long)d * h->V;
-        RQ_TRY(step_gemm(h, h->y, E, h->w_cls + cls_off * E, B, h->V, E, EPI_F32, h->b_cls + cls_off, nullptr, 0, h->logits, h->V, nullptr, st));
-        if (c.sample) {
-            // LogitMask (primitives.py:78-93): codes beyond this depth's vocabulary cannot be drawn.  (The reference's teacher-
-            // forced logits are NOT masked -- its mask indexes the wrong axis there -- so rqamd_rqt_logits leaves them alone.)
-            if (h->Vd[d] < h->V) RQ_TRY(rq_launch_mask_logits(h->logits, B, h->V, h->Vd[d], st));
-            SampleArgs s{};
-            s.logits = h->logits; s.rows = B; s.V = h->V; s.temperature = c.temperature; s.top_k = c.top_k[d]; s.top_p = c.top_p[d];
-            s.redo = h->smp_redo; s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;
-            RQ_TRY(rq_launch_sample(s, st));
-        } else if (c.logits_out) {
-            float* dst = c.logits_out + ((long)host_pos * h->D + d) * h->V;
-            RQ_HIP(hipMemcpy2DAsync(dst, (size_t)h->HW * h->D * h->V * 4, h->logits, (size_t)h->V * 4, (size_t)h->V * 4, B,
-                                    hipMemcpyDeviceToDevice, st));
-        }
+    for (size_t li = 0; li < h->head.size(); ++li) {
+        RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
+    }
+    ResidLnArgs r{};
+    r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
+    if (h->head.empty()) { r.x_in = x_in; r.addvec = addvec; }     // no head stack: the classifier sees the head token itself
+    r.gamma = h->cls_lnw; r.beta = h->cls_lnb; r.y = h->y; r.rows = B; r.E = E; r.eps = 1e-5f;
+    RQ_TRY(rq_launch_resid_ln(r, st));
+    // shared classifier, or BatchLinear's matrix of this depth
+    const long cls_off = h->shared_cls ? 0 : (long)d * h->V;
+    RQ_TRY(step_gemm(h, h->y, E, h->w_cls + cls_off * E, B, h->V, E, EPI_F32, h->b_cls + cls_off, nullptr, 0, h->logits, h->V, nullptr, st));
+    if (c.sample || mask_only) {
+        // LogitMask (primitives.py:78-93): codes beyond this depth's vocabulary cannot be drawn.  (The reference's teacher-
+        // forced logits are NOT masked -- its mask indexes the wrong axis there -- so rqamd_rqt_logits leaves them alone.)
+        if (h->Vd[d] < h->V) RQ_TRY(rq_launch_mask_logits(h->logits, B, h->V, h->Vd[d], st));
+    }
+    if (c.sample) {
+        SampleArgs s{};
+        s.logits = h->logits; s.rows = B; s.V = h->V; s.temperature = c.temperature; s.top_k = c.top_k[d]; s.top_p = c.top_p[d];
+        s.redo = h->smp_redo; s.rng = h->rng; s.pos = h->st; s.d = d; s.D = h->D; s.out = h->xs; s.out_stride = (long)h->HW * h->D;
+        RQ_TRY(rq_launch_sample(s, st));
+    } else if (c.logits_out) {
+        float* dst = c.logits_out + ((long)host_pos * h->D + d) * h->V;
+        RQ_HIP(hipMemcpy2DAsync(dst, (size_t)h->HW * h->D * h->V * 4, h->logits, (size_t)h->V * 4, (size_t)h->V * 4, B,
+                                hipMemcpyDeviceToDevice, st));
     }
     return RQAMD_OK;
 }
 
-static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const int64_t* cond, int start_idx, bool use_graph,
-                   int64_t* codes_out, hipStream_t st) {
+// everything that happens at one spatial position (position read from h->st[0] on the device)
+static int position_sequence(rqamd_rqt* h, const StepCtx& c, bool first_pos, bool do_head, int host_pos, hipStream_t st) {
+    Pending pend;
+    RQ_TRY(position_body(h, c, first_pos, host_pos, pend, st));
+    if (!do_head) return RQAMD_OK;                 // (the next position overwrites h->x)
+    for (int d = 0; d < h->D; ++d) RQ_TRY(position_depth(h, c, d, pend, host_pos, false, st));
+    return RQAMD_OK;
+}
+
+// inputs into the workspace, position counter to 0, conditioning prefix through the body stack
+static int begin_batch(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const int64_t* cond, hipStream_t st) {
     const int B = c.B;
+    h->step_on = false;                            // any new batch ends a stepping sequence (same workspace)
     RQ_TRY(ensure_batch(h, B));
     RQ_TRY(finalize_tables(h, st));
     RQ_HIP(hipMemcpyAsync(h->xs, partial, (size_t)B * h->HW * h->D * 8, hipMemcpyDeviceToDevice, st));
@@ -539,6 +559,13 @@ static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const
             }
         }
     }
+    return RQAMD_OK;
+}
+
+static int run_all(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, const int64_t* cond, int start_idx, bool use_graph,
+                   int64_t* codes_out, hipStream_t st) {
+    const int B = c.B;
+    RQ_TRY(begin_batch(h, c, partial, cond, st));
     for (int pos = 0; pos < h->HW; ++pos) {
         const bool do_head = pos >= start_idx;
         const bool graphable = use_graph && c.sample && do_head && pos >= 1 && !h->prof.on;
@@ -590,6 +617,7 @@ extern "C" int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int6
     if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_sample: batch < 1");
     if (!(temperature > 0.f)) return rq_fail(RQAMD_ERR_INVALID, "rqt_sample: temperature must be > 0");
     hipStream_t st = (hipStream_t)stream;
+    h->step_on = false;
     RQ_TRY(ensure_batch(h, batch));
     StepCtx c{};
     c.B = batch; c.codebooks = codebooks; c.temperature = temperature; c.top_k = top_k; c.top_p = top_p; c.sample = true;
@@ -634,6 +662,64 @@ extern "C" int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64
     StepCtx c{};
     c.B = batch; c.codebooks = codebooks; c.temperature = 1.f; c.sample = false; c.logits_out = logits_out; c.cond_logits_out = cond_logits_out;
     return run_all(h, c, codes, cond, 0, false, nullptr, (hipStream_t)stream);
+}
+
+// ---- stepping form: the caller draws the samples (include/rqamd.h)
+extern "C" int rqamd_rqt_step_begin(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, int batch, const float* const* codebooks, void* stream) {
+    if (!h || !partial || !codebooks) return rq_fail(RQAMD_ERR_INVALID, "rqt_step_begin: null argument");
+    if (batch < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_step_begin: batch < 1");
+    h->step_on = false;
+    for (int d = 0; d < h->D; ++d) h->step_cb[d] = codebooks[d];
+    StepCtx c{};
+    c.B = batch; c.codebooks = h->step_cb; c.temperature = 1.f; c.sample = false;
+    RQ_TRY(begin_batch(h, c, partial, cond, (hipStream_t)stream));
+    h->step_on = true; h->step_B = batch; h->step_pos = 0; h->step_d = 0;
+    return RQAMD_OK;
+}
+
+extern "C" int rqamd_rqt_step_logits(rqamd_rqt* h, int pos, int d, const float** logits_dev, void* stream) {
+    if (!h || !h->step_on) return rq_fail(RQAMD_ERR_STATE, "rqt_step_logits: no rqamd_rqt_step_begin");
+    const bool body_only = d < 0;
+    if (pos != h->step_pos || (body_only ? h->step_d != 0 : d != h->step_d) || pos >= h->HW)
+        return rq_fail(RQAMD_ERR_INVALID, "rqt_step_logits: step (%d, %d) out of order, expected (%d, %d)", pos, d, h->step_pos, h->step_d);
+    if (h->cap < h->step_B) return rq_fail(RQAMD_ERR_STATE, "rqt_step_logits: the workspace was re-sized by another call");
+    hipStream_t st = (hipStream_t)stream;
+    StepCtx c{};
+    c.B = h->step_B; c.codebooks = h->step_cb; c.temperature = 1.f; c.sample = false;
+    if (body_only || d == 0) {
+        RQ_TRY(rq_launch_set_int(h->st, pos, st));
+        Pending pend;
+        RQ_TRY(position_body(h, c, pos == 0, pos, pend, st));
+        h->step_pend_slabs = pend.slabs; h->step_pend_n = pend.n; h->step_pend_bias = pend.bias;
+    }
+    if (body_only) { h->step_pos = pos + 1; h->step_d = 0; return RQAMD_OK; }
+    if (!logits_dev) return rq_fail(RQAMD_ERR_INVALID, "rqt_step_logits: null argument");
+    const Pending pend{h->step_pend_slabs, h->step_pend_n, h->step_pend_bias};
+    RQ_TRY(position_depth(h, c, d, pend, pos, true, st));
+    *logits_dev = h->logits;
+    if (d + 1 < h->D) h->step_d = d + 1;
+    else { h->step_d = 0; h->step_pos = pos + 1; }
+    return RQAMD_OK;
+}
+
+__global__ void set_codes_kernel(int64_t* xs, const int64_t* codes, int rows, long stride, int slot) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) xs[(long)r * stride + slot] = codes[r];
+}
+
+extern "C" int rqamd_rqt_step_set_code(rqamd_rqt* h, int pos, int d, const int64_t* codes, void* stream) {
+    if (!h || !h->step_on || !codes) return rq_fail(RQAMD_ERR_STATE, "rqt_step_set_code: no step in progress / null argument");
+    if (pos < 0 || pos >= h->HW || d < 0 || d >= h->D) return rq_fail(RQAMD_ERR_INVALID, "rqt_step_set_code: step (%d, %d)", pos, d);
+    RQ_LAUNCH(set_codes_kernel, dim3((unsigned)((h->step_B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->xs, codes, h->step_B,
+              (long)h->HW * h->D, pos * h->D + d);
+    return rq_check_launch("set_codes_kernel");
+}
+
+extern "C" int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream) {
+    if (!h || !h->step_on) return rq_fail(RQAMD_ERR_STATE, "rqt_step_end: no step in progress");
+    h->step_on = false;
+    if (codes_out) RQ_HIP(hipMemcpyAsync(codes_out, h->xs, (size_t)h->step_B * h->HW * h->D * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return RQAMD_OK;
 }
 
 extern "C" int rqamd_rqt_set_profile(rqamd_rqt* h, int profile) {

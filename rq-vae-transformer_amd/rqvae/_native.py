@@ -60,6 +60,10 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p]),
     'rqamd_rqt_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
     'rqamd_rqt_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_step_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    'rqamd_rqt_step_logits': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    'rqamd_rqt_step_set_code': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_rqt_step_end': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_rqt_set_profile': (C.c_int, [C.c_void_p, C.c_int]),
     'rqamd_rqt_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double)]),
@@ -133,6 +137,18 @@ def on_device_of(t):
     the tensor's device -- model.to('cuda:1') with current device 0 must not mix the two."""
     dev = t if isinstance(t, torch.device) else t.device
     return torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext()
+
+
+def _view_f32(address, shape, device):
+    """A float32 tensor over `address` (device memory owned by the library; no copy, no ownership)."""
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+
+    class _Mem:
+        __cuda_array_interface__ = {'shape': (n,), 'typestr': '<f4', 'data': (int(address), False), 'version': 2}
+    with on_device_of(device):
+        return torch.as_tensor(_Mem(), device=device).view(*shape)
 
 
 def _ptr_array(tensors, dtype=torch.float32):
@@ -455,6 +471,42 @@ class RqtEngine(_Engine):
         self._run(lambda: lib().rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
                                                   ptr(out), ptr(cl), stream_of(codes)))
         return out, cl
+
+    # ---- stepping form: the caller draws the samples (rqamd_rqt_step_*)
+    def step_begin(self, partial, cond, codebooks):
+        self._check(partial, cond, codebooks)
+        self._step = (partial.shape[0], partial.device, [cb for cb in codebooks[:self.cfg.D]])     # keeps the codebooks alive
+        cbs = _ptr_array(self._step[2])
+        self._run(lambda: lib().rqamd_rqt_step_begin(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), partial.shape[0], cbs,
+                                                     stream_of(partial)))
+
+    def step_logits(self, pos, d):
+        """logits (B, V) fp32 of step (pos, d) -- a view of the engine's workspace, valid until the next engine call; d < 0:
+        body stack only (returns None)."""
+        B, dev, _ = self._step
+        out = C.c_void_p()
+        with on_device_of(dev):
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else 0)
+            check(lib().rqamd_rqt_step_logits(self._h, int(pos), int(d), C.byref(out), st))
+        if d < 0:
+            return None
+        return _view_f32(out.value, (B, self.cfg.vocab_size), dev)
+
+    def step_set_code(self, pos, d, codes):
+        B, dev, _ = self._step
+        if tuple(codes.shape) != (B,):
+            raise ValueError(f'codes of shape {tuple(codes.shape)}; expected ({B},)')
+        with on_device_of(dev):
+            check(lib().rqamd_rqt_step_set_code(self._h, int(pos), int(d), ptr(codes.contiguous(), torch.int64), stream_of(codes)))
+
+    def step_end(self):
+        B, dev, _ = self._step
+        c = self.cfg
+        out = torch.empty((B, c.H, c.W, c.D), dtype=torch.int64, device=dev)
+        with on_device_of(dev):
+            check(lib().rqamd_rqt_step_end(self._h, ptr(out), stream_of(out)))
+        self._step = None
+        return out
 
     def set_profile(self, on):
         check(lib().rqamd_rqt_set_profile(self._h, int(bool(on))))

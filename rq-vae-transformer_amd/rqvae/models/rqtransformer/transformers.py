@@ -90,6 +90,8 @@ class RQTransformer(Stage2Model):
         self._engine_sig = None
         self._side = SideStream()
         self.use_graph = os.environ.get('RQAMD_GRAPH', '1') != '0'
+        # 'philox' (default): on-device sampler inside the captured graphs; 'torch': host loop + torch.multinomial (see sample)
+        self.sampler = os.environ.get('RQAMD_SAMPLER', 'philox')
 
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
@@ -214,10 +216,37 @@ class RQTransformer(Stage2Model):
         cbs = self._checked_codebooks(model_aux)
         xs = partial_sample.to(torch.long).contiguous()
         c = self._cond(cond, B, device)
+        if self.sampler == 'torch':
+            return self._sample_torch_multinomial(eng, xs, c, cbs, start_loc, temperature, top_k_list, top_p_list)
         seed, offset = self._draw_rng(device, H * W * D)
         out = self._on_side_stream(device, lambda: eng.sample(xs, c, cbs, start_loc, temperature, top_k_list, top_p_list,
                                                               seed, offset, self.use_graph))
         return out
+
+    def _sample_torch_multinomial(self, eng, xs, cond, cbs, start_loc, temperature, top_k_list, top_p_list):
+        """``self.sampler = 'torch'`` (or RQAMD_SAMPLER=torch): the loop of transformers.py:346-364 driven from the host, one engine
+        step per (h, w, d), the draw by ``torch.multinomial(probs, num_samples=1)`` on the filtered probabilities -- the call
+        sample_from_logits makes (rqvae/utils/utils.py:112), so the device generator is consumed exactly as the reference consumes
+        it (one multinomial over a (B, V) tensor per step).  ~10x slower than the default on-device sampler (no graphs, one host
+        round per step); meant for seed-for-seed comparisons, not for throughput."""
+        from ... import _native
+        (H, W, D) = self.block_size
+        start = max(int(start_loc[0]) * W + int(start_loc[1]), 0)
+        eng.step_begin(xs, cond, cbs)
+        for pos in range(H * W):
+            if pos < start:
+                eng.step_logits(pos, -1)               # given codes: body KV cache only
+                continue
+            for d in range(D):
+                logits = eng.step_logits(pos, d)
+                _, probs = _native.sample_logits(logits, temperature, top_k_list[d], top_p_list[d], want_probs=True, want_samples=False)
+                try:
+                    idx = torch.multinomial(probs, num_samples=1).squeeze(-1)
+                except RuntimeError:
+                    print(probs, logits, torch.sum(probs), torch.sum(probs < 0))
+                    raise
+                eng.step_set_code(pos, d, idx)
+        return eng.step_end()
 
     @staticmethod
     def _draw_rng(device, n_steps):

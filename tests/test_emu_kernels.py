@@ -306,6 +306,55 @@ def test_emu_rqt_tiny_sample(nat, golden):
     # (seed determinism, hipGraph == eager and start_loc are covered on the GPU: tests/test_gpu_parity.py)
 
 
+def test_emu_rqt_stepping_form(nat, golden):
+    """rqamd_rqt_step_*: the engine stepped one (position, depth) at a time with the codes supplied by the caller gives the
+    logits of the teacher-forced pass bit for bit (same kernels, same order); a host loop that draws with torch.multinomial from
+    the filtered probabilities (what RQTransformer.sampler = 'torch' does, the reference's sample_from_logits call) is
+    reproducible under torch.manual_seed and only draws codes of non-zero filtered probability; start_loc skips positions."""
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    eng = _rqt_engine(nat, cfg, params)
+    cbs = [T(cb)] * 4
+    cond = T(g['cond'].astype(np.int64))[:2].contiguous()
+    codes = T(g['codes'].astype(np.int64))[:2].contiguous()
+    want = eng.logits(codes, cond, cbs)
+    eng.step_begin(torch.zeros_like(codes), cond, cbs)
+    for pos in range(16):
+        for d in range(4):
+            lg = eng.step_logits(pos, d)
+            assert torch.equal(lg, want[:, pos // 4, pos % 4, d]), (pos, d)
+            eng.step_set_code(pos, d, codes[:, pos // 4, pos % 4, d].contiguous())
+    assert torch.equal(eng.step_end(), codes)
+    with pytest.raises(Exception):
+        eng.step_logits(0, 0)                                  # no sequence in progress
+
+    def host_sample(seed, start=0, partial=None):
+        torch.manual_seed(seed)
+        part = torch.zeros_like(codes) if partial is None else partial
+        eng.step_begin(part, cond, cbs)
+        for pos in range(16):
+            if pos < start:
+                eng.step_logits(pos, -1)
+                continue
+            for d in range(4):
+                _, pr = nat.sample_logits(eng.step_logits(pos, d), 1.0, 5, 0.9, want_probs=True, want_samples=False)
+                eng.step_set_code(pos, d, torch.multinomial(pr, num_samples=1).squeeze(-1))
+        return eng.step_end()
+    a, b, c2 = host_sample(3), host_sample(3), host_sample(4)
+    assert torch.equal(a, b) and not torch.equal(a, c2)
+    lg = eng.logits(a, cond, cbs).numpy()
+    for pos in range(16):
+        for d in range(4):
+            pr = oracle.filtered_probs(lg[:, pos // 4, pos % 4, d], 1.0, 5, 0.9)
+            assert (pr[np.arange(2), a[:, pos // 4, pos % 4, d].numpy()] > 0).all()
+    # start_loc = (2, 1): positions 0..8 keep the given codes
+    s = host_sample(5, start=9, partial=a)
+    assert torch.equal(s.reshape(2, 16, 4)[:, :9], a.reshape(2, 16, 4)[:, :9])
+
+
 def _vae_engine(nat, hps, dd, params):
     eng = nat.VaeEngine(dd, hps['embed_dim'], device='cpu')
     for k, v in params.items():

@@ -304,6 +304,60 @@ def test_rqt_sample_semantics(nat, golden):
     assert torch.equal(o1, o2)
 
 
+def test_rqt_sample_torch_multinomial_mode(nat, golden):
+    """ar.sampler = 'torch' (SURVEY §7 step 6): the sampling loop driven from the host, the draw by torch.multinomial on the
+    filtered probabilities -- the reference's own call (rqvae/utils/utils.py:112).  Reproducible under the torch seed; every drawn
+    code has non-zero filtered probability under teacher forcing; the device generator is consumed exactly as H*W*D
+    torch.multinomial calls on a (B, V) tensor consume it (what the reference's loop does); start_loc keeps the given prefix;
+    the stepped logits equal the teacher-forced ones bit for bit."""
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    cond = G(g['cond'], torch.long)
+    partial = torch.zeros((3, 4, 4, 4), dtype=torch.long, device=DEV)
+    ar.sampler = 'torch'
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+    torch.cuda.manual_seed_all(77)
+    off0 = gen.get_offset()
+    a = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+    used = gen.get_offset() - off0
+    torch.cuda.manual_seed_all(77)
+    b = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+    assert torch.equal(a, b)
+    c = ar.sample(partial, vae, cond=cond, temperature=1.0, top_k=5, top_p=0.9)
+    assert not torch.equal(a, c)
+    assert a.dtype == torch.long and a.shape == partial.shape and int(a.min()) >= 0 and int(a.max()) < 500
+    # generator consumption == 64 multinomial draws over (3, 500) probabilities
+    dummy = torch.full((3, 500), 1.0 / 500, device=DEV)
+    off1 = gen.get_offset()
+    for _ in range(4 * 4 * 4):
+        torch.multinomial(dummy, num_samples=1)
+    assert gen.get_offset() - off1 == used
+    logits = N(ar(a, vae, cond=cond))
+    for h in range(4):
+        for w in range(4):
+            for d in range(4):
+                pr = oracle.filtered_probs(logits[:, h, w, d], 1.0, 5, 0.9)
+                assert (pr[np.arange(3), N(a[:, h, w, d])] > 0).all()
+    # the same draws by hand: torch.multinomial on the library's filtered probabilities of the stepped logits
+    torch.cuda.manual_seed_all(77)
+    eng = ar._eng()
+    cbs = ar._checked_codebooks(vae)
+    eng.step_begin(partial, cond, cbs)
+    tf = ar(a, vae, cond=cond)
+    for pos in range(16):
+        for d in range(4):
+            lg = eng.step_logits(pos, d)
+            assert torch.equal(lg, tf[:, pos // 4, pos % 4, d]), (pos, d)
+            _, pr = nat.sample_logits(lg, 1.0, 5, 0.9, want_probs=True, want_samples=False)
+            eng.step_set_code(pos, d, torch.multinomial(pr, num_samples=1).squeeze(-1))
+    assert torch.equal(eng.step_end(), a)
+    part2 = a.clone()
+    part2[:, 2:] = 0
+    out3 = ar.sample(part2, vae, cond=cond, start_loc=(2, 0), top_k=5, top_p=0.9)
+    assert torch.equal(out3[:, :2], a[:, :2])
+    ar.sampler = 'philox'
+
+
 def test_rqt_text_conditioned(nat, golden):
     """block_size_cond = 4: the cond prefix is prefilled through the body KV cache."""
     g = golden('rqt_tiny_txt.npz')
