@@ -342,8 +342,8 @@ def test_rqt_sample_torch_multinomial_mode(nat, golden):
     torch.cuda.manual_seed_all(77)
     eng = ar._eng()
     cbs = ar._checked_codebooks(vae)
+    tf = ar(a, vae, cond=cond)                       # (before step_begin: any other engine call ends a stepping sequence)
     eng.step_begin(partial, cond, cbs)
-    tf = ar(a, vae, cond=cond)
     for pos in range(16):
         for d in range(4):
             lg = eng.step_logits(pos, d)
