@@ -35,7 +35,6 @@ struct ConvHaloArgs {
 constexpr int HT_H = 8, HT_W = 32;                 // output tile
 constexpr int HP_W = HT_W + 2;                     // halo patch of the plain conv: 34 x 10 = 340 pixels
 constexpr int H_BN = 128;
-constexpr int H_NTH = 512;
 constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
 constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + 3 * HW_BYTES;     // two patch buffers + three weight slots = 135 KB (every variant)
 
