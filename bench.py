@@ -351,6 +351,27 @@ def main(argv=None):
     vcfg = presets.RQVAE[presets.RQTRANSFORMER[args.model][1]]
     set_seed(0 + rank)                                   # main_sampling_fid.py:166-169
     B = args.batch if args.batch > 0 else DEFAULT_BATCH.get(args.model, 1024)
+    # safety net (normally a no-op): the default batch is sized for an empty 288-GB device (KV caches ~17 MB per image at the
+    # 1.4B shape).  If this device has less free memory, shrink the batch to what fits -- in whole 256-row GEMM tiles, the same on
+    # every rank -- instead of dying in hipMalloc; the line then reports the batch actually used (config.batch_per_gpu).
+    E = cfg['embed_dim']
+    t_body = cfg['block_size'][0] * cfg['block_size'][1] + max(cfg.get('block_size_cond', 1), 1) - 1
+    per_row = 2 * (cfg['body']['n_layer'] * t_body + cfg['head']['n_layer'] * cfg['block_size'][2]) * E * 2 \
+        + 12 * E * 4 + cfg['vocab_size'] * 4 + 16 * E * 2 + 3 * 256 * 256 * 4
+    free_b, _ = torch.cuda.mem_get_info(device)
+    fit = int((free_b - 42e9) // per_row)
+    if world > 1:
+        import torch.distributed as dist
+        t_fit = torch.tensor([fit], device=device, dtype=torch.int64)
+        dist.all_reduce(t_fit, op=dist.ReduceOp.MIN)
+        fit = int(t_fit.item())
+    batch_note = None
+    if args.batch <= 0 and fit < B:
+        newB = max(256, fit // 256 * 256)
+        batch_note = f'default batch {B} does not fit the free device memory ({free_b / 1e9:.0f} GB); using {newB}'
+        if rank == 0:
+            print('bench.py: ' + batch_note, file=sys.stderr)
+        B = newB
     empty_sample = torch.zeros((B,) + tuple(ar.block_size), device=device, dtype=torch.long)
     empty_cond = torch.zeros((B, ar.block_size_cond), device=device, dtype=torch.long)
 
@@ -473,7 +494,7 @@ def main(argv=None):
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'RQ-Transformer {args.model} ({WORKLOADS.get(args.model, args.model)}) sampling 8x8x4 codes + RQ-VAE decode; '
                                    f'random-init weights, zero condition',
-                       'batch_per_gpu': B, 'global_batch': B * world, 'top_k': args.top_k, 'top_p': args.top_p,
+                       'batch_per_gpu': B, 'global_batch': B * world, 'batch_note': batch_note, 'top_k': args.top_k, 'top_p': args.top_p,
                        'overlap_decode_with_next_sampling': bool(args.overlap), 'world_size': world, 'requested_gpus': args.gpus,
                        'per_rank_seconds': rank_times,
                        'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather (RCCL) per step' if world > 1 else 'single GPU',
