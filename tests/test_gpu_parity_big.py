@@ -100,3 +100,35 @@ def test_rqt_logits_vs_reference(golden, tag, cfg):
         assert torch.equal(res[0], res[1]) and int(res[0].min()) >= 0 and int(res[0].max()) < V
     del ar
     torch.cuda.empty_cache()
+
+
+def test_rqt_in1400m_through_the_benchmarked_kernels(golden):
+    """The full 1.4B model through the kernels bench.py's batch selects (256 x 256 eight-phase GEMMs, large-batch attention /
+    LayerNorm variants): 2050 rows (the two fixture images tiled; kernel selection sees 5x as many = 10250 rows, the
+    diagnostics row-scale hook) against the REFERENCE's logits.  Same bound as the two-row test above: the error must not depend
+    on which GEMM kernel produced the logits."""
+    from rqvae import _native
+    g = golden('rqt_in1400m.npz')
+    cfg = C.RQT_IN_1400M
+    ar = _load(cfg, int(g['seed']))
+    V, D = cfg['vocab_size'], cfg['block_size'][2]
+    cb = np.random.default_rng(int(g['cb_seed'])).standard_normal((V, 256), dtype=np.float32)
+    aux = Aux(cb, D)
+    reps = 1025
+    codes = G(np.tile(g['codes'], (reps, 1, 1, 1)), torch.long)
+    cond = G(np.tile(g['cond'], (reps, 1)), torch.long)
+    _native.dbg_set_row_scale(5)
+    try:
+        out = ar(codes, aux, cond=cond)
+    finally:
+        _native.dbg_set_row_scale(1)
+    ref = g['logits'].astype(np.float32)
+    worst, mean = 0.0, 0.0
+    for r0 in (0, 1024, 2048):
+        got = torch.stack([out[r0:r0 + 2, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+        err = np.abs(got - ref)
+        worst, mean = max(worst, float(err.max())), max(mean, float(err.mean()))
+    print(f'rqt in1400m through the large-batch kernels (2050 rows): logits max err {worst:.4f} mean {mean:.5f}')
+    assert worst < 0.08 and mean < 0.012
+    del out, ar
+    torch.cuda.empty_cache()
