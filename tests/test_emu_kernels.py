@@ -343,12 +343,11 @@ def test_emu_rqt_stepping_form(nat, golden):
                 _, pr = nat.sample_logits(eng.step_logits(pos, d), 1.0, 5, 0.9, want_probs=True, want_samples=False)
                 eng.step_set_code(pos, d, torch.multinomial(pr, num_samples=1).squeeze(-1))
         return eng.step_end()
-    a, b = host_sample(3), host_sample(3)
-    assert torch.equal(a, b) and int(a.min()) >= 0 and int(a.max()) < cfg['vocab_size']
-    # start_loc = (2, 1): positions 0..8 keep the given codes (body passes only), the rest is drawn
-    s = host_sample(5, start=9, partial=a)
-    assert torch.equal(s.reshape(2, 16, 4)[:, :9], a.reshape(2, 16, 4)[:, :9])
-    # (non-zero filtered probability of every drawn code, generator consumption: tests/test_gpu_parity.py)
+    # start_loc = (2, 1): positions 0..8 keep the given codes (body passes only), the rest is drawn; same seed, same draw
+    s, s2 = host_sample(5, start=9, partial=codes), host_sample(5, start=9, partial=codes)
+    assert torch.equal(s, s2) and int(s.min()) >= 0 and int(s.max()) < cfg['vocab_size']
+    assert torch.equal(s.reshape(2, 16, 4)[:, :9], codes.reshape(2, 16, 4)[:, :9])
+    # (full-length draws, non-zero filtered probability of every drawn code, generator consumption: tests/test_gpu_parity.py)
 
 
 def _vae_engine(nat, hps, dd, params):
