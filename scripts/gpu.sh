@@ -6,6 +6,7 @@
 #   bench [args]     python bench.py  (RQ_BENCH_ARGS="--steps 2 ..." for arguments)
 #   trace            rocprofv3 --kernel-trace --stats of one bench step -> <TAG>_kernel_stats.md
 #   pmc              FETCH_SIZE / WRITE_SIZE of the decode GEMM shapes at RQ_M rows (separate passes) -> <TAG>_gemm_traffic_m<M>.json
+#   ktrace           rocprofv3 --kernel-trace --stats of "$RQ_PMC_CMD" -> <TAG>_ktrace.md
 #   sqpmc            SQ counters (three passes) of "$RQ_PMC_CMD", kernels matching $RQ_PMC_FILTER -> <TAG>_sqpmc.txt
 #   gemm             scripts/gemm_bench.py (RQ_MS=4096,8192 ...)
 #   cmd              run "$RQ_CMD"
@@ -55,6 +56,11 @@ pmc)
   cd $R; grep algorithmic gpurun_out/pmc_FETCH_SIZE.log
   python scripts/summarize_traffic.py $M gpurun_out/${TAG}_gemm_traffic_m$M.json
   rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE ;;
+ktrace)
+  # kernel trace of "$RQ_PMC_CMD" -> <TAG>_ktrace.md
+  cd /tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_k -o trace -- $RQ_PMC_CMD > $R/gpurun_out/${TAG}_ktrace.log 2>&1
+  cd $R; stats_md gpurun_out/prof_k gpurun_out/${TAG}_ktrace.md; rm -rf gpurun_out/prof_k ;;
 sqpmc)
   # SQ counters of "$RQ_PMC_CMD" (kernels matching $RQ_PMC_FILTER), two passes -> <TAG>_sqpmc.txt
   cd /tmp; : > $R/gpurun_out/${TAG}_sqpmc.txt
