@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch
 from rqvae import _native
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (diagnostics only)
+    _native.LIB_PATH = os.path.join(ROOT, 'rq-vae-transformer_amd', os.environ['RQ_LIB'])
 
 dev = 'cuda'
 VARIANTS = (('th8', dict(persistent=False)), ('th8p', dict(persistent=True)))
@@ -20,7 +22,7 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-shapes = ((8, 256, 128, 128, 0), (32, 256, 128, 128, 0), (8, 128, 128, 128, 0), (8, 128, 256, 128, 0), (8, 64, 256, 256, 0), (8, 128, 256, 256, 0),
+shapes = ((8, 256, 128, 128, 0),) if os.environ.get('RQ_QUICK') else ((8, 256, 128, 128, 0), (32, 256, 128, 128, 0), (8, 128, 128, 128, 0), (8, 128, 256, 128, 0), (8, 64, 256, 256, 0), (8, 128, 256, 256, 0),
           (8, 256, 128, 128, 1), (8, 128, 256, 256, 1))
 for B, H, Cin, Cout, ups in shapes:
     Hs = H // 2 if ups else H
