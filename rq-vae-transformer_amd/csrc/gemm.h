@@ -111,6 +111,32 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
 // Epilogue shared by the GEMM kernels: bias / GELU / residual / bf16 packing / fp32 and split-K slab stores from the
 // accumulators of a WGM x WGN wavefront grid over a BM x BN tile.  `smem` is the workgroup's dynamic LDS segment of
 // SMEM_BYTES bytes (the operand buffers, free once every wave has passed the barrier inside); TR as in the kernels.
+#ifdef RQ_GEMM_TRACE
+// Diagnostics build only (scripts/gemm_trace.sh): shader-clock stamps of one workgroup's epilogue phases.
+__device__ unsigned long long g_gemm_trace[8 * 16];
+#define RQ_GT(slot) do { if (blockIdx.x == RQ_GEMM_TRACE && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_gemm_trace[(threadIdx.x >> 6) * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RQ_GT(slot) do { } while (0)
+#endif
+// bias[n .. n+3] without control flow (columns >= N give 0): the epilogues fetch all of a lane's bias vectors up front, back
+// to back -- inside their store loops, behind per-column bounds checks, every fetch was a serialised L2 round trip (32 of them:
+// 12 000 of the 17 000 cycles of the eight-phase kernel's bf16 epilogue, profiles/r02_gemm_p8_epilogue_timeline.txt)
+static __device__ __forceinline__ f32x4 rq_bias4(const float* bias, int n, int N) {
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (!bias) return b;                                   // uniform
+    if ((N & 3) == 0) {                                    // uniform: n is a multiple of 4, so n < N <=> n + 3 < N
+        const f32x4 v = *(const f32x4*)(bias + (n < N ? n : N - 4));
+        if (n < N) b = v;
+        return b;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = bias[n + e < N ? n + e : N - 1];
+        b[e] = n + e < N ? v : 0.f;
+    }
+    return b;
+}
+
 template <int BM, int BN, int TR, int WGM, int WGN, int SMEM_BYTES>
 static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                         unsigned char* smem, int m0, int n0) {
@@ -142,7 +168,14 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         constexpr int LDR = BN * 2 + 16;           // padded row stride in bytes (16-byte aligned rows)
         static_assert(BM * LDR <= SMEM_BYTES, "bf16 epilogue tile must fit the operand buffers");
         char* sT = (char*)smem;
+        f32x4 bvec[NI][4];                          // the lane's bias vectors (the same for every row block i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bvec[j][q] = rq_bias4(bias, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
+        RQ_GT(1);
         rq_syncthreads();                          // every wave is done reading the operand buffers
+        RQ_GT(2);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int ml = wm * WM + i * 32 + (lane & 31);
@@ -154,16 +187,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                     const int n = n0 + nl;
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                    if (bias) {
-                        if (n + 3 < p.N) {
-                            const f32x4 bv = *(const f32x4*)(bias + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                        } else {
-                            for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bvec[j][q][e];
                     if (epi == EPI_BF16_GELU) {
                         rq_gelu4(v, p.gelu_v2);
                     }
@@ -188,7 +212,9 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                 }
             }
         }
+        RQ_GT(3);
         rq_syncthreads();
+        RQ_GT(4);
         constexpr int CPR = BN / 8;                // 16-byte chunks per row
         const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
 #pragma unroll 4
@@ -205,6 +231,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                 for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = t[e];
             }
         }
+        RQ_GT(5);
         return;
     }
     if (TR) {
@@ -215,6 +242,12 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
     // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
     // time on the decoder convs; an LDS-staged transpose was 19 %.)
     const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+    f32x4 bvec[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bvec[j][q] = rq_bias4(epi != EPI_F32_PARTIAL ? bias : nullptr, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WM + i * 32 + (lane & 31);
@@ -226,17 +259,8 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                 if (m >= p.M || n >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bvec[j][q][e];
                 const bool full4 = vec_ok && n + 3 < p.N;
-                if (bias && epi != EPI_F32_PARTIAL) {
-                    if (full4) {
-                        const f32x4 bv = *(const f32x4*)(bias + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                    } else {
-                        for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bias[n + e];
-                    }
-                }
                 if (epi == EPI_BF16_GELU) {
                     rq_gelu4(v, p.gelu_v2);
                 }
@@ -286,6 +310,13 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         static_assert(HB % WM == 0 && HB * BN * 4 <= SM_BYTES, "epilogue slab must fit the operand buffers");
         constexpr int QPR = BN / 4;                // float4 groups per row
         const bool n_vec_ok = (p.N & 3) == 0 && (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+        float bvj[NI];                             // the lane's bias values, fetched up front (see rq_bias4)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn * WN + j * 32 + (lane & 31);
+            const float b = bias ? bias[n < p.N ? n : p.N - 1] : 0.f;
+            bvj[j] = (bias && n < p.N) ? b : 0.f;
+        }
 #pragma unroll
         for (int hh = 0; hh < NH; ++hh) {
             rq_syncthreads();                      // operand buffers / previous slab are free
@@ -295,8 +326,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
                         const int nl = wn * WN + j * 32 + (lane & 31);
-                        const int n = n0 + nl;
-                        const float bv = (bias && n < p.N) ? bias[n] : 0.f;
+                        const float bv = bvj[j];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ml = wm * WM - hh * HB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -337,12 +367,20 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         return;
     }
     // fp32 outputs: a wavefront store already covers 2 x 128 contiguous bytes
+    float bvj[NI];                                 // the lane's bias values, fetched up front (see rq_bias4)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool on = bias && epi != EPI_F32_PARTIAL;
+        const float b = on ? bias[n < p.N ? n : p.N - 1] : 0.f;
+        bvj[j] = (on && n < p.N) ? b : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WN + j * 32 + (lane & 31);
-            const float bv = (bias && n < p.N && epi != EPI_F32_PARTIAL) ? bias[n] : 0.f;
+            const float bv = bvj[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -906,6 +944,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     int mt, nt;
     if (!rq_gemm_tile_coords(p, BM, BN, mt, nt)) return;
+    RQ_GT(0);
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt_total = p.K / BK;
     const int per = (kt_total + p.splitk - 1) / p.splitk;

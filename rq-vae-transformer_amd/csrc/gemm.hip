@@ -324,3 +324,11 @@ extern "C" int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bi
     if (bn <= 0) bn = (Cout % 128 == 0) ? 128 : 64;
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
 }
+
+#ifdef RQ_GEMM_TRACE
+// diagnostics build only (scripts/gemm_trace.sh)
+extern "C" int rqamd_dbg_gemm_trace(unsigned long long* out_host) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gemm_trace), sizeof(g_gemm_trace)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "gemm_trace: copy failed");
+    return RQAMD_OK;
+}
+#endif
