@@ -931,7 +931,14 @@ static __device__ __forceinline__ bool rq_gemm_tile_coords(const GemmArgs& p, in
 //        AH1 3 -> 6): row 1 retires its phase-k reads (lgkmcnt(0)) in interval 2k+1, row 0 issues the refill in interval
 //        2(k+2)-1 = 2k+3.
 // The last two K-tiles issue nothing new and wait with the matching smaller counts.  Needs K/64 (per split) >= 2.
-template <int TR>
+// PH = phases per K-tile.  4 (round 2's first schedule): every 16-KB unit is consumed in its own phase, 8 MFMAs per wavefront
+// between barriers.  2: phase I reads AH0, BH0, BH1 and runs the 16 MFMAs of m-half 0, phase II reads AH1 and runs m-half 1 (B stays
+// in registers) -- half the barriers per K-tile (a phase's two barriers and waits cost ~300 cycles whatever its length, and at 8
+// MFMAs the non-MFMA half of a phase was longer than the other wavefront row's MFMA burst that is meant to cover it).  Staging for
+// PH = 2: phase I(t) refills [AH0, BH0, BH1] of the other buffer with tile t+1 (last read two phases ago, in I(t-1)), phase II(t)
+// refills its AH1; the wait that ends I(t) leaves three units in flight (vmcnt(6): AH1(t) has landed for II(t)), the wait that
+// ends II(t) one (vmcnt(2): [AH0, BH0, BH1](t+1) have landed for I(t+1)).
+template <int TR, int PH = 4>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4;
     constexpr int UNIT = 128 * BK * 2;                 // 16 KB
@@ -1039,6 +1046,55 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     rq_barrier_raw();              \
     rq_sched_barrier();
 
+    if (PH == 2 && nk >= 2) {
+        auto mma16 = [&](int ih, bool n1_first) {      // 16 MFMAs: m-blocks 2 ih, 2 ih + 1 x both n-blocks x 4 k-steps
+            rq_sched_barrier();
+            rq_wait_lgkmcnt<0>();
+            rq_sched_barrier();
+            if (!(p.dbg & 32)) rq_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = n1_first ? 1 - jj : jj;
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const bf16x8 b = j ? fb1[ks] : fb0[ks];
+                        acc[2 * ih + ii][j] = TR ? rq_mfma_32x32x16_bf16(b, fa[ii][ks], acc[2 * ih + ii][j])
+                                                 : rq_mfma_32x32x16_bf16(fa[ii][ks], b, acc[2 * ih + ii][j]);
+                    }
+                }
+            rq_setprio(0);
+            rq_sched_barrier();
+            rq_barrier_raw();
+            rq_sched_barrier();
+        };
+        // prologue: tile 0 whole; AH0, BH0, BH1 must have landed before phase I reads them (AH1 may still be in flight)
+        stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1);
+        RQ_P8_LOAD_END(2)
+        if (wm == 1) rq_barrier_raw();           // wave row 1 runs half a phase behind
+        rq_sched_barrier();
+        for (int t = 0; t < nk; ++t) {
+            const char* sb = (const char*)smem + (t & 1) * BUF;
+            const int kt = kt0 + t;
+            const bool more = t + 1 < nk;
+            // ---- phase I
+            read_b(sb, U_BH0, fb0);
+            read_b(sb, U_BH1, fb1);
+            rq_sched_barrier();
+            read_a(sb, U_AH0);
+            if (more) { stage_a(kt + 1, U_AH0, 0); stage_b(kt + 1, U_BH0, 0); stage_b(kt + 1, U_BH1, 1); RQ_P8_LOAD_END(6) }
+            else { RQ_P8_LOAD_END(0) }
+            mma16(0, false);
+            // ---- phase II (B is still in registers)
+            read_a(sb, U_AH1);
+            if (more) { stage_a(kt + 1, U_AH1, 1); RQ_P8_LOAD_END(2) }
+            else { RQ_P8_LOAD_END(0) }
+            mma16(1, true);
+        }
+        if (wm == 0) rq_barrier_raw();           // wave row 0 catches up
+        rq_sched_barrier();
+    } else
     if (nk >= 2) {
         // prologue: tile 0 whole, AH0 / BH0 of tile 1; the first two units must have landed before phase 1 reads them
         stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1);
@@ -1050,6 +1106,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
             const char* sb = (const char*)smem + (t & 1) * BUF;
             const int kt = kt0 + t;
             const int ahead = nk - 1 - t;        // K-tiles after this one
+            if (t == 10) RQ_GT(6);
             // ---- phase 1
             read_b(sb, U_BH0, fb0);
             rq_sched_barrier();
@@ -1057,22 +1114,26 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
             if (ahead >= 1) { stage_b(kt + 1, U_BH1, 1); RQ_P8_LOAD_END(8) }          // in flight: AH1(t+1) .. this one
             else { RQ_P8_LOAD_END(2) }                                                   // last tile: only AH1(t) may still be pending
             mma(0, 0, fb0);
+            if (t == 10) RQ_GT(7);
             // ---- phase 2
             read_b(sb, U_BH1, fb1);
             if (ahead >= 1) { stage_a(kt + 1, U_AH1, 1); RQ_P8_LOAD_END(8) }
             else { RQ_P8_LOAD_END(0) }
             mma(0, 1, fb1);
+            if (t == 10) RQ_GT(8);
             // ---- phase 3
             read_a(sb, U_AH1);
             if (ahead >= 2) { stage_a(kt + 2, U_AH0, 0); RQ_P8_LOAD_END(8) }
             else if (ahead == 1) { RQ_P8_LOAD_END(6) }                                   // BH0(t+1), BH1(t+1), AH1(t+1) stay in flight
             else { RQ_P8_LOAD_END(0) }
             mma(1, 1, fb1);
+            if (t == 10) RQ_GT(9);
             // ---- phase 4 (no LDS reads: B(n0) is still in registers)
             if (ahead >= 2) { stage_b(kt + 2, U_BH0, 0); RQ_P8_LOAD_END(8) }
             else if (ahead == 1) { RQ_P8_LOAD_END(4) }                                   // BH1(t+1), AH1(t+1) stay in flight
             else { RQ_P8_LOAD_END(0) }
             mma(1, 0, fb0);
+            if (t == 10) RQ_GT(10);
         }
         if (wm == 0) rq_barrier_raw();           // wave row 0 catches up: every wave has executed the same number of barriers
         rq_sched_barrier();

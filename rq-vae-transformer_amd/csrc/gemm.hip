@@ -73,13 +73,13 @@ static int launch_rb(const GemmArgs& a, hipStream_t stream) {
 }
 
 // 256 x 256 eight-phase kernel (gemm.h): dense operands, >= 2 K-tiles per split
-template <int TR>
+template <int TR, int PH = 4>
 static int launch_p8(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = 256, BN = 256;
     const size_t smem = (size_t)BM * (BN * 2 + 16);
     static RqDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     GemmArgs g = a;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
@@ -96,7 +96,7 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
         if (g.sched_gm > MT) g.sched_gm = MT;
         nblocks = 8 * ((MT * NT + 7) / 8);
     }
-    RQ_LAUNCH((gemm_p8_kernel<TR>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
+    RQ_LAUNCH((gemm_p8_kernel<TR, PH>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
     return rq_check_launch("gemm_p8_kernel");
 }
 
@@ -144,6 +144,12 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
         if (a.conv || ktiles < 2 || (a.K / 64) % a.splitk != 0)
             return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm 256x256: dense operands and >= 2 K-tiles per (even) split needed");
+        // phases per K-tile: two for the transposed-accumulator kernels (bf16 outputs, split-K slabs: -3.3 ... -4.5 % at M = 10752),
+        // four for the fp32-row kernel (classifier: two phases measured +2.4 %); profiles/r02_gemm_p8_two_phase.txt.
+        // RQAMD_P8_PH=2|4 forces one schedule (A/B switch)
+        static const int ph_env = getenv("RQAMD_P8_PH") ? atoi(getenv("RQAMD_P8_PH")) : 0;
+        const bool ph2 = (a.dbg & 64) ? true : (a.dbg & 128) ? false : ph_env == 2 ? true : ph_env == 4 ? false : a.epi != EPI_F32;
+        if (ph2) return a.epi != EPI_F32 ? launch_p8<1, 2>(a, stream) : launch_p8<0, 2>(a, stream);
         return a.epi != EPI_F32 ? launch_p8<1>(a, stream) : launch_p8<0>(a, stream);
     }
     {   // LDS-DMA staged variants (dense operands): RQAMD_GEMM_GL = number of LDS stages (experiment switch)
@@ -290,6 +296,8 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
     int flags = 0, glds = 0;
+    if (epi >= 1024) { flags |= 128; epi -= 1024; }           // epi + 1024: 256x256 kernel with four phases per K-tile (A/B)
+    if (epi >= 512) { flags |= 64; epi -= 512; }              // epi + 512: 256x256 kernel with two phases per K-tile (A/B)
     if (epi >= 256) { flags |= 32; epi -= 256; }              // epi + 256: eight-phase kernel without s_setprio (A/B)
     if (epi >= 64) { glds = epi / 32; epi -= glds * 32; }      // epi + 32 * stages: LDS-DMA operand staging (2 or 3 stages)
     if (epi >= 16) { flags |= 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)

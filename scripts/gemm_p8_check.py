@@ -27,7 +27,11 @@ def run(a, w, bias, epi, bm, bn, sk, out=None):
 
 def screen(M, N, K, epi, sk, reps=12):
     a, ws, bias = problem(M, N, K)
-    first = run(a, ws[0], bias, epi, 256, 256, sk).clone()
+    first = run(a, ws[0], bias, epi + 1024, 256, 256, sk).clone()
+    for _ in range(reps):          # the two-phase schedule must give the four-phase schedule's bits, launch after launch
+        if not torch.equal(run(a, ws[0], bias, epi + 512, 256, 256, sk), first):
+            print(f'TWO-PHASE SCHEDULE DIFFERS M={M} N={N} K={K} epi={epi} sk={sk}', flush=True)
+            return False
     ref = a.float() @ ws[0].float().T + (0 if epi == 4 else bias)
     got = first.float().sum(0) if epi == 4 else first.float()
     if epi == 1:
@@ -65,13 +69,13 @@ if __name__ == "__main__":
     for M in Ms:
         for name, N, K, epi in shapes:
             a, ws, bias = problem(M, N, K)
-            variants = [('auto', 0, 0, 0), ('p8', 256, 256, 1)]
+            variants = [('ph4', 256, 256, 1), ('ph2', 256, 256, 1)]          # four / two phases per K-tile (epi + 1024 / + 512)
             if epi == 4:
                 variants += [('p8/sk2', 256, 256, 2), ('p8/sk4', 256, 256, 4)]
             res = {v[0]: [] for v in variants}
             for rnd in range(5):                      # interleaved rounds in one process
                 for v in variants:
-                    res[v[0]].append(timeit(a, ws, bias, epi, v[1], v[2], v[3]))
+                    res[v[0]].append(timeit(a, ws, bias, epi + (512 if v[0] == 'ph2' else 1024 if v[0] == 'ph4' else 0), v[1], v[2], v[3]))
             fl = 2.0 * M * N * K
             line = f'M={M:5d} {name:5s} N={N:5d} K={K:5d} |'
             for v in variants:

@@ -22,5 +22,8 @@ for (name, M, N, K, epi) in (('qkv', 10752, 4608, 1536, 0), ('fc1', 10752, 6144,
     assert fn(buf) == 0
     print(f'== {name}: cycles from kernel start; [main loop end] [wait at barrier 1] [pack -> LDS] [wait at barrier 2] [LDS -> global stores]')
     for wv in range(8):
+        ph = [buf[wv * 16 + i] for i in range(6, 11)]
+        print(f'wave {wv}: K-tile 10 phases: ' + ' '.join(str(ph[i + 1] - ph[i]) for i in range(4)) + f' (sum {ph[4] - ph[0]})')
+    for wv in range(8):
         t = [buf[wv * 16 + i] for i in range(6)]
         print(f'wave {wv}: main loop {t[1] - t[0]:6d} | barrier {t[2] - t[1]:5d} | pack {t[3] - t[2]:5d} | barrier {t[4] - t[3]:5d} | store loop {t[5] - t[4]:5d} | total {t[5] - t[0]:6d}')

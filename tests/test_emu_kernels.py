@@ -413,6 +413,11 @@ def test_emu_gemm_256x256_eight_phase(nat):
         assert np.abs(out - ref).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
         out = nat.dbg_gemm(a, w, bias, epi=0, bm=256, bn=256, splitk=1).float().numpy()      # bf16 through the LDS transpose (TR = 1)
         assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max(), (M, N, K)
+        # two phases per K-tile (+ 512) against four (+ 1024): the same MFMA order per accumulator, so the same bits
+        for epi in (3, 0, 4):
+            bias_ = None if epi == 4 else bias
+            assert torch.equal(nat.dbg_gemm(a, w, bias_, epi=epi + 512, bm=256, bn=256, splitk=1),
+                               nat.dbg_gemm(a, w, bias_, epi=epi + 1024, bm=256, bn=256, splitk=1)), (M, N, K, epi)
         if K >= 256:
             out = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=2).numpy().sum(0)   # split-K slabs, 2 K-tiles per split
             assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
