@@ -364,6 +364,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         }
         rq_syncthreads();
     }
+    // the lane's residual values, ALL read before the first packed value is written back: each 8-byte slot is read and then
+    // overwritten in place, and the compiler will not move a later read above an earlier write to the same tile -- slot by slot
+    // that was 32 serialised LDS round trips (~2 800 cycles of a fused + residual tile's epilogue)
+    uint32_t rres[RPW][NJ][4][2];
+    if (p.resid) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ml = (wm * RPW + i) * HT_W + (lane & 31);
+                    const int nl = wn * (NJ * 32) + j * 32 + 8 * q + 4 * (lane >> 5);
+                    const uint32_t* rp = (const uint32_t*)(sT + ml * LDR + nl * 2);
+                    rres[i][j][q][0] = rp[0];
+                    rres[i][j][q][1] = rp[1];
+                }
+        rq_sched_barrier();
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int ty = wm * RPW + i, tx = lane & 31;
@@ -377,8 +396,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (p.resid) {
-                    const uint32_t* rp = (const uint32_t*)(sT + ml * LDR + nl * 2);
-                    const uint32_t r0 = rp[0], r1 = rp[1];
+                    const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
                     v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
                     v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
                 }

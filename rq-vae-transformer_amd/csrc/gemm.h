@@ -173,6 +173,25 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) bvec[j][q] = rq_bias4(bias, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
+        // likewise the lane's residual values (8 bytes per 4 columns), fetched up front with clamped addresses (rows / columns
+        // outside the problem are computed but never stored): inside the loop below they were one global round trip each
+        const bool res_vec = epi == EPI_BF16_RESID && (p.ldr & 3) == 0 && (p.N & 3) == 0;
+        uint32_t rres[MI][NI][4][2];
+        if (res_vec) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int m = m0 + wm * WM + i * 32 + (lane & 31), n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                        m = m < p.M ? m : p.M - 1;
+                        n = n < p.N ? n : p.N - 4;
+                        const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
+                        rres[i][j][q][0] = rp[0];
+                        rres[i][j][q][1] = rp[1];
+                    }
+        }
         RQ_GT(1);
         rq_syncthreads();                          // every wave is done reading the operand buffers
         RQ_GT(2);
@@ -191,8 +210,12 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                     if (epi == EPI_BF16_GELU) {
                         rq_gelu4(v, p.gelu_v2);
                     }
-                    if (epi == EPI_BF16_RESID) {
+                    if (res_vec) {
                         // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
+                        const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
+                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
+                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                    } else if (epi == EPI_BF16_RESID) {
                         const int m = m0 + ml;
                         if (m < p.M && n < p.N) {
                             const bf16_t* rp = p.resid + (long)m * p.ldr + n;
