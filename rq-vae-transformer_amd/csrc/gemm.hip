@@ -206,22 +206,30 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
         *bm = 64; *bn = 32; *splitk = 1;
         return;
     }
-    // 256 x 256 eight-phase kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how well the tile count fills
-    // rounds of 256 CUs.  From the interleaved A/B on MI355X (profiles/r02_gemm_p8_ab.txt): it wins whenever the last round is
-    // >= ~85 % full or there are >= 4 rounds; residual-producing GEMMs may split K to reach ~192-256 workgroups (M = 4096 fc2:
-    // 2 splits 76 us vs 102; M = 2048: 4 splits 45 vs 59), with >= 12 K-tiles per split.
+    // 256 x 256 kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how the tile count fills rounds of 256 CUs.  A
+    // small cost model fitted to the interleaved A/B runs on MI355X (profiles/r02_gemm_p8_ab.txt, r02_gemm_p8_picker.txt; within
+    // ~10 % of the measurements): a round costs nk * t_k + t_epilogue with t_k = 1.05 us per K-tile on a nearly empty chip to
+    // 1.5 us with every CU busy (the operand stream through the L2s), t_epilogue 6 us (bf16 tile) / 8 us (fp32 slab), + 4 us per
+    // launch; against the other tiles at ~750 TF (bf16 outputs) / ~650 TF (split-K slab GEMMs) at these row counts.
+    // Residual-producing GEMMs may split K 2 or 4 ways with >= 12 K-tiles per split.
     if (glds && !no_glds && !no_p8 && M >= 2048 && K % 64 == 0 && K / 64 >= 2) {
-        const int MT = (M + 255) / 256, NT = (N + 255) / 256;
+        const int MT = (M + 255) / 256, NT = (N + 255) / 256, nk = K / 64;
         const long tiles = (long)MT * NT;
-        int sk = 1;
-        if (allow_splitk && tiles < 160) {
-            while (sk < 4 && tiles * sk < 160 && (K / 64) % (sk * 2) == 0 && K / 64 / (sk * 2) >= 12) sk *= 2;
+        const double t_epi = allow_splitk ? 8.0 : 6.0;
+        double best = 1e30;
+        int best_sk = 1;
+        for (int sk = 1; sk <= (allow_splitk ? 4 : 1); sk *= 2) {
+            if (sk > 1 && (nk % sk != 0 || nk / sk < 12)) continue;
+            const long wgs = tiles * sk, full = wgs / 256, rem = wgs % 256;
+            const int nkp = nk / sk;
+            double t = 4.0 + (double)full * (nkp * 1.5 + t_epi);
+            if (rem) t += nkp * (1.05 + 0.45 * (double)rem / 256.0) + t_epi;
+            if (sk > 1) t += 6.0 * (sk - 1);                  // sk fp32 slabs written here and read again by the consumer
+            if (t < best) { best = t; best_sk = sk; }
         }
-        const long wgs = tiles * sk;
-        const long rounds = (wgs + 255) / 256;
-        const double fill = (double)wgs / (256.0 * rounds);
-        if (wgs >= 160 && (fill >= 0.84 || rounds >= 4 || (fill >= 0.74 && (N <= 2048 || M >= 8192)))) {
-            *bm = 256; *bn = 256; *splitk = sk; *glds = 2;
+        const double other = 2.0 * M * (double)N * K / 1e6 / (allow_splitk ? 650.0 : 750.0);      // us
+        if (best < other) {
+            *bm = 256; *bn = 256; *splitk = best_sk; *glds = 2;
             return;
         }
     }

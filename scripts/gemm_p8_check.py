@@ -69,7 +69,7 @@ if __name__ == "__main__":
     for M in Ms:
         for name, N, K, epi in shapes:
             a, ws, bias = problem(M, N, K)
-            variants = [('ph4', 256, 256, 1), ('ph2', 256, 256, 1)]          # four / two phases per K-tile (epi + 1024 / + 512)
+            variants = [('auto', 0, 0, 0), ('p8', 256, 256, 1)] if os.environ.get('RQ_AUTO') else [('ph4', 256, 256, 1), ('ph2', 256, 256, 1)]   # picker vs forced 256x256; or four / two phases per K-tile (epi + 1024 / + 512)
             if epi == 4:
                 variants += [('p8/sk2', 256, 256, 2), ('p8/sk4', 256, 256, 4)]
             res = {v[0]: [] for v in variants}
