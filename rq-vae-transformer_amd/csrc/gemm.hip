@@ -92,7 +92,13 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
         // balanced contiguous ranges per XCD (sched 3 in rq_gemm_tile_coords); groups of 8 m-tiles: 32 concurrent tiles of
         // an XCD = 8 A panels x 4 W panels
         g.sched = 3;
-        g.sched_gm = env_gm > 0 ? env_gm : 8;
+        // group height: ~8 m-tiles, preferring a divisor of MT so that no ragged last group is left (42 m-tiles: 6 -- the
+        // classifier measured 546 -> 525 us, the other shapes are insensitive; profiles/r02_gemm_p8_picker.txt)
+        int gm = 8;
+        static const int pref[] = {8, 6, 7, 5, 10, 9, 4};
+        for (int c : pref)
+            if (MT % c == 0) { gm = c; break; }
+        g.sched_gm = env_gm > 0 ? env_gm : gm;
         if (g.sched_gm > MT) g.sched_gm = MT;
         nblocks = 8 * ((MT * NT + 7) / 8);
     }
