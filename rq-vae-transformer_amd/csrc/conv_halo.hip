@@ -941,18 +941,31 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
     const int ty0 = (trem / tiles_x) * OT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
 
     // ---- stage the patch: piece q = (pixel hp, 16-byte chunk cq of the Cin channels); cq is the same for all of a
-    // thread's pieces (256 % (Cin/8) == 0), so its 8 (scale, shift) pairs are loaded once
-    const int CPP = p.Cin / 8;                             // chunks per pixel: 8, 16 or 32
+    // thread's pieces (256 % (Cin/8) == 0), so its 8 (scale, shift) pairs are loaded once.  All of a thread's pieces (13 at
+    // Cin = 128) are requested before the first is used, and the weight rows (fp32, 16-byte loads) ride in the same batch:
+    // four pieces at a time and a scalar weight loop cost three extra memory round trips and ~18 serialised L2 ones per tile.
+    const int cpp_sh = p.Cin == 64 ? 3 : p.Cin == 128 ? 4 : 5;      // chunks per pixel CPP = Cin / 8 = 8, 16 or 32
+    const int CPP = 1 << cpp_sh;
     const int cq = tid & (CPP - 1);
-    const int n_piece = OP_N * CPP;
+    const int n_piece = OP_N << cpp_sh;
     f32x4 gs[4];
     if (FUSE_GN) {
         const float* gn = p.gn + ((long)img * p.Cin + cq * 8) * 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4);
     }
+    // weights: fp32 [Cout][9*Cin] -> bf16 rows 0..Cout-1 of sW (rows Cout..7 feed output rows nobody stores: zero)
+    const int KT = 9 * p.Cin;
+    const int n_w4 = p.Cout * (KT >> 2);                   // 16-byte groups of real weights
+    constexpr int WIT = 5;                                 // covers Cout = 4, Cin = 128 in one batch
+    f32x4 wr[WIT];
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = tid + O_NTH * k;
+        if (i < n_w4) wr[k] = *(const f32x4*)(p.w + (long)i * 4);
+    }
     const char* gX = (const char*)p.x;
-    constexpr int PIT = 4;                                 // pieces in flight per thread
+    constexpr int PIT = 13;                                // pieces in flight per thread
     for (int q0 = tid; q0 < n_piece; q0 += O_NTH * PIT) {
         rq_u128 r[PIT];
         unsigned loff[PIT];
@@ -961,12 +974,12 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
         for (int k = 0; k < PIT; ++k) {
             const int q = q0 + O_NTH * k;
             in[k] = q < n_piece;
-            const int hp = in[k] ? q / CPP : 0;
+            const int hp = q >> cpp_sh;
             const int hy = hp / HP_W, hx = hp - hy * HP_W;
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             ok[k] = in[k] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-            r[k] = ld128(gX + ((((long)img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);     // clamped: always readable
+            if (in[k]) r[k] = ld128(gX + ((((long)img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);     // clamped: always readable
             loff[k] = (unsigned)((cq >> 3) * O_PLANE) + halo_lds_off(hy, hx, cq & 7);
         }
 #pragma unroll
@@ -993,13 +1006,20 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
             st128(sH + loff[k], v);
         }
     }
-    // ---- weights: fp32 [Cout][9*Cin] -> bf16 rows 0..Cout-1, zero rows up to 8
-    const int KT = 9 * p.Cin;
-    for (int i = tid; i < 8 * (KT / 2); i += O_NTH) {
-        const int row = i / (KT / 2), k2 = (i - row * (KT / 2)) * 2;
-        uint32_t v = 0;
-        if (row < p.Cout) v = pack_bf16x2(p.w[(long)row * KT + k2], p.w[(long)row * KT + k2 + 1]);
-        *(uint32_t*)(sW + row * wrow + k2 * 2) = v;
+    // ---- weights into LDS: group i = (row, 4 consecutive k); the rest of the 8 rows zero
+    auto store_w4 = [&](int i, const f32x4& v) {
+        const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
+        *(uint64_t*)(sW + row * wrow + k4 * 2) = (uint64_t)pack_bf16x2(v[0], v[1]) | ((uint64_t)pack_bf16x2(v[2], v[3]) << 32);
+    };
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = tid + O_NTH * k;
+        if (i < n_w4) store_w4(i, wr[k]);
+    }
+    for (int i = tid + O_NTH * WIT; i < n_w4; i += O_NTH) store_w4(i, *(const f32x4*)(p.w + (long)i * 4));      // (Cin = 256)
+    for (int i = n_w4 + tid; i < 8 * (KT >> 2); i += O_NTH) {
+        const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
+        *(uint64_t*)(sW + row * wrow + k4 * 2) = 0ull;
     }
     rq_syncthreads();
 
