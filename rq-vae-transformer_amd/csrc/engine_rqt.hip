@@ -84,16 +84,6 @@ struct rqamd_rqt {
     const float* step_pend_slabs = nullptr;        // the body's last fc2 partials, consumed by depth 0 of the same position
     int step_pend_n = 0;
     const float* step_pend_bias = nullptr;
-
-    // persistent stack kernel for small batches (rqt_stack_kernel): descriptor tables + grid-barrier flags on the device
-    int stack_mode = 0;            // RQAMD_STACK: 0 off, 1 on (rows <= stack_rows and rq_stack_supported)
-    int stack_G = 0, stack_rows = 128;
-    bool stack_stepwise = false;   // RQAMD_STACK_STEPWISE: one launch per phase (diagnostics)
-    bool stack_dirty = true;
-    DevBuf stack_tab, stack_act;   // descriptor tables + barrier flags; per-block activation regions (StackArgs::act)
-    std::vector<StackLayer> stack_host;
-    StackLayer *d_body = nullptr, *d_head = nullptr;
-    unsigned* stack_flags = nullptr;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -120,18 +110,6 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     if (c->D < 1 || c->D > 8 || c->H < 1 || c->W < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: bad block_size");
     rqamd_rqt* h = new rqamd_rqt();
     h->cfg = *c;
-    {
-        const char* e = getenv("RQAMD_STACK");
-        h->stack_mode = e ? atoi(e) : 0;
-        int cus = 0;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-        e = getenv("RQAMD_STACK_G");
-        h->stack_G = e ? atoi(e) : (cus >= 256 ? 256 : 0);
-        if (h->stack_G > cus && cus > 0 && !e) h->stack_G = 0;
-        e = getenv("RQAMD_STACK_ROWS");
-        if (e) h->stack_rows = atoi(e);
-        h->stack_stepwise = getenv("RQAMD_STACK_STEPWISE") != nullptr;
-    }
     h->E = c->embed_dim; h->HW = c->H * c->W; h->D = c->D; h->V = c->vocab_size; h->Din = c->input_embed_dim;
     h->cond_len = c->block_size_cond < 1 ? 1 : c->block_size_cond;
     h->Tbody = h->HW + h->cond_len - 1;
@@ -327,7 +305,6 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     // (cap 0, no graphs), never pointing at freed memory; the caller may retry with a smaller batch.
     h->cap = 0;
     h->gvalid = false;
-    h->stack_dirty = true;
     for (auto& L : h->body) L.kc = L.vc = nullptr;
     for (auto& L : h->head) L.kc = L.vc = nullptr;
     const size_t E = h->E, V = h->V;
@@ -449,60 +426,10 @@ struct StepCtx {
     float* cond_logits_out; // teacher-forced, text-conditioned: (B, cond_len-1, vocab_size_cond) or null
 };
 
-// ---- persistent stack kernel (small batches)
-static bool use_stack(const rqamd_rqt* h, int rows, int Tcap, size_t n_layers) {
-    return h->stack_mode > 0 && n_layers > 0 && h->stack_G > 0 && rows <= h->stack_rows && !h->prof.on &&
-           rq_stack_supported(h->E, h->cfg.n_head, Tcap, h->stack_G, h->max_slabs);
-}
-// descriptor tables follow the KV-cache pointers: rebuilt after every regrowth (never while a graph is being captured:
-// begin_batch calls this)
-static int ensure_stack(rqamd_rqt* h, hipStream_t st) {
-    if (h->stack_mode <= 0 || !h->stack_dirty) return RQAMD_OK;
-    const size_t nb = h->body.size(), nh = h->head.size();
-    const size_t tab = al((nb + nh) * sizeof(StackLayer)), fl = al((size_t)(1 + 1024) * 32 * 4);
-    RQ_TRY(h->stack_tab.reserve(tab + fl));
-    RQ_TRY(h->stack_act.reserve((size_t)(nb > nh ? nb : nh) * h->stack_rows * 10 * h->E * 2));
-    h->stack_host.resize(nb + nh);
-    auto fill = [](StackLayer& d, const RqtLayer& L) {
-        d.ln1w = L.ln1w; d.ln1b = L.ln1b; d.ln2w = L.ln2w; d.ln2b = L.ln2b; d.bproj = L.bproj; d.bfc2 = L.bfc2;
-        d.w[0] = L.wqkv; d.w[1] = L.wproj; d.w[2] = L.wfc1; d.w[3] = L.wfc2;
-        d.gb[0] = L.bqkv; d.gb[1] = nullptr; d.gb[2] = L.bfc1; d.gb[3] = nullptr;
-        d.kc = L.kc; d.vc = L.vc;
-    };
-    for (size_t i = 0; i < nb; ++i) fill(h->stack_host[i], h->body[i]);
-    for (size_t i = 0; i < nh; ++i) fill(h->stack_host[nb + i], h->head[i]);
-    h->d_body = h->stack_tab.as<StackLayer>();
-    h->d_head = h->d_body + nb;
-    h->stack_flags = (unsigned*)((char*)h->stack_tab.p + tab);
-    RQ_HIP(hipMemcpyAsync(h->d_body, h->stack_host.data(), (nb + nh) * sizeof(StackLayer), hipMemcpyHostToDevice, st));
-    RQ_HIP(hipMemsetAsync(h->stack_flags, 0, fl, st));
-    RQ_HIP(hipStreamSynchronize(st));              // stack_host may change before an asynchronous copy has read it
-    h->stack_dirty = false;
-    return RQAMD_OK;
-}
-static int run_stack(rqamd_rqt* h, const StackLayer* layers, const std::vector<RqtLayer>& host_layers, const float* x_in, float* x, Pending& pend,
-                     const float* addvec, int rows, const int* step, int step_off, int t_max, int Tcap, hipStream_t st) {
-    if (h->stack_dirty || !layers) return rq_fail(RQAMD_ERR_STATE, "rqt: stack tables not built");
-    StackArgs a{};
-    a.layers = layers; a.n_layers = (int)host_layers.size();
-    a.x_in0 = x_in; a.x = x; a.pend_slabs = pend.slabs; a.pend_n = pend.n; a.pend_bias = pend.bias; a.addvec = addvec;
-    a.act = h->stack_act.as<bf16_t>(); a.act_stride = (long)h->stack_rows * 10 * h->E; a.slabs = h->slabs;
-    a.step = step; a.step_off = step_off; a.Tcap = Tcap;
-    const int nj_cap = (Tcap + 7) / 8;
-    a.nj = t_max >= 0 ? (t_max >> 3) + 1 : nj_cap;
-    if (a.nj > nj_cap) a.nj = nj_cap;
-    a.rows = rows; a.E = h->E; a.nh = h->cfg.n_head; a.eps = 1e-5f; a.gelu_v2 = h->cfg.gelu_v2;
-    a.flags = h->stack_flags;
-    RQ_TRY(rq_launch_stack(a, h->stack_G, h->stack_stepwise, st));
-    pend.slabs = h->slabs; pend.n = 4; pend.bias = host_layers.back().bfc2;
-    return RQAMD_OK;
-}
-
 // body stack for the token whose input is already in h->x; leaves the last fc2 un-reduced in `pend`
 // t_max: host-side bound on the number of cached keys (selects the attention kernel's register-block count)
 static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, int t_max, Pending& pend, hipStream_t st) {
     pend = Pending{nullptr, 0, nullptr};
-    if (use_stack(h, rows, h->Tbody, h->body.size())) return run_stack(h, h->d_body, h->body, h->x, h->x, pend, nullptr, rows, step, step_off, t_max, h->Tbody, st);
     for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, step, step_off, t_max, h->Tbody, st));
     return RQAMD_OK;
 }
@@ -561,12 +488,8 @@ static int position_depth(rqamd_rqt* h, const StepCtx& c, int d, const Pending& 
         else RQ_TRY(tok_embed(h, c, 0, d - 1, d, h->pos_d, false, d, h->xh, st));
         hp = Pending{nullptr, 0, nullptr};
     }
-    if (use_stack(h, B, h->D, h->head.size())) {
-        RQ_TRY(run_stack(h, h->d_head, h->head, x_in, h->xh, hp, addvec, B, nullptr, d, d, h->D, st));
-    } else {
-        for (size_t li = 0; li < h->head.size(); ++li) {
-            RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
-        }
+    for (size_t li = 0; li < h->head.size(); ++li) {
+        RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
     }
     ResidLnArgs r{};
     r.x_in = h->xh; r.x_out = nullptr; r.slabs = hp.slabs; r.n_slabs = hp.n; r.bias = hp.bias;
@@ -609,7 +532,6 @@ static int begin_batch(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, c
     h->step_on = false;                            // any new batch ends a stepping sequence (same workspace)
     RQ_TRY(ensure_batch(h, B));
     RQ_TRY(finalize_tables(h, st));
-    RQ_TRY(ensure_stack(h, st));
     RQ_HIP(hipMemcpyAsync(h->xs, partial, (size_t)B * h->HW * h->D * 8, hipMemcpyDeviceToDevice, st));
     if (cond) RQ_HIP(hipMemcpyAsync(h->cond, cond, (size_t)B * h->cond_len * 8, hipMemcpyDeviceToDevice, st));
     else RQ_HIP(hipMemsetAsync(h->cond, 0, (size_t)B * h->cond_len * 8, st));

@@ -164,42 +164,3 @@ static __device__ __forceinline__ rq_u128 zero128() { rq_u128 z; z.x = z.y = z.z
 static __device__ __forceinline__ bf16x8 as_bf16x8(rq_u128 v) {
     union { rq_u128 u; bf16x8 b; } c; c.u = v; return c.b;
 }
-
-// ---------------------------------------------------------------------------------------------
-// Accesses that are coherent between workgroups of ONE running kernel (csrc/rqt_kernels.hip, the persistent stack kernel).
-// Every XCD has its own L2: a plain store may stay dirty in the writer's L2 and a plain load may hit a stale line in the
-// reader's, and the fences that repair that (buffer_wbl2 / buffer_inv sc1) walk the whole L2 -- 11 us per grid barrier with 32
-// workgroups per XCD issuing them (profiles/r02_grid_barrier_micro.txt).  Relaxed agent-scope atomics are sc1 accesses: they are
-// performed at the memory side, need no cache maintenance, and `s_waitcnt vmcnt(0)` after the stores orders them before a
-// later flag store.  At most 8 bytes per access (there is no wider atomic), so a 16-byte fragment is two loads.
-#ifndef RQ_EMU
-static __device__ __forceinline__ uint64_t rq_ldc64(const void* p) { return __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ uint32_t rq_ldc32(const void* p) { return __hip_atomic_load((const uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ void rq_stc64(void* p, uint64_t v) { __hip_atomic_store((uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ void rq_stc32(void* p, uint32_t v) { __hip_atomic_store((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-static __device__ __forceinline__ void rq_stc16(void* p, uint16_t v) { __hip_atomic_store((uint16_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// all of this workgroup's earlier stores performed (call in every thread, before the barrier that precedes the flag store)
-static __device__ __forceinline__ void rq_stores_done() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-}
-static __device__ __forceinline__ void rq_loads_after() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-static __device__ __forceinline__ void rq_spin_pause() { __builtin_amdgcn_s_sleep(1); }
-static __device__ __forceinline__ int rq_syncthreads_and(int v) { return __syncthreads_and(v); }
-#else
-static inline uint64_t rq_ldc64(const void* p) { return *(const uint64_t*)p; }
-static inline uint32_t rq_ldc32(const void* p) { return *(const uint32_t*)p; }
-static inline void rq_stc64(void* p, uint64_t v) { *(uint64_t*)p = v; }
-static inline void rq_stc32(void* p, uint32_t v) { *(uint32_t*)p = v; }
-static inline void rq_stc16(void* p, uint16_t v) { *(uint16_t*)p = v; }
-static inline void rq_stores_done() {}
-static inline void rq_loads_after() {}
-static inline void rq_spin_pause() {}
-static inline int rq_syncthreads_and(int v) { rq_syncthreads(); return v; }      // (the emulator never runs a grid barrier)
-#endif
-static __device__ __forceinline__ rq_u128 rq_ldc128(const void* p) {
-    const uint64_t a = rq_ldc64(p), b = rq_ldc64((const char*)p + 8);
-    rq_u128 v;
-    v.x = (uint32_t)a; v.y = (uint32_t)(a >> 32); v.z = (uint32_t)b; v.w = (uint32_t)(b >> 32);
-    return v;
-}

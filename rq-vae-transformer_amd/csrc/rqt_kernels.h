@@ -79,50 +79,6 @@ struct SampleArgs {
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s);
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s);
-
-// Whole AttentionStack step (attentions.py:162-165: every AttentionBlock.cached_forward of a stack, one token per row) as ONE
-// persistent launch for small batches -- see rqt_stack_kernel in rqt_kernels.hip.
-struct StackLayer {          // device-resident, one per AttentionBlock
-    const float *ln1w, *ln1b, *ln2w, *ln2b, *bproj, *bfc2;
-    const bf16_t* w[4];                            // qkv, proj, fc1, fc2: [N][K] bf16
-    const float* gb[4];                            // bias applied by the GEMM phase itself (qkv, fc1) or null (proj, fc2: by the next LayerNorm phase)
-    bf16_t *kc, *vc;                               // KV cache [rows][nh][Tcap][64]
-};
-struct StackArgs {
-    const StackLayer* layers;
-    int n_layers;
-    const float* x_in0;      // input of the first block (may be x itself)
-    float* x;                // [rows][E] fp32 residual stream, updated in place
-    const float* pend_slabs; // un-reduced output of the GEMM that precedes the stack (or null), its slab count and bias
-    int pend_n;
-    const float* pend_bias;
-    const float* addvec;     // [E] added to every row on entry (positional embedding) or null
-    // bf16 activations exchanged between the phases: one region PER BLOCK, [LayerNorm1 out | qkv | attention out | LayerNorm2
-    // out | GELU(fc1)] = rows x (E, 3E, E, E, 4E).  No address is written twice in a launch, so no L2 can hold a stale copy:
-    // producers write through (rq_stc*), consumers use plain cached loads and the 32 workgroups of an XCD share one fetch.
-    bf16_t* act;
-    long act_stride;         // elements between the regions of consecutive blocks (>= rows * 10 E)
-    float* slabs;            // [ks][rows][E]; on exit holds the last fc2's ks_fc2 partial slabs (bias bfc2 pending)
-    const int* step;         // device-side position counter (or null); t = *step + step_off cached keys
-    int step_off, nj, Tcap;  // nj = register blocks of 8 keys (host bound on t, as rq_launch_attn_decode)
-    int rows, E, nh;
-    float eps;
-    int gelu_v2;
-    int ks_proj, ks_fc2;     // K splits of the residual-producing GEMMs
-    // the four GEMM phases (qkv, proj, fc1, fc2) as tables indexed by the GEMM number -- filled by rq_launch_stack.  (A chain of
-    // `if (phase == ..)` assignments building the same descriptor compiled, on ROCm 7.2, into code that left the weight pointer
-    // of the last case undefined: a memory fault at the first fc2 phase.)
-    int gAoff[4], gOutOff[4]; // operand / output of each GEMM as an offset (units of rows * E) into the block's region; output < 0: p.slabs
-    int gN[4], gK[4], gKS[4], gEpi[4], gLda[4], gLdo[4];      // gEpi 0: +bias -> bf16; 1: +bias, GELU -> bf16; 2: fp32 partial slab
-    unsigned* flags;         // grid barrier: [0] epoch base, [32 * (1 + w)] arrival flag of workgroup w
-    int step_lo, step_hi;    // (block * 7 + phase) range of this launch; a partial range never crosses a grid barrier
-    int dbg;                 // diagnostics (RQAMD_STACK_DBG): 1 no weight prefetch after a GEMM, 2 skip the fc2 GEMM
-};
-constexpr int RQ_STACK_PHASES = 7;
-// supported: E % 256 == 0, E <= 1536, head_dim 64, Tcap <= 64, and a workgroup count G (<= CUs) that divides the GEMMs
-bool rq_stack_supported(int E, int nh, int Tcap, int G, int max_slabs);
-// stepwise: one launch per phase instead of grid barriers (diagnostics; the host emulator always runs this way)
-int rq_launch_stack(StackArgs a, int G, bool stepwise, hipStream_t s);
 int rq_launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s);
 int rq_launch_embed_tokens(const EmbedTokArgs& a, hipStream_t s);
 // x[(img, i)] = cond_emb[cond[img][i]] + pos_emb_cond[i] for i < n_tok: the prefix rows of the prefill

@@ -1,7 +1,6 @@
 // rqt_kernels.hip -- see rqt_kernels.h for the reference call sites of each kernel.
 #include "rqt_kernels.h"
 #include "rq_common.h"
-#include "gemm.h"          // rq_gelu4 (the fc1 epilogue of the stack kernel rounds like the GEMM kernels')
 #include <mutex>
 #include <stdlib.h>
 
@@ -197,9 +196,7 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
 // P = (row, head) pairs per wavefront (heads h0 .. h0+P-1 of one row), processed stage by stage so that the loads of
 // all P pairs are in flight together: at short contexts a wavefront's lifetime is one memory round trip, and with
 // 98 304 pairs per launch the launch time was 12 rounds of 8192 resident wavefronts x that latency (45 us at t = 0).
-// COH: the output row is written through the coherent accessors of rq_hip.h (the persistent stack kernel, where other
-// workgroups of the same launch consume it; its q / k / v come from a region no cache has seen before, see StackArgs::act).
-template <int NJ, bool DYN, int P, bool COH = false>
+template <int NJ, bool DYN, int P>
 static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, int b, int h0, int t) {
     const int E = p.E, Tcap = p.Tcap;
     const int cc = lane & 7, g = lane >> 3;
@@ -327,8 +324,7 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
         const float keep1 = up8 ? a2[1] : a2[0], send1 = up8 ? a2[0] : a2[1];
         const float o1 = keep1 + rq_dpp_ror8(send1);
         const int eo = (up32 ? 4 : 0) + (up16 ? 2 : 0) + (up8 ? 1 : 0);            // which of the 8 channels of chunk cc
-        if (COH) rq_stc16(p.y + (long)b * E + (h0 + i) * 64 + cc * 8 + eo, (uint16_t)(pack_bf16x2(o1, 0.f) & 0xffffu));
-        else p.y[(long)b * E + (h0 + i) * 64 + cc * 8 + eo] = (bf16_t)(pack_bf16x2(o1, 0.f) & 0xffffu);
+        p.y[(long)b * E + (h0 + i) * 64 + cc * 8 + eo] = (bf16_t)(pack_bf16x2(o1, 0.f) & 0xffffu);
     }
 }
 
@@ -1341,362 +1337,4 @@ extern "C" int rqamd_sample_logits(const float* logits, int rows, int vocab, flo
     a.seed = seed; a.offset = offset; a.out = samples_out; a.out_stride = 1; a.probs_out = probs_out; a.D = 1;
     a.redo = row_flags;     // caller-owned (rows ints) or NULL: without it every row takes the general kernel
     return rq_launch_sample(a, (hipStream_t)stream);
-}
-
-
-// =================================================================================================
-// Small batches: a whole AttentionStack step as ONE persistent launch.
-//
-// At B <= ~128 rows a decode step is 7 launches per block (2 resid_ln, 4 GEMMs, attention) of 3-12 us each around 2-3 us of weight
-// streaming: every launch starts cold (dispatch, first HBM round trip, drain), so the stack runs at ~1.3 TB/s of weights
-// (profiles/r02_gemm_skinny_ab.txt).  Here G workgroups (one per CU) stay resident for all blocks of the
-// stack and walk 7 phases per block separated by a software grid barrier (1.6 us at 256 workgroups, rq_hip.h):
-//   0  x += pending partial slabs + bias (+ addvec); y = LayerNorm1(x)          one wavefront per row
-//   1  qkv = y Wqkv^T + b                                                         GEMM, N split over the workgroups
-//   2  ya = attention(q, K cache + k, V cache + v); append k, v                   one wavefront per (row, head)
-//   3  slabs[ks] = ya Wproj^T (K split ks ways)                                   GEMM
-//   4  x += slabs + bproj; y = LayerNorm2(x)
-//   5  h = GELU(y Wfc1^T + b)                                                     GEMM
-//   6  slabs[ks] = h Wfc2^T (K split)                                             GEMM; reduced by phase 0 of the next block
-// GEMM phases: workgroup w owns NC <= 32 weight rows x one K split, i.e. all of its weights fit its registers (<= 24 fragments
-// per lane): they are requested right after the PREVIOUS GEMM's last MFMA, so the weight stream runs underneath the epilogue,
-// the barriers and the phase in between instead of starting cold, and the phase itself only waits for its A rows (L2 / MALL).
-// Wavefront v takes K quarter v; the four partial 64 x 32 tiles meet in LDS.  Row blocks of 64 reuse the weight registers.
-// Everything one workgroup writes and another reads inside the launch (y, qkv, ya, h, slabs) moves through the coherent
-// accessors of rq_hip.h; x rows are private to a wavefront; weights and earlier cache rows are read-only here.
-// Arithmetic: the same bf16 operands, fp32 accumulation, bias / GELU / LayerNorm forms as the per-launch kernels; only the
-// summation order over K differs (tests/test_gpu_parity.py compares the two paths).
-constexpr int STK_T = 256, STK_MAXKS = 24, STK_ACH = 12;      // STK_ACH: K steps of A fragments requested together
-
-struct StkGemm {
-    const bf16_t* A; int lda;
-    const bf16_t* W; int N, K, NC, KS, epi;      // epi 0: +bias -> bf16; 1: +bias, GELU -> bf16; 2: fp32 partial slab
-    const float* bias; void* out; int ldo;
-};
-static __device__ __forceinline__ bool stk_is_gemm(int ph) { return ph == 1 || ph == 3 || ph == 5 || ph == 6; }
-static __device__ __forceinline__ StkGemm stk_gemm(const StackArgs& p, const StackLayer& L, int layer, int ph, int G) {
-    const int gi = ph == 6 ? 3 : ph >> 1;                     // phases 1, 3, 5, 6 -> GEMM 0..3
-    StkGemm g;
-    const long re = (long)p.rows * p.E;
-    bf16_t* act = p.act + (long)layer * p.act_stride;
-    g.A = act + p.gAoff[gi] * re; g.lda = p.gLda[gi]; g.W = L.w[gi]; g.N = p.gN[gi]; g.K = p.gK[gi]; g.KS = p.gKS[gi]; g.epi = p.gEpi[gi];
-    g.bias = L.gb[gi]; g.out = p.gOutOff[gi] < 0 ? (void*)p.slabs : (void*)(act + p.gOutOff[gi] * re); g.ldo = p.gLdo[gi];
-    g.NC = g.N * g.KS / G;
-    return g;
-}
-
-// weight fragments of this workgroup's unit: lane (n = lane & 31, kg = lane >> 5) holds W[c0 + n][k .. k+8) of K step i of
-// the wavefront's K quarter -- the B operand of v_mfma_f32_32x32x16_bf16
-static __device__ __forceinline__ void stk_load_w(const StkGemm& g, int G, int wg, int wave, int lane, rq_u128 (&W)[STK_MAXKS]) {
-    const int NT = G / g.KS, nt = wg % NT, ksp = wg / NT, KL = g.K / g.KS, nks = KL >> 6;
-    const int n = lane & 31, kg = lane >> 5;
-    const bool valid = n < g.NC;
-    const bf16_t* src = g.W + (long)(nt * g.NC + (valid ? n : 0)) * g.K + ksp * KL + wave * (KL >> 2) + kg * 8;
-#pragma unroll
-    for (int i = 0; i < STK_MAXKS; ++i) {
-        W[i] = zero128();
-        if (i < nks && valid) W[i] = ld128(src + i * 16);
-    }
-}
-
-template <int CH, bool TWO>
-static __device__ __forceinline__ void stk_mma(const bf16_t* a0, const bf16_t* a1, bool v0, bool v1, int nks, const rq_u128 (&W)[STK_MAXKS], f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int i0 = 0; i0 < STK_MAXKS; i0 += CH) {
-        if (i0 >= nks) break;                                 // uniform
-        rq_u128 fa[TWO ? 2 : 1][CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            fa[0][j] = zero128();
-            if (TWO) fa[TWO ? 1 : 0][j] = zero128();
-            if (i0 + j < nks) {
-                if (v0) fa[0][j] = ld128(a0 + (i0 + j) * 16);
-                if (TWO && v1) fa[TWO ? 1 : 0][j] = ld128(a1 + (i0 + j) * 16);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (i0 + j < nks) {
-                acc[0] = rq_mfma_32x32x16_bf16(as_bf16x8(fa[0][j]), as_bf16x8(W[i0 + j]), acc[0]);
-                if (TWO) acc[1] = rq_mfma_32x32x16_bf16(as_bf16x8(fa[TWO ? 1 : 0][j]), as_bf16x8(W[i0 + j]), acc[1]);
-            }
-        }
-    }
-}
-
-static __device__ __forceinline__ void stk_run_gemm(const StackArgs& p, const StkGemm& g, int G, int wg, int tid, const rq_u128 (&W)[STK_MAXKS], float* red) {
-    const int lane = tid & 63, wave = rq_uniform(tid >> 6);
-    const int NT = G / g.KS, nt = wg % NT, ksp = wg / NT, KL = g.K / g.KS, nks = KL >> 6;
-    const int n = lane & 31, kg = lane >> 5;
-    const int c0 = nt * g.NC;
-    for (int r0 = 0; r0 < p.rows; r0 += 64) {
-        f32x16 acc[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-        const bool two = r0 + 32 < p.rows;                    // uniform: the second 32-row block has live rows
-        const bool v0 = r0 + n < p.rows, v1 = r0 + 32 + n < p.rows;
-        const bf16_t* a0 = g.A + (long)(r0 + (v0 ? n : 0)) * g.lda + ksp * KL + wave * (KL >> 2) + kg * 8;
-        const bf16_t* a1 = g.A + (long)(r0 + (v1 ? 32 + n : 0)) * g.lda + ksp * KL + wave * (KL >> 2) + kg * 8;
-        // every A fragment of a batch is requested before the first MFMA: a round trip to the memory side costs ~2 us here
-        // (the weight stream of the next GEMM runs underneath), so a phase is as long as its chain of dependent round trips
-        if (two) stk_mma<STK_ACH, true>(a0, a1, v0, v1, nks, W, acc);
-        else stk_mma<STK_MAXKS, false>(a0, a1, v0, v1, nks, W, acc);
-        // the four K quarters meet in LDS: red[wave][m][n]; C layout: register r of lane = row (r>>2)*8 + kg*4 + (r&3), column n
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb * 32 + (r >> 2) * 8 + kg * 4 + (r & 3);
-                red[(wave * 64 + m) * 32 + n] = acc[mb][r];
-            }
-        rq_syncthreads();
-        {
-            const int m = tid >> 2, n8 = (tid & 3) * 8, row = r0 + m;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const f32x4 lo = *(const f32x4*)(red + (w * 64 + m) * 32 + n8), hi = *(const f32x4*)(red + (w * 64 + m) * 32 + n8 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[j] += lo[j]; v[4 + j] += hi[j]; }
-            }
-            if (row < p.rows) {
-                if (g.epi == 2) {
-                    float* o = (float*)g.out + ((long)ksp * p.rows + row) * g.ldo + c0 + n8;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2)
-                        if (n8 + j < g.NC) rq_stc64(o + j, (uint64_t)__float_as_uint(v[j]) | ((uint64_t)__float_as_uint(v[j + 1]) << 32));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (n8 + j < g.NC) ? g.bias[c0 + n8 + j] : 0.f;
-                    if (g.epi == 1) {
-                        float a[4] = {v[0], v[1], v[2], v[3]}, b[4] = {v[4], v[5], v[6], v[7]};
-                        rq_gelu4(a, p.gelu_v2); rq_gelu4(b, p.gelu_v2);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
-                    }
-                    bf16_t* o = (bf16_t*)g.out + (long)row * g.ldo + c0 + n8;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2)
-                        if (n8 + j < g.NC) rq_stc32(o + j, pack_bf16x2(v[j], v[j + 1]));
-                }
-            }
-        }
-        rq_syncthreads();
-    }
-}
-
-// residual add (+ partial slabs + bias + addvec) and LayerNorm, a wavefront per row: the arithmetic of resid_ln_wave_kernel
-static __device__ __forceinline__ void stk_run_ln(const StackArgs& p, const float* x_in, const float* slabs, int ns, const float* bias, const float* addvec,
-                                                  const float* gamma, const float* beta, bf16_t* y, int G, int wg, int tid) {
-    const int lane = tid & 63, wave = rq_uniform(tid >> 6);
-    const int E = p.E, nv = E >> 8;
-    const long slab_stride = (long)p.rows * E;
-    for (int row = wg * 4 + wave; row < p.rows; row += 4 * G) {
-        const long base = (long)row * E;
-        f32x4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nv) v[i] = *(const f32x4*)(x_in + base + (lane + 64 * i) * 4);
-        // all slabs requested in one batch (one round trip, not one per slab), four at a time; summed in slab order
-        for (int s0 = 0; s0 < ns; s0 += 4) {
-            rq_u128 t[4][8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (i < nv && s0 + q < ns) t[q][i] = rq_ldc128(slabs + (s0 + q) * slab_stride + base + (lane + 64 * i) * 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (i < nv && s0 + q < ns) {
-                        v[i][0] += __uint_as_float(t[q][i].x); v[i][1] += __uint_as_float(t[q][i].y);
-                        v[i][2] += __uint_as_float(t[q][i].z); v[i][3] += __uint_as_float(t[q][i].w);
-                    }
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nv) {
-                const int c = (lane + 64 * i) * 4;
-                if (bias) v[i] += *(const f32x4*)(bias + c);
-                if (addvec) v[i] += *(const f32x4*)(addvec + c);
-                *(f32x4*)(p.x + base + c) = v[i];
-                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            }
-        const float mean = wave_sum(s) / (float)E;
-        float s2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nv) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; s2 = fmaf(d, d, s2); }
-            }
-        const float rstd = 1.0f / sqrtf(wave_sum(s2) / (float)E + p.eps);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < nv) {
-                const int c = (lane + 64 * i) * 4;
-                const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
-                const uint32_t lo = pack_bf16x2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
-                const uint32_t hi = pack_bf16x2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
-                rq_stc64(y + base + c, (uint64_t)lo | ((uint64_t)hi << 32));
-            }
-    }
-}
-
-static __device__ __forceinline__ void stk_run_attn(const StackArgs& p, const StackLayer& L, bf16_t* act, int G, int wg, int tid) {
-    const int lane = tid & 63, wave = rq_uniform(tid >> 6);
-    const long re = (long)p.rows * p.E;
-    AttnDecodeArgs a;
-    a.qkv = act + re; a.kc = L.kc; a.vc = L.vc; a.y = act + 4 * re; a.step = p.step; a.step_off = p.step_off; a.t_max = -1;
-    a.rows = p.rows; a.nh = p.nh; a.E = p.E; a.Tcap = p.Tcap;
-    const int t = (p.step ? *p.step : 0) + p.step_off;
-    if ((t >> 3) >= p.nj) rq_trap();                           // host bound violated: never drop keys silently
-    const int pairs = p.rows * p.nh;
-    for (int pair = wg * 4 + wave; pair < pairs; pair += 4 * G) {
-        const int b = pair / p.nh, h0 = pair - b * p.nh;
-        switch (p.nj) {
-            case 1: attn_run<1, false, 1, true>(a, lane, b, h0, t); break;
-            case 2: attn_run<2, false, 1, true>(a, lane, b, h0, t); break;
-            case 3: attn_run<3, false, 1, true>(a, lane, b, h0, t); break;
-            case 4: attn_run<4, false, 1, true>(a, lane, b, h0, t); break;
-            case 5: attn_run<5, false, 1, true>(a, lane, b, h0, t); break;
-            case 6: attn_run<6, false, 1, true>(a, lane, b, h0, t); break;
-            case 7: attn_run<7, false, 1, true>(a, lane, b, h0, t); break;
-            default: attn_run<8, false, 1, true>(a, lane, b, h0, t); break;
-        }
-    }
-}
-
-// Software grid barrier: workgroup w publishes its epoch in flags[32 (1 + w)] (one store to its own cache line: no read-modify-
-// write on a shared line), thread t of every workgroup waits for the flags of workgroups t, t + 256, ...  Relaxed sc1 accesses
-// only (rq_hip.h).  A bounded spin: a workgroup that never sees its peers (not all resident -- must not happen with G <= CUs and
-// one workgroup per CU) traps instead of hanging the device.
-static __device__ __forceinline__ void stk_grid_barrier(unsigned* flags, unsigned& epoch, int G, int wg, int tid) {
-    rq_stores_done();
-    rq_syncthreads();
-    ++epoch;
-    if (tid == 0) rq_stc32(flags + 32 * (1 + wg), epoch);
-    int ok = 1;
-    for (int w = tid; w < G; w += STK_T) {
-        unsigned spins = 0;
-        while ((int)(rq_ldc32(flags + 32 * (1 + w)) - epoch) < 0) {
-            rq_spin_pause();
-            if (++spins > (1u << 24)) { ok = 0; break; }
-        }
-    }
-    if (!rq_syncthreads_and(ok)) rq_trap();
-    rq_loads_after();
-}
-
-#ifdef RQ_STACK_TRACE
-// diagnostics build (scripts/stack_trace.sh): constant-clock stamps (10 ns ticks) of workgroups 0 and RQ_STACK_TRACE at the start of
-// every phase, at its end and after the grid barrier, for the first 64 steps of a body-sized stack (the last launch wins)
-__device__ unsigned long long g_stack_trace[2 * 64 * 3];
-#define STK_STAMP(k) do { if (tid == 0 && (wg == 0 || wg == RQ_STACK_TRACE) && s < 64 && p.n_layers > 8) g_stack_trace[((wg ? 1 : 0) * 64 + s) * 3 + (k)] = wall_clock64(); } while (0)
-extern "C" int rqamd_dbg_stack_trace(unsigned long long* out_host) {
-    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stack_trace), sizeof(g_stack_trace)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "stack_trace: copy failed");
-    return RQAMD_OK;
-}
-#else
-#define STK_STAMP(k) do {} while (0)
-#endif
-
-__global__ __launch_bounds__(STK_T) void rqt_stack_kernel(StackArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 64 * 32];        // 32 KB (+ 64 KB dynamic, unused: one workgroup per CU)
-    const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
-    const int G = gridDim.x, wg = blockIdx.x;
-    const int n_steps = p.n_layers * RQ_STACK_PHASES;
-    unsigned epoch = p.flags[0];
-    rq_u128 W[STK_MAXKS];
-    int w_step = -1;                                            // the step whose weights sit in W
-    auto prefetch_from = [&](int s) {                           // weights of the first GEMM step >= s
-        while (s < n_steps && !stk_is_gemm(s % RQ_STACK_PHASES)) ++s;
-        if (s < n_steps) {
-            const StkGemm g = stk_gemm(p, p.layers[s / RQ_STACK_PHASES], s / RQ_STACK_PHASES, s % RQ_STACK_PHASES, G);
-            stk_load_w(g, G, wg, wave, lane, W);
-            w_step = s;
-        }
-    };
-    prefetch_from(p.step_lo);
-    bool crossed = false;
-    for (int s = p.step_lo; s < p.step_hi; ++s) {
-        const int layer = s / RQ_STACK_PHASES, ph = s - layer * RQ_STACK_PHASES;
-        const StackLayer& L = p.layers[layer];
-        bf16_t* act = p.act + (long)layer * p.act_stride;
-        STK_STAMP(0);
-        if (ph == 0) {
-            if (layer == 0) stk_run_ln(p, p.x_in0, p.pend_slabs, p.pend_slabs ? p.pend_n : 0, p.pend_bias, p.addvec, L.ln1w, L.ln1b, act, G, wg, tid);
-            else stk_run_ln(p, p.x, p.slabs, p.ks_fc2, p.layers[layer - 1].bfc2, nullptr, L.ln1w, L.ln1b, act, G, wg, tid);
-        } else if (ph == 4) {
-            stk_run_ln(p, p.x, p.slabs, p.ks_proj, L.bproj, nullptr, L.ln2w, L.ln2b, act + 5 * (long)p.rows * p.E, G, wg, tid);
-        } else if (ph == 2) {
-            stk_run_attn(p, L, act, G, wg, tid);
-        } else {
-            const StkGemm g = stk_gemm(p, L, layer, ph, G);
-            if (w_step != s) { stk_load_w(g, G, wg, wave, lane, W); w_step = s; }        // (uniform; only a partial range gets here)
-            if (!((p.dbg & 2) && ph == 6)) stk_run_gemm(p, g, G, wg, tid, W, red);
-            if (!(p.dbg & 1)) prefetch_from(s + 1);
-        }
-        STK_STAMP(1);
-        if (s + 1 < p.step_hi) { stk_grid_barrier(p.flags, epoch, G, wg, tid); crossed = true; }
-        STK_STAMP(2);
-    }
-    if (crossed) {                                              // every workgroup has read the old base: publish the new one
-        stk_grid_barrier(p.flags, epoch, G, wg, tid);
-        if (wg == 0 && tid == 0) rq_stc32(p.flags, epoch);
-    }
-}
-
-bool rq_stack_supported(int E, int nh, int Tcap, int G, int max_slabs) {
-    if (E % 256 != 0 || E > 1536 || E != nh * 64 || Tcap > 64 || G < 8 || max_slabs < 4) return false;
-    const int ks = 4;
-    auto unit_ok = [&](int N, int K, int KS) {
-        if ((long)N * KS % G != 0 || G % KS != 0) return false;
-        const int NC = N * KS / G, KL = K / KS;
-        return NC >= 2 && NC <= 32 && NC % 2 == 0 && K % KS == 0 && KL % 64 == 0 && KL / 64 <= STK_MAXKS;
-    };
-    return unit_ok(3 * E, E, 1) && unit_ok(E, E, ks) && unit_ok(4 * E, E, 1) && unit_ok(E, 4 * E, ks);
-}
-
-int rq_launch_stack(StackArgs a, int G, bool stepwise, hipStream_t s) {
-    a.ks_proj = a.ks_fc2 = 4;
-    {
-        const int E = a.E;
-        const int gAoff[4] = {0, 4, 5, 6}, gOutOff[4] = {1, -1, 6, -1};
-        const int gN[4] = {3 * E, E, 4 * E, E}, gK[4] = {E, E, E, 4 * E}, gKS[4] = {1, a.ks_proj, 1, a.ks_fc2}, gEpi[4] = {0, 2, 1, 2};
-        const int gLda[4] = {E, E, E, 4 * E}, gLdo[4] = {3 * E, E, 4 * E, E};
-        for (int i = 0; i < 4; ++i) {
-            a.gAoff[i] = gAoff[i]; a.gOutOff[i] = gOutOff[i]; a.gN[i] = gN[i]; a.gK[i] = gK[i]; a.gKS[i] = gKS[i]; a.gEpi[i] = gEpi[i];
-            a.gLda[i] = gLda[i]; a.gLdo[i] = gLdo[i];
-        }
-    }
-    static const int dbg = getenv("RQAMD_STACK_DBG") ? atoi(getenv("RQAMD_STACK_DBG")) : 0;      // diagnostics bits, see the kernel
-    a.dbg = dbg;
-    if (!rq_stack_supported(a.E, a.nh, a.Tcap, G, 4)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "stack kernel: E=%d heads=%d Tcap=%d G=%d", a.E, a.nh, a.Tcap, G);
-    if (a.nj < 1 || a.nj > 8) return rq_fail(RQAMD_ERR_INVALID, "stack kernel: %d key blocks", a.nj);
-    static RqDeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute((const void*)rqt_stack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    const int n_steps = a.n_layers * RQ_STACK_PHASES;
-#ifdef RQ_EMU
-    stepwise = true;                                            // workgroups run one after another there
-#endif
-    if (!stepwise) {
-        a.step_lo = 0; a.step_hi = n_steps;
-        RQ_LAUNCH(rqt_stack_kernel, dim3(G), dim3(STK_T), 64 * 1024, s, a);
-    } else {
-        static const bool trace = getenv("RQAMD_STACK_TRACE") != nullptr;      // diagnostics: names the phase a fault happens in (eager streams only)
-        for (int st = 0; st < n_steps; ++st) {
-            a.step_lo = st; a.step_hi = st + 1;
-            if (trace) fprintf(stderr, "stack: block %d phase %d rows %d nj %d Tcap %d\n", st / RQ_STACK_PHASES, st % RQ_STACK_PHASES, a.rows, a.nj, a.Tcap);
-            RQ_LAUNCH(rqt_stack_kernel, dim3(G), dim3(STK_T), 64 * 1024, s, a);
-            if (trace) (void)hipStreamSynchronize(s);
-        }
-    }
-    return rq_check_launch("rqt_stack_kernel");
 }

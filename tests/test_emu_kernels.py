@@ -350,39 +350,6 @@ def test_emu_rqt_stepping_form(nat, golden):
     # (full-length draws, non-zero filtered probability of every drawn code, generator consumption: tests/test_gpu_parity.py)
 
 
-def test_emu_rqt_stack_kernel(nat, monkeypatch):
-    """The persistent small-batch stack kernel (rqt_stack_kernel: LayerNorm / GEMM / attention phases of every block in one
-    launch; the emulator runs it one phase per launch) against the per-launch kernels and the oracle: E = 512, 8 heads, 67 rows
-    (two 64-row blocks), G = 64 workgroups."""
-    cfg = C.rqt(512, 8, 2, 2, 500, vocab_cond=10, block_size=(2, 2, 2), input_embed_dim=64)
-    rng = np.random.default_rng(11)
-    params = oracle.make_params(oracle.rqt_param_shapes(cfg), 3)
-    cb = rng.standard_normal((500, 64)).astype(np.float32)
-    B = 67
-    codes = T(rng.integers(0, 500, (B, 2, 2, 2)).astype(np.int64))
-    cond = T(rng.integers(0, 10, (B, 1)).astype(np.int64))
-    ref_eng = _rqt_engine(nat, cfg, params)
-    ref = ref_eng.logits(codes, cond, [T(cb)] * 2).numpy()
-    monkeypatch.setenv('RQAMD_STACK', '1')
-    monkeypatch.setenv('RQAMD_STACK_G', '64')
-    eng = _rqt_engine(nat, cfg, params)
-    got = eng.logits(codes, cond, [T(cb)] * 2).numpy()
-    d = np.abs(got - ref)
-    print('emu stack kernel vs per-launch kernels: max diff %.5f mean %.6f (|logits| max %.2f)' % (d.max(), d.mean(), np.abs(ref).max()))
-    assert d.max() < 0.02 and d.mean() < 0.002
-    o = oracle.RQTransformerOracle(cfg, params)
-    want = o.forward(codes.numpy()[:5], [cb] * 2, cond=cond.numpy()[:5])
-    err = np.abs(got[:5] - want)
-    print('emu stack kernel vs oracle: max err %.4f mean %.5f' % (err.max(), err.mean()))
-    assert err.max() < 0.06 and err.mean() < 0.01
-    # sampling through it: same seed -> same codes as the per-launch path is NOT required (different fp32 summation order may
-    # flip a draw); determinism and range are
-    part, c3 = torch.zeros_like(codes[:3]).contiguous(), cond[:3].contiguous()
-    s1 = eng.sample(part, c3, [T(cb)] * 2, (0, 0), 1.0, [50, 50], [0.9, 0.9], 4, 0, False)
-    s2 = eng.sample(part, c3, [T(cb)] * 2, (0, 0), 1.0, [50, 50], [0.9, 0.9], 4, 0, False)
-    assert torch.equal(s1, s2) and int(s1.min()) >= 0 and int(s1.max()) < 500
-
-
 def _vae_engine(nat, hps, dd, params):
     eng = nat.VaeEngine(dd, hps['embed_dim'], device='cpu')
     for k, v in params.items():
