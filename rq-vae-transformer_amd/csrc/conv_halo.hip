@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
 }
 
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
-    return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 64 && H * W <= 65536;
+    return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 32 && H * W <= 65536;      // (whether it pays below 64^2: engine_vae.hip)
 }
 
 int rq_conv_halo_stat_tiles(int H, int W) { return (H / HT_H) * (W / HT_W); }

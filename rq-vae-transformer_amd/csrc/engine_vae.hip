@@ -30,6 +30,7 @@ struct rqamd_vae {
     int chunk = 0;
     int chunk_max = 128;
     bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false, no_splitk = false;
+    int halo_min_wgs = 512;        // 32^2 layers take the halo kernel when batch x tiles gives at least this many workgroups (RQAMD_HALO_MIN_WGS)
     std::string missing;
     // Small batches (the drivers decode ONE image per call, measure_throughput/__main__.py:297-299, main_sampling_fid.py:223;
     // the rFID loop encodes and decodes one image per call, rqvae/metrics/fid.py:167-169) are launch-bound: ~200 launches
@@ -65,6 +66,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
     h->no_splitk = getenv("RQAMD_VAE_NO_SPLITK") != nullptr;
+    if (const char* e = getenv("RQAMD_HALO_MIN_WGS")) h->halo_min_wgs = atoi(e);      // 0: always, 1 << 30: never (the round-1 rule)
     if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RQAMD_OK;
@@ -154,6 +156,13 @@ struct VaeRun {
         return it->second->p;
     }
     void swap() { bf16_t* t = X; X = Y; Y = t; }
+    // Halo-reuse kernel or implicit GEMM for a 3x3 / stride-1 layer: always at >= 64^2; at 32^2 (four 8 x 32 tiles per image) only
+    // when the batch fills the chip -- 128 images: 256 -> 256 215 us + 45 us of GroupNorm passes as implicit GEMM against ~175 us fused
+    // (profiles/r02_decode_timeline_b128.txt); a handful of images would leave most CUs idle and keeps the split-K implicit GEMM.
+    bool halo_here(int H, int W, int Cin, int Cout) const {
+        if (h->no_halo || !rq_conv_halo_supported(H, W, Cin, Cout)) return false;
+        return H >= 64 || (long)B * rq_conv_halo_stat_tiles(H, W) * (Cout / 128) >= h->halo_min_wgs;
+    }
 
     // src: NHWC [B][Hin>>ups][Win>>ups][Cin]  ->  dst [B][Hout][Wout][Cout]
     void conv(const std::string& name, const bf16_t* src, void* dst, int Hin, int Win, int Cin, int Cout, int ks, int stride, int ups,
@@ -166,7 +175,7 @@ struct VaeRun {
         if (stride == 2) { Hout = Hin / 2; Wout = Win / 2; pad = 0; }      // F.pad(0,1,0,1) + conv(s2, p0), layers.py:50-54
         // high-resolution 3x3 / stride-1 layers: halo-reuse kernel (one patch staged per 64-channel chunk, 9 taps)
         if (ks == 3 && stride == 1 && (!ups || (epi == EPI_BF16 && !h->no_halo_ups)) && (epi == EPI_BF16 || epi == EPI_BF16_RESID) &&
-            !h->no_halo && rq_conv_halo_supported(Hin, Win, Cin, Cout)) {
+            halo_here(Hin, Win, Cin, Cout)) {
             const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(Hin, Win);
             err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst,
                                       st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, ups, st);
@@ -217,7 +226,7 @@ struct VaeRun {
     void norm_conv(const std::string& nname, const std::string& cname, const bf16_t* src, bf16_t* tmp, bf16_t* dst, int H, int W,
                    int Cin, int Cout, int epi, const bf16_t* resid) {
         if (err) return;
-        if (!h->no_halo && !h->no_fuse_gn && rq_conv_halo_supported(H, W, Cin, Cout)) {
+        if (!h->no_fuse_gn && halo_here(H, W, Cin, Cout)) {
             const float* g = (const float*)P(nname + ".weight");
             const float* be = (const float*)P(nname + ".bias");
             const bf16_t* w = (const bf16_t*)P(cname + ".weight");

@@ -480,6 +480,22 @@ def test_emu_conv_halo(nat):
     ref2 = conv2d(x2.float().numpy(), np.transpose(w2.float().numpy(), (0, 3, 1, 2)), b2.numpy())
     out = nat.dbg_conv_halo(x2, w2, b2, persistent=False).float().numpy()
     assert np.abs(out - ref2).max() < 0.02 * np.abs(ref2).max()
+    # 32 x 32 maps (one tile wide, four tall: what large batches run at the 32^2 level), fused GroupNorm + residual + statistics
+    x3 = bf(rng.standard_normal((2, 32, 32, Cin)).astype(np.float32))
+    r3 = bf(rng.standard_normal((2, 32, 32, Cout)).astype(np.float32))
+    gn3 = T(np.stack([1.0 + 0.2 * rng.standard_normal((2, Cin)), 0.3 * rng.standard_normal((2, Cin))], -1).astype(np.float32))
+    xn3 = bf(silu(x3.float().numpy() * gn3.numpy()[:, None, None, :, 0] + gn3.numpy()[:, None, None, :, 1]).astype(np.float32)).float().numpy()
+    ref3 = conv2d(xn3, wf, bias.numpy()) + r3.float().numpy()
+    st3 = torch.zeros((2, 4, 32, 2), dtype=torch.float32)
+    out = nat.dbg_conv_halo(x3, w, bias, gn=gn3, resid=r3, stats=st3).float().numpy()
+    assert np.abs(out - ref3).max() < 0.02 * np.abs(ref3).max()
+    t3 = out.reshape(2, 4, 8, 1, 32, 32, Cout // 32).astype(np.float64)
+    want3 = np.stack([t3.sum((2, 4, 6)), (t3 * t3).sum((2, 4, 6))], -1).reshape(2, -1, 32, 2)
+    assert np.abs(st3.numpy() - want3).max() < 1e-3 * np.abs(want3).max()
+    xs3 = bf(rng.standard_normal((1, 16, 16, Cin)).astype(np.float32))
+    ref_up3 = conv2d(np.repeat(np.repeat(xs3.float().numpy(), 2, axis=1), 2, axis=2), wf, bias.numpy())
+    out = nat.dbg_conv_halo(xs3, w, bias, ups=True).float().numpy()
+    assert out.shape == (1, 32, 32, Cout) and np.abs(out - ref_up3).max() < 0.02 * np.abs(ref_up3).max()
     # Upsample.conv (layers.py:31-35): nearest 2x folded into the patch staging; 32x32 source -> 64x64 output
     xs = bf(rng.standard_normal((B, H // 2, W // 2, Cin)).astype(np.float32))
     xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)

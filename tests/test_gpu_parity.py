@@ -467,6 +467,30 @@ def test_vae_full_size_golden(nat, golden, tag, cfg):
     assert agree > 0.9
 
 
+def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
+    """At 32 x 32 the 3x3 layers run as implicit GEMMs for a few images and through the halo kernel (fused GroupNorm, epilogue
+    statistics) once the batch fills the chip (engine_vae.hip: halo_here).  RQAMD_HALO_MIN_WGS=0 forces the large-batch choice on
+    one image: same golden tolerance as test_vae_full_size_golden, and close to the default path."""
+    g = golden('vae_imagenet.npz')
+    ref = g['decode_code'].astype(np.float32)
+    vae0, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    d0 = N(vae0.decode_code(G(g['codes'], torch.long)))
+    monkeypatch.setenv('RQAMD_HALO_MIN_WGS', '0')
+    vae1, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    d1 = N(vae1.decode_code(G(g['codes'], torch.long)))
+    err = np.abs(d1 - ref)
+    print('vae imagenet decode_code, halo kernel at 32^2: max err %.4f mean %.5f; vs default path max %.4f mean %.5f'
+          % (err.max(), err.mean(), np.abs(d1 - d0).max(), np.abs(d1 - d0).mean()))
+    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
+    assert np.abs(d1 - d0).mean() < 0.01
+    rng = np.random.default_rng(int(g['data_seed']))
+    rng.integers(0, C.VAE_IMAGENET[0]['n_embed'], (1, 8, 8, 4))
+    x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
+    e = np.abs(N(vae1.encode(G(x))) - g['z_e'])
+    print('vae imagenet encode, halo kernel at 32^2: max err %.4f mean %.5f' % (e.max(), e.mean()))
+    assert e.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and e.mean() < 0.01
+
+
 def test_vae_batch_invariance_and_chunking(nat, golden):
     g = golden('vae_tiny.npz')
     vae, _, _, _ = _models(C.VAE_TINY, None, int(g['seed']), 0)
