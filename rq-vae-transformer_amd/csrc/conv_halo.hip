@@ -921,6 +921,12 @@ constexpr int OT_H = 4, OP_N = (OT_H + 2) * HP_W;          // 6 x 34 = 204 patch
 constexpr int O_NTH = 256;
 constexpr int O_PLANE = OP_N * 128;                        // one 64-channel plane of the patch
 
+// Persistent form: a workgroup walks a contiguous range of tiles (row-major inside an image, so the halo rows a tile shares with the
+// tile above come back out of the L2), the weights are repacked into LDS once per workgroup, and the next tile's patch pieces
+// (13 per thread at Cin = 128) are requested into registers before the current tile's MFMAs, normalised and stored after them.
+// Two workgroups per CU (71 KB of LDS each) interleave one's MFMA phase with the other's GroupNorm + SiLU arithmetic.
+// (Measured and not kept, profiles/r02_conv_out_staging.txt: the weight fragments in registers with v_mfma_f32_16x16x32_bf16 --
+// both operands come out of LDS for every MFMA here, 576 KB per tile -- needs ~320 registers, i.e. one workgroup per CU: 1.6x slower.)
 template <int FUSE_GN>
 __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
     RQ_DYN_SMEM(smem);
@@ -930,61 +936,61 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
     char* sW = sH + NC * O_PLANE;                          // [8][wrow]: rows >= Cout are zero
     const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
 
-    const int tiles_x = p.W / HT_W, tiles_y = p.H / OT_H;
-    const int n_mt = p.B * tiles_y * tiles_x;
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int tiles_x = p.W / HT_W, tiles_y = p.H / OT_H, tiles_img = tiles_x * tiles_y;
+    const int n_mt = p.B * tiles_img;
+    // tile range: the XCD of this workgroup (blockIdx & 7) owns a contiguous eighth, split evenly over its workgroups
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3, S = (int)gridDim.x >> 3;
     const int per = (n_mt + 7) >> 3;
-    const int mtile = xcd * per + slot;
-    if (slot >= per || mtile >= n_mt) return;
-    const int img = mtile / (tiles_y * tiles_x);
-    const int trem = mtile - img * (tiles_y * tiles_x);
-    const int ty0 = (trem / tiles_x) * OT_H, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+    const int x0 = xcd * per, x1 = x0 + per < n_mt ? x0 + per : n_mt;
+    const int sub = (x1 - x0 + S - 1) / (S > 0 ? S : 1);
+    const int t0 = x0 + slot * sub, t1 = t0 + sub < x1 ? t0 + sub : x1;
+    if (x0 >= x1 || t0 >= t1) return;
 
-    // ---- stage the patch: piece q = (pixel hp, 16-byte chunk cq of the Cin channels); cq is the same for all of a
-    // thread's pieces (256 % (Cin/8) == 0), so its 8 (scale, shift) pairs are loaded once.  All of a thread's pieces (13 at
-    // Cin = 128) are requested before the first is used, and the weight rows (fp32, 16-byte loads) ride in the same batch:
-    // four pieces at a time and a scalar weight loop cost three extra memory round trips and ~18 serialised L2 ones per tile.
-    const int cpp_sh = p.Cin == 64 ? 3 : p.Cin == 128 ? 4 : 5;      // chunks per pixel CPP = Cin / 8 = 8, 16 or 32
+    // piece q = (pixel hp of the patch, 16-byte chunk cq of the Cin channels); cq is the same for all of a thread's pieces
+    // (256 % (Cin/8) == 0), so its 8 (scale, shift) pairs are one set of registers per tile
+    const int cpp_sh = p.Cin == 64 ? 3 : 4;                // chunks per pixel CPP = Cin / 8 = 8 or 16
     const int CPP = 1 << cpp_sh;
     const int cq = tid & (CPP - 1);
     const int n_piece = OP_N << cpp_sh;
-    f32x4 gs[4];
-    if (FUSE_GN) {
-        const float* gn = p.gn + ((long)img * p.Cin + cq * 8) * 2;
+    constexpr int PIT = 13;                                // pieces per thread: ceil(204 * 16 / 256)
+    unsigned hyx[PIT];                                     // (hy << 8 | hx) of piece k, or 0xffff beyond the patch
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4);
-    }
-    // weights: fp32 [Cout][9*Cin] -> bf16 rows 0..Cout-1 of sW (rows Cout..7 feed output rows nobody stores: zero)
-    const int KT = 9 * p.Cin;
-    const int n_w4 = p.Cout * (KT >> 2);                   // 16-byte groups of real weights
-    constexpr int WIT = 5;                                 // covers Cout = 4, Cin = 128 in one batch
-    f32x4 wr[WIT];
-#pragma unroll
-    for (int k = 0; k < WIT; ++k) {
-        const int i = tid + O_NTH * k;
-        if (i < n_w4) wr[k] = *(const f32x4*)(p.w + (long)i * 4);
+    for (int k = 0; k < PIT; ++k) {
+        const int q = tid + O_NTH * k;
+        const int hp = q >> cpp_sh;
+        const int hy = hp / HP_W, hx = hp - hy * HP_W;
+        hyx[k] = q < n_piece ? (unsigned)(hy << 8 | hx) : 0xffffu;
     }
     const char* gX = (const char*)p.x;
-    constexpr int PIT = 13;                                // pieces in flight per thread
-    for (int q0 = tid; q0 < n_piece; q0 += O_NTH * PIT) {
-        rq_u128 r[PIT];
-        unsigned loff[PIT];
-        bool ok[PIT], in[PIT];
+    struct Tile { int img, ty0, tx0; };
+    auto decode = [&](int t) {
+        Tile d;
+        d.img = t / tiles_img;
+        const int trem = t - d.img * tiles_img;
+        d.ty0 = (trem / tiles_x) * OT_H;
+        d.tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
+        return d;
+    };
+    auto request = [&](const Tile& d, rq_u128* r, f32x4* gs) {
+        if (FUSE_GN) {
+            const float* gn = p.gn + ((long)d.img * p.Cin + cq * 8) * 2;
 #pragma unroll
-        for (int k = 0; k < PIT; ++k) {
-            const int q = q0 + O_NTH * k;
-            in[k] = q < n_piece;
-            const int hp = q >> cpp_sh;
-            const int hy = hp / HP_W, hx = hp - hy * HP_W;
-            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-            ok[k] = in[k] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
-            if (in[k]) r[k] = ld128(gX + ((((long)img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);     // clamped: always readable
-            loff[k] = (unsigned)((cq >> 3) * O_PLANE) + halo_lds_off(hy, hx, cq & 7);
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4);
         }
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
-            if (!in[k]) continue;
+            if (hyx[k] == 0xffffu) continue;
+            const int gy = d.ty0 + (int)(hyx[k] >> 8) - 1, gx = d.tx0 + (int)(hyx[k] & 255u) - 1;
+            const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+            r[k] = ld128(gX + ((((long)d.img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);      // clamped: always readable
+        }
+    };
+    auto stage = [&](const Tile& d, const rq_u128* r, const f32x4* gs) {
+#pragma unroll
+        for (int k = 0; k < PIT; ++k) {
+            if (hyx[k] == 0xffffu) continue;
+            const int hy = (int)(hyx[k] >> 8), hx = (int)(hyx[k] & 255u);
+            const int gy = d.ty0 + hy - 1, gx = d.tx0 + hx - 1;
             rq_u128 v = r[k];
             if (FUSE_GN) {
                 float f[8];
@@ -1002,58 +1008,86 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
                 v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
                 v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
             }
-            if (!ok[k]) v = zero128();                     // zero padding of the (normalised) input
-            st128(sH + loff[k], v);
+            if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) v = zero128();      // zero padding of the (normalised) input
+            st128(sH + (unsigned)((cq >> 3) * O_PLANE) + halo_lds_off(hy, hx, cq & 7), v);
         }
-    }
-    // ---- weights into LDS: group i = (row, 4 consecutive k); the rest of the 8 rows zero
-    auto store_w4 = [&](int i, const f32x4& v) {
-        const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
-        *(uint64_t*)(sW + row * wrow + k4 * 2) = (uint64_t)pack_bf16x2(v[0], v[1]) | ((uint64_t)pack_bf16x2(v[2], v[3]) << 32);
     };
-#pragma unroll
-    for (int k = 0; k < WIT; ++k) {
-        const int i = tid + O_NTH * k;
-        if (i < n_w4) store_w4(i, wr[k]);
-    }
-    for (int i = tid + O_NTH * WIT; i < n_w4; i += O_NTH) store_w4(i, *(const f32x4*)(p.w + (long)i * 4));      // (Cin = 256)
-    for (int i = n_w4 + tid; i < 8 * (KT >> 2); i += O_NTH) {
-        const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
-        *(uint64_t*)(sW + row * wrow + k4 * 2) = 0ull;
-    }
-    rq_syncthreads();
 
-    // ---- 9 taps x Cin/16 MFMAs: wave = output row of the tile, lane&31 = pixel (B operand) / weight row (A operand)
-    const int ftx = lane & 31, fk = lane >> 5;
-    f32x16 acc;
+    // ---- first tile and the weights (fp32 [Cout][9*Cin], 16-byte loads) in one batch of requests
+    rq_u128 r[PIT];
+    f32x4 gs[4];
+    Tile cur = decode(t0);
+    request(cur, r, gs);
+    const int KT = 9 * p.Cin;
+    const int n_w4 = p.Cout * (KT >> 2);                   // 16-byte groups of real weights
+    constexpr int WIT = 5;                                 // covers Cout = 4, Cin = 128
+    {
+        f32x4 wr[WIT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const char* wl = sW + (ftx & 7) * wrow + fk * 16;
-    for (int c = 0; c < NC; ++c) {
+        for (int k = 0; k < WIT; ++k) {
+            const int i = tid + O_NTH * k;
+            if (i < n_w4) wr[k] = *(const f32x4*)(p.w + (long)i * 4);
+        }
+        stage(cur, r, gs);
+        // weights into LDS: group i = (row, 4 consecutive k) as bf16; rows Cout..7 feed output rows nobody stores: zero
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const unsigned ha = (unsigned)(c * O_PLANE) + halo_lds_off(wave + ky, ftx + kx, fk);
-            const char* wt = wl + (tap * p.Cin + c * 64) * 2;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 af = as_bf16x8(ld128(sH + (ha ^ (unsigned)(ks << 5))));
-                const bf16x8 wf = as_bf16x8(ld128(wt + ks * 32));
-                acc = rq_mfma_32x32x16_bf16(wf, af, acc);
+        for (int k = 0; k < WIT; ++k) {
+            const int i = tid + O_NTH * k;
+            if (i < n_w4) {
+                const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
+                *(uint64_t*)(sW + row * wrow + k4 * 2) = (uint64_t)pack_bf16x2(wr[k][0], wr[k][1]) | ((uint64_t)pack_bf16x2(wr[k][2], wr[k][3]) << 32);
             }
         }
+        for (int i = n_w4 + tid; i < 8 * (KT >> 2); i += O_NTH) {
+            const int row = i / (KT >> 2), k4 = (i - row * (KT >> 2)) * 4;
+            *(uint64_t*)(sW + row * wrow + k4 * 2) = 0ull;
+        }
     }
-    // C/D layout: lanes 0..31 hold rows (= cout) 0..3 of column (= pixel) lane in acc[0..3]
-    if (lane < 32) {
-        const int oy = ty0 + wave, ox = tx0 + lane;
+
+    const int ftx = lane & 31, fk = lane >> 5;
+    const char* wl = sW + (ftx & 7) * wrow + fk * 16;
+    float bias_r[4];
 #pragma unroll
-        for (int co = 0; co < 4; ++co)
-            if (co < p.Cout) p.y[(((long)img * p.Cout + co) * p.H + oy) * p.W + ox] = acc[co] + p.bias[co];
+    for (int co = 0; co < 4; ++co) bias_r[co] = co < p.Cout ? p.bias[co] : 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        Tile nxt = cur;
+        if (more) { nxt = decode(t + 1); request(nxt, r, gs); }      // in flight under this tile's MFMAs
+        rq_syncthreads();                                  // this tile's patch (and the weights) are in LDS
+        // ---- 9 taps x Cin/16 MFMAs: wave = output row of the tile, lane&31 = pixel (B operand) / weight row (A operand)
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const unsigned ha = (unsigned)(c * O_PLANE) + halo_lds_off(wave + ky, ftx + kx, fk);
+                const char* wt = wl + (tap * p.Cin + c * 64) * 2;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 af = as_bf16x8(ld128(sH + (ha ^ (unsigned)(ks << 5))));
+                    const bf16x8 wf = as_bf16x8(ld128(wt + ks * 32));
+                    acc = rq_mfma_32x32x16_bf16(wf, af, acc);
+                }
+            }
+        }
+        // C/D layout: lanes 0..31 hold rows (= cout) 0..3 of column (= pixel) lane in acc[0..3]
+        if (lane < 32) {
+            const int oy = cur.ty0 + wave, ox = cur.tx0 + lane;
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < p.Cout) p.y[(((long)cur.img * p.Cout + co) * p.H + oy) * p.W + ox] = acc[co] + bias_r[co];
+        }
+        if (!more) break;
+        rq_syncthreads();                                  // every wavefront is done reading the patch
+        stage(nxt, r, gs);
+        cur = nxt;
     }
 }
 
 bool rq_conv_out_halo_supported(int H, int W, int Cin, int Cout) {
-    return H % OT_H == 0 && W % HT_W == 0 && (Cin == 64 || Cin == 128 || Cin == 256) && Cout >= 1 && Cout <= 4;
+    return H % OT_H == 0 && W % HT_W == 0 && (Cin == 64 || Cin == 128) && Cout >= 1 && Cout <= 4;
 }
 
 int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, const float* gn, float* y, int B, int H, int W,
@@ -1068,7 +1102,14 @@ int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, 
         (void)hipFuncSetAttribute((const void*)conv_out_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const int n_mt = B * (H / OT_H) * (W / HT_W);
-    const int nblocks = 8 * ((n_mt + 7) / 8);
+    int nblocks = 8 * ((n_mt + 7) / 8);
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    if (nblocks > 2 * cus) nblocks = 2 * cus / 8 * 8;      // two resident workgroups per CU, each walking a range of tiles
+    if (const char* e = getenv("RQAMD_CONV_OUT_WGS")) {    // diagnostics / tests: fewer workgroups, longer walks
+        const int v = atoi(e) / 8 * 8;
+        if (v >= 8 && v < nblocks) nblocks = v;
+    }
     if (gn) RQ_LAUNCH(conv_out_halo_kernel<1>, dim3(nblocks), dim3(O_NTH), smem, s, a);
     else RQ_LAUNCH(conv_out_halo_kernel<0>, dim3(nblocks), dim3(O_NTH), smem, s, a);
     return rq_check_launch("conv_out_halo_kernel");

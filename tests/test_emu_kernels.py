@@ -561,12 +561,14 @@ def test_emu_conv_in_mfma(nat):
     assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
 
 
-def test_emu_conv_out_mfma(nat):
+def test_emu_conv_out_mfma(nat, monkeypatch):
     """Decoder.conv_out as an MFMA halo kernel (csrc/conv_halo.hip): Cin -> 3, NCHW fp32 out, optional fused
-    norm_out GroupNorm+SiLU; image borders, two channel planes, against the oracle's conv2d."""
+    norm_out GroupNorm+SiLU; image borders, two channel planes, against the oracle's conv2d.  8 workgroups walk the 24
+    tiles (three each, one range crossing an image boundary: the next tile's patch is requested under the current tile's MFMAs)."""
     from oracle.vae import conv2d, silu
+    monkeypatch.setenv('RQAMD_CONV_OUT_WGS', '8')
     rng = np.random.default_rng(6)
-    B, H, W, Cin, Cout = 2, 8, 64, 128, 3
+    B, H, W, Cin, Cout = 3, 16, 64, 128, 3
     x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).to(torch.bfloat16)
     w = (0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32)
     bias = rng.standard_normal(Cout).astype(np.float32)

@@ -582,7 +582,7 @@ def test_conv_kernels_vs_torch(nat):
     ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), bias, padding=1).permute(0, 2, 3, 1)
     out = nat.dbg_conv_in(x, w.permute(2, 3, 1, 0).contiguous(), bias).float()
     assert float((out - ref).abs().max()) < 1e-2 * float(ref.abs().max())
-    for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (1, 64, 64, 256)):
+    for (B, H, W, Cin) in ((3, 256, 256, 128), (2, 12, 32, 64), (70, 64, 64, 128)):      # the last: workgroups walk ranges of tiles
         x = rn(B, H, W, Cin).to(torch.bfloat16)
         w = rn(3, 3, 3, Cin, scale=0.05)
         bias = rn(3)
