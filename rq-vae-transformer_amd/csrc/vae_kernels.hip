@@ -209,9 +209,131 @@ __global__ __launch_bounds__(256) void vae_attn_kernel(const bf16_t* qkv, bf16_t
     }
 }
 
+// The same attention for T = 64 tokens (the 8 x 8 AttnBlocks of the released models) on the matrix pipe, one workgroup per image.
+// The wavefront-per-query kernel above reads a different K row per lane (64 cache lines per load instruction: the CU's address
+// path, not arithmetic, set its 119 us per 128 images, profiles/r02_decode_timeline_b128.txt).  Here:
+//   1. S = Q K^T: wavefront w owns the 32 x 32 block (w >> 1, w & 1); both operands are K-contiguous rows of qkv, loaded from
+//      global memory in MFMA fragment layout (16 bytes per lane), fp32 scores * C^-0.5 into LDS;
+//   2. softmax per row in fp32 (4 threads per row), P rounded to bf16 into LDS;
+//   3. O^T = V^T P^T: A = V^T gathered out of a row-major LDS copy of V (8 two-byte reads per fragment; the row pitch C + 4 puts
+//      the two 8-row groups of a read on disjoint banks), B = P rows; D[channel][query] leaves 4 consecutive channels per lane:
+//      8-byte stores.  V's staging loads are issued first and land under steps 1-2.
+constexpr int VA_T = 64;
+__global__ __launch_bounds__(256) void vae_attn_mfma_kernel(const bf16_t* qkv, bf16_t* out, int C, float scale) {
+    RQ_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int VP = C + 4;                                  // V row pitch (elements)
+    bf16_t* sV = (bf16_t*)smem;                            // [64][VP]
+    float* sS = (float*)(smem + (size_t)VA_T * VP * 2);    // [64][65]
+    bf16_t* sP = (bf16_t*)(sS + VA_T * 65);                // [64][72]
+    const bf16_t* base = qkv + (long)blockIdx.x * VA_T * 3 * C;
+
+    // ---- V -> LDS (row-major, 8-byte stores: the pitch is not a multiple of 16 bytes); at most 16 chunks per thread
+    const int CC = C >> 3, n_chunk = VA_T * CC;
+    rq_u128 vr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = tid + 256 * i;
+        if (id < n_chunk) vr[i] = ld128(base + (long)(id / CC) * 3 * C + 2 * C + (id % CC) * 8);
+    }
+    // ---- 1. scores
+    {
+        const int mb = wave >> 1, nb = wave & 1, nks = C >> 4;
+        const bf16_t* qp = base + (long)(mb * 32 + l31) * 3 * C + kg * 8;
+        const bf16_t* kp = base + (long)(nb * 32 + l31) * 3 * C + C + kg * 8;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k0 = 0; k0 < nks; k0 += 8) {
+            rq_u128 a[8], b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[j] = zero128(); b[j] = zero128();
+                if (k0 + j < nks) { a[j] = ld128(qp + (k0 + j) * 16); b[j] = ld128(kp + (k0 + j) * 16); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < nks) acc = rq_mfma_32x32x16_bf16(as_bf16x8(a[j]), as_bf16x8(b[j]), acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sS[(mb * 32 + (r >> 2) * 8 + kg * 4 + (r & 3)) * 65 + nb * 32 + l31] = acc[r] * scale;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = tid + 256 * i;
+        if (id < n_chunk) {
+            uint64_t* d = (uint64_t*)(sV + (id / CC) * VP + (id % CC) * 8);
+            d[0] = (uint64_t)vr[i].x | ((uint64_t)vr[i].y << 32);
+            d[1] = (uint64_t)vr[i].z | ((uint64_t)vr[i].w << 32);
+        }
+    }
+    rq_syncthreads();
+    // ---- 2. softmax (layers.py:171-172): 4 threads per row, 16 keys each
+    {
+        const int row = tid >> 2, part = tid & 3;
+        float v[16], mx = -__int_as_float(0x7f800000);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = sS[row * 65 + part * 16 + i]; mx = fmaxf(mx, v[i]); }
+        mx = fmaxf(mx, rq_shfl_xor(mx, 1));
+        mx = fmaxf(mx, rq_shfl_xor(mx, 2));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - mx); sum += v[i]; }
+        sum += rq_shfl_xor(sum, 1);
+        sum += rq_shfl_xor(sum, 2);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) *(uint32_t*)(sP + row * 72 + part * 16 + i) = pack_bf16x2(v[i] * inv, v[i + 1] * inv);
+    }
+    rq_syncthreads();
+    // ---- 3. O^T = V^T P^T
+    rq_u128 pf[2][4];                                      // B operand: P[q = qb*32 + l31][ks*16 + kg*8 ..]
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) pf[qb][ks] = ld128(sP + (qb * 32 + l31) * 72 + ks * 16 + kg * 8);
+    for (int cb = wave; cb < (C >> 5); cb += 4) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
+        const bf16_t* vcol = sV + cb * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const uint32_t lo = vcol[(ks * 16 + kg * 8 + e) * VP], hi = vcol[(ks * 16 + kg * 8 + e + 1) * VP];
+                w4[e >> 1] = lo | (hi << 16);
+            }
+            rq_u128 af;
+            af.x = w4[0]; af.y = w4[1]; af.z = w4[2]; af.w = w4[3];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) acc[qb] = rq_mfma_32x32x16_bf16(as_bf16x8(af), as_bf16x8(pf[qb][ks]), acc[qb]);
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            bf16_t* o = out + ((long)blockIdx.x * VA_T + qb * 32 + l31) * C + cb * 32 + kg * 4;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *(uint64_t*)(o + rq * 8) = (uint64_t)pack_bf16x2(acc[qb][rq * 4], acc[qb][rq * 4 + 1]) | ((uint64_t)pack_bf16x2(acc[qb][rq * 4 + 2], acc[qb][rq * 4 + 3]) << 32);
+        }
+    }
+}
+
 int rq_launch_vae_attn(const bf16_t* qkv, bf16_t* out, int B, int T, int C, hipStream_t s) {
     if (C % 8 != 0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "vae attention: C %d", C);
     const float scale = 1.0f / sqrtf((float)C);      // int(c)**(-0.5), layers.py:170
+    static const bool no_mfma = getenv("RQAMD_VAE_ATTN_VALU") != nullptr;      // A/B switch
+    if (T == VA_T && C % 64 == 0 && C <= 512 && !no_mfma) {
+        const size_t smem = (size_t)VA_T * (C + 4) * 2 + (size_t)VA_T * 65 * 4 + (size_t)VA_T * 72 * 2;
+        static RqDeviceOnce attr_once;
+        if (attr_once.first()) (void)hipFuncSetAttribute((const void*)vae_attn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        RQ_LAUNCH(vae_attn_mfma_kernel, dim3((unsigned)B), dim3(256), smem, s, qkv, out, C, scale);
+        return rq_check_launch("vae_attn_mfma_kernel");
+    }
     dim3 grid((unsigned)(((long)B * T + 3) / 4));
     if (T <= 64) RQ_LAUNCH(vae_attn_kernel<1>, grid, dim3(256), 0, s, qkv, out, B, T, C, scale);
     else if (T <= 256) RQ_LAUNCH(vae_attn_kernel<4>, grid, dim3(256), 0, s, qkv, out, B, T, C, scale);
