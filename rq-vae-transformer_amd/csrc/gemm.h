@@ -53,6 +53,8 @@ struct GemmArgs {
     const bf16_t* resid;
     int ldr;
     int splitk;
+    int accum;               // EPI_F32_PARTIAL with splitk == 1 only: out[m][n] = (out[m][n] + acc) + bias[n] -- the fp32 residual stream
+                             // updated in place by the GEMM that produces the branch (same order of additions as slab + resid_ln)
     int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
     int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
     int glds;                // 0 = register-staged operands; 2..3 = LDS-DMA ring with that many stages (dense only)
@@ -270,10 +272,26 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            bvec[j][q] = rq_bias4(epi != EPI_F32_PARTIAL ? bias : nullptr, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
+            bvec[j][q] = rq_bias4((epi != EPI_F32_PARTIAL || p.accum) ? bias : nullptr, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
+    const bool accum = epi == EPI_F32_PARTIAL && p.accum;      // (launcher: splitk == 1, N % 4 == 0, ldo % 4 == 0)
+    f32x4 xr2[2][NI][4];
+    auto load_x = [&](int i, f32x4 (&dst)[NI][4]) {
+        const int m = m0 + wm * WM + i * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
+                dst[j][q] = (m < p.M && n < p.N) ? *(const f32x4*)((const float*)p.out + (long)m * p.ldo + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+    };
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * WM + i * 32 + (lane & 31);
+        // in-place residual update: the lane's vectors of a 32-row block are requested together, one block ahead of their use
+        if (accum && i == 0) load_x(0, xr2[0]);
+        if (accum && i + 1 < MI) load_x(i + 1, xr2[(i + 1) & 1]);
+        f32x4 (&xr)[NI][4] = xr2[i & 1];
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
@@ -282,7 +300,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                 if (m >= p.M || n >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bvec[j][q][e];
+                for (int e = 0; e < 4; ++e) v[e] = accum ? (xr[j][q][e] + acc[i][j][4 * q + e]) + bvec[j][q][e] : acc[i][j][4 * q + e] + bvec[j][q][e];
                 const bool full4 = vec_ok && n + 3 < p.N;
                 if (epi == EPI_BF16_GELU) {
                     rq_gelu4(v, p.gelu_v2);
