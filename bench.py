@@ -180,7 +180,11 @@ def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model
                      'algorithmic_bytes_per_launch': pf['gemm_bytes'] / pf['gemm_launches'], 'kernel': 'decode-step bf16 MFMA GEMMs (gemm_* kernels)',
                      'launches_per_batch': pf['gemm_launches'], 'avg_launch_us': pf['gemm_ms_total'] * 1e3 / pf['gemm_launches'],
                      'algorithmic_GB_per_batch': pf['gemm_bytes'] / 1e9, 'algorithmic_TFLOP_per_batch': pf['gemm_flops'] / 1e12,
-                     'achieved_GBps': gbs, 'achieved_TFLOPs': tfl, 'flop_per_byte': intensity})
+                     'achieved_GBps': gbs, 'achieved_TFLOPs': tfl, 'flop_per_byte': intensity,
+                     'note': ('proj / fc2 launches also carry the residual update of the fp32 stream (read + write of rows x E x 4 B in their '
+                              'epilogue, counted in algorithmic_bytes) when K is not split; RQAMD_NO_FUSE_RESID=1 restores the plain slab '
+                              'epilogue (GEMM frac 0.42 instead of 0.40 at 10752 rows, 2.5 % fewer images/s)')
+                             if not os.environ.get('RQAMD_NO_FUSE_RESID') else 'plain slab epilogues (RQAMD_NO_FUSE_RESID)'})
     return roofline
 
 
