@@ -182,7 +182,8 @@ int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_lau
  * One raw launch of the engines' bf16 MFMA GEMM: out[M,N] = A[M,K] . W[N,K]^T (+bias), both operands bf16
  * K-contiguous (W = nn.Linear.weight layout).  epi: 0 bf16 out, 1 bf16 + GELU, 3 fp32 out, 4 fp32 split-K
  * partial slabs out[splitk][M][N] (no bias); + 16: skip the epilogue (ablation); + 64 / + 96: stage the operands by
- * LDS-DMA through 2 / 3 LDS stages (tiles 128x64, 128x128, 256x128).  bm/bn <= 0: the engine's own tile choice.
+ * LDS-DMA through 2 / 3 LDS stages (tiles 128x64, 128x128, 256x128); 4 + 2048 (splitk 1): update out[M][N] in place,
+ * out = (out + A.W^T) + bias -- the residual-stream epilogue of the decode step.  bm/bn <= 0: the engine's own tile choice.
  * Used by the kernel-level parity test and scripts/gemm_bench.py; not part of the reference-facing surface. */
 int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                         void* out, int bm, int bn, int splitk, void* stream);

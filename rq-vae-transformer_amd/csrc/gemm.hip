@@ -311,7 +311,8 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
 extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
-    int flags = 0, glds = 0;
+    int flags = 0, glds = 0, accum = 0;
+    if (epi >= 2048) { accum = 1; epi -= 2048; }              // 4 + 2048: in-place residual accumulation (splitk 1)
     if (epi >= 1024) { flags |= 128; epi -= 1024; }           // epi + 1024: 256x256 kernel with four phases per K-tile (A/B)
     if (epi >= 512) { flags |= 64; epi -= 512; }              // epi + 512: 256x256 kernel with two phases per K-tile (A/B)
     if (epi >= 256) { flags |= 32; epi -= 256; }              // epi + 256: eight-phase kernel without s_setprio (A/B)
@@ -319,7 +320,7 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
     if (epi >= 16) { flags |= 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
-    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags; a.glds = glds;
+    a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags; a.glds = glds; a.accum = accum;
     if (bm <= 0 || bn <= 0) {
         int sk, gl = 0;
         rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);

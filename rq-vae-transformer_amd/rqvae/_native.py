@@ -245,7 +245,7 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
     M, K = a_bf16.shape
     N = w_bf16.shape[0]
     if out is None:
-        kind = epi % 16                      # + 16 / + 64 / + 96 are launch options (include/rqamd.h)
+        kind = epi % 16                      # + 16 / + 64 / + 96 / ... are launch options (include/rqamd.h)
         if kind == 4:
             out = torch.empty((splitk if splitk > 0 else 8, M, N), dtype=torch.float32, device=a_bf16.device)
         else:

@@ -418,6 +418,16 @@ def test_emu_gemm_256x256_eight_phase(nat):
             bias_ = None if epi == 4 else bias
             assert torch.equal(nat.dbg_gemm(a, w, bias_, epi=epi + 512, bm=256, bn=256, splitk=1),
                                nat.dbg_gemm(a, w, bias_, epi=epi + 1024, bm=256, bn=256, splitk=1)), (M, N, K, epi)
+        # residual-stream epilogue (4 + 2048): out = (out + a w^T) + bias in place, the additions in the order of slab + resid_ln
+        x0 = T(rng.standard_normal((M, N)).astype(np.float32))
+        slab = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=1)[0]
+        xs = x0.clone()
+        if N % 4 == 0:
+            nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=256, bn=256, splitk=1, out=xs)
+            assert torch.equal(xs, (x0 + slab) + bias), (M, N, K)
+            xs2 = x0.clone()
+            nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=128, bn=64, splitk=1, out=xs2)               # the shared epilogue of the other tiles
+            assert np.abs(xs2.numpy() - xs.numpy()).max() < 1e-4 * np.abs(xs.numpy()).max()
         if K >= 256:
             out = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=2).numpy().sum(0)   # split-K slabs, 2 K-tiles per split
             assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K)

@@ -597,6 +597,29 @@ def test_conv_kernels_vs_torch(nat):
         assert float((out - ref).abs().max()) < 0.02 * float(ref.abs().max())
 
 
+def test_gemm_residual_epilogue(nat):
+    """Decode-step proj / fc2 at the benchmark's row count class: the in-place residual epilogue (epi 4 + 2048: out = (out + a w^T) + bias)
+    of the 256 x 256 kernel gives the bits of the slab epilogue followed by the two additions resid_ln makes, on every launch, and the
+    engine's own tile choice agrees with it to fp32 rounding."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for (M, N, K) in ((2304, 1536, 1536), (2050, 1536, 6144)):
+        a = torch.randn((M, K), device=DEV, generator=g).to(torch.bfloat16)
+        w = (0.05 * torch.randn((N, K), device=DEV, generator=g)).to(torch.bfloat16)
+        bias = torch.randn((N,), device=DEV, generator=g)
+        x0 = torch.randn((M, N), device=DEV, generator=g)
+        slab = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=1)[0]
+        want = (x0 + slab) + bias
+        for _ in range(4):
+            xs = x0.clone()
+            nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=256, bn=256, splitk=1, out=xs)
+            assert torch.equal(xs, want), (M, N, K)
+        ref = x0.double() + a.double() @ w.double().T + bias.double()
+        assert float((want.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+        xs = x0.clone()
+        nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=128, bn=128, splitk=1, out=xs)
+        assert float((xs - want).abs().max()) < 1e-4 * float(want.abs().max())
+
+
 def test_create_model_and_state_dict_roundtrip(nat):
     from rqvae.models import create_model
     from rqvae.utils.config import Config, augment_arch_defaults
