@@ -489,6 +489,13 @@ def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
     e = np.abs(N(vae1.encode(G(x))) - g['z_e'])
     print('vae imagenet encode, halo kernel at 32^2: max err %.4f mean %.5f' % (e.max(), e.mean()))
     assert e.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and e.mean() < 0.01
+    # the default engine reaches the same choice by itself once the batch fills the chip: 64 copies of the golden codes
+    codes64 = G(g['codes'], torch.long).repeat(64, 1, 1, 1).contiguous()
+    d64 = N(vae0.decode_code(codes64))
+    err = np.abs(d64 - ref[:1])
+    print('vae imagenet decode_code at batch 64 (default rule): max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
+    assert np.abs(d64 - d64[:1]).max() == 0.0                  # every copy decodes to the same bits
 
 
 def test_vae_batch_invariance_and_chunking(nat, golden):
