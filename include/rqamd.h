@@ -28,7 +28,9 @@ typedef enum {
     RQAMD_ERR_INVALID = -1,      /* bad argument / shape (reference raises ValueError / AssertionError) */
     RQAMD_ERR_UNSUPPORTED = -2,  /* shape outside what the gfx950 kernels implement */
     RQAMD_ERR_HIP = -3,          /* HIP runtime error */
-    RQAMD_ERR_STATE = -4         /* handle not ready (missing parameters) */
+    RQAMD_ERR_STATE = -4,        /* handle not ready (missing parameters) */
+    RQAMD_ERR_NOMEM = -5         /* hipMalloc of an engine workspace ran out of device memory; the handle is left empty (not
+                                    dangling) and the call may be retried after the caller released memory */
 } rqamd_status;
 
 int rqamd_abi_version(void);

@@ -130,13 +130,21 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     }
     if (!(h->in_vq && h->head_vq)) {
         const bool shared_tok = legacy || c->shared_tok_emb;
+        // one shared table has Vd[0] rows: a depth with a larger vocabulary would read past it (the reference asserts equal
+        // vocabularies for shared_tok_emb, transformers.py:55-56, and nn.Embedding raises an index error)
+        for (int d = 0; shared_tok && d < c->D; ++d)
+            if (h->Vd[d] > h->Vd[0]) {
+                const int vd = h->Vd[d], v0 = h->Vd[0];
+                delete h;
+                return rq_fail(RQAMD_ERR_INVALID, "rqt_create: shared_tok_emb with vocab_sizes[%d] = %d > vocab_sizes[0] = %d", d, vd, v0);
+            }
         long rows = 0;
         for (int d = 0; d < c->D; ++d) { h->tok_offs[d] = shared_tok ? 0 : (int)rows; rows += h->Vd[d]; }
         h->tok_rows = shared_tok ? h->Vd[0] : rows;
         total += al((size_t)h->tok_rows * E * 4);
     }
     if (!h->shared_cls) total += al((size_t)c->D * V * E * 2) + al((size_t)c->D * V * 4);
-    if (h->arena.reserve(total) != RQAMD_OK) { delete h; return RQAMD_ERR_HIP; }
+    { const int rc = h->arena.reserve(total); if (rc != RQAMD_OK) { delete h; return rc; } }
     char* p = (char*)h->arena.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
     auto mk = [&](std::vector<RqtLayer>& v, int n) {

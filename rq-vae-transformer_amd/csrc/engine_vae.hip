@@ -23,14 +23,15 @@
 struct rqamd_vae {
     rqamd_vae_config cfg;
     std::map<std::string, std::unique_ptr<DevBuf>> params;
-    DevBuf slab;               // fp32 split-K partial slabs of the small-batch mode (<= 8 images per call)
+    DevBuf slab;               // fp32 split-K partial slabs (calls of <= SPLIT_MAX_B images; reserved on the first such call)
     DevBuf ws, part, gnp;      // gnp: [chunk][C][2] GroupNorm (scale, shift) for the fused norm->swish->conv
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
     bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false, no_splitk = false;
-    int halo_min_wgs = 512;        // 32^2 layers take the halo kernel when batch x tiles gives at least this many workgroups (RQAMD_HALO_MIN_WGS)
+    bool halo_lowres = true;       // 32^2 layers take the halo kernel like the >= 64^2 ones (RQAMD_HALO_LOWRES=0: implicit GEMM there)
+    static constexpr int SPLIT_MAX_B = 8;      // calls of at most this many images divide the K loop of low-resolution convs over workgroups
     std::string missing;
     // Small batches (the drivers decode ONE image per call, measure_throughput/__main__.py:297-299, main_sampling_fid.py:223;
     // the rFID loop encodes and decodes one image per call, rqvae/metrics/fid.py:167-169) are launch-bound: ~200 launches
@@ -66,7 +67,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
     h->no_splitk = getenv("RQAMD_VAE_NO_SPLITK") != nullptr;
-    if (const char* e = getenv("RQAMD_HALO_MIN_WGS")) h->halo_min_wgs = atoi(e);      // 0: always, 1 << 30: never (the round-1 rule)
+    if (const char* e = getenv("RQAMD_HALO_LOWRES")) h->halo_lowres = atoi(e) != 0;
     if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
     *out = h;
     return RQAMD_OK;
@@ -156,12 +157,23 @@ struct VaeRun {
         return it->second->p;
     }
     void swap() { bf16_t* t = X; X = Y; Y = t; }
-    // Halo-reuse kernel or implicit GEMM for a 3x3 / stride-1 layer: always at >= 64^2; at 32^2 (four 8 x 32 tiles per image) only
-    // when the batch fills the chip -- 128 images: 256 -> 256 215 us + 45 us of GroupNorm passes as implicit GEMM against ~175 us fused
-    // (profiles/r02_decode_timeline_b128.txt); a handful of images would leave most CUs idle and keeps the split-K implicit GEMM.
+    // Halo-reuse kernel or implicit GEMM for a 3x3 / stride-1 layer.  The choice is a function of the LAYER only, never of the
+    // batch: a different kernel means a different summation order, and an image's pixels must not depend on how many other
+    // images shared its call (rows of a batched decode == the same rows decoded one by one, bit for bit -- the speculative
+    // batching behind RQVAE.decode_code relies on it, tests/test_gpu_parity.py::test_vae_batch_invariance_and_chunking).
+    // Always at >= 64^2; at 32^2 (four 8 x 32 tiles per image) as well: at 128 images 256 -> 256 takes ~175 us fused against 215 us
+    // + 45 us of GroupNorm passes as implicit GEMM (profiles/r02_decode_timeline_b128.txt); a single image pays ~0.15 ms per
+    // decode for it (8-16 workgroups per launch) against the split-K implicit GEMM that round 2 used there below 64 images.
     bool halo_here(int H, int W, int Cin, int Cout) const {
         if (h->no_halo || !rq_conv_halo_supported(H, W, Cin, Cout)) return false;
-        return H >= 64 || (long)B * rq_conv_halo_stat_tiles(H, W) * (Cout / 128) >= h->halo_min_wgs;
+        return H >= 64 || h->halo_lowres;
+    }
+    // K split of a low-resolution implicit-GEMM conv: a function of the layer only (see halo_here).  kt K-tiles of 64 -> the
+    // largest split count <= 16 that leaves an even number (>= 4) of K-tiles per chunk; 1 = no split.
+    static int k_split(int kt) {
+        for (int sk = 16; sk >= 2; --sk)
+            if (kt % (2 * sk) == 0 && kt / sk >= 4) return sk;
+        return 1;
     }
 
     // src: NHWC [B][Hin>>ups][Win>>ups][Cin]  ->  dst [B][Hout][Wout][Cout]
@@ -192,23 +204,25 @@ struct VaeRun {
         int bm = a.M >= 128 ? 128 : 64;
         const int bn = (Cout % 128 == 0) ? 128 : 64;
         if (bn == 128 && (long)(a.M / 256) * (Cout / 128) >= 512) bm = 256;     // 8-wave tile for the big layers
-        // small-batch mode: a low-resolution conv with a long reduction has a handful of tiles (8x8, 512 -> 512: four
-        // workgroups walking 72 K-tiles each, 47 us) -- divide K over blockIdx.z and finish with splitk_reduce.  The split
-        // factor depends on the layer only, so results do not depend on the batch size inside this mode.
+        // A low-resolution conv with a long reduction (8x8, 512 -> 512: 72 K-tiles) is summed as sk chunks of K, each from zero,
+        // added in chunk order -- for EVERY batch size, so that the result does not depend on it (see halo_here):
+        //  * few images (a handful of output tiles: four workgroups walking 72 K-tiles each took 47 us): the chunks go to
+        //    blockIdx.z as fp32 slabs and splitk_reduce finishes (slab sum in chunk order + bias + residual, one rounding);
+        //  * many images: one workgroup per tile walks all chunks and folds its accumulators into a running total at the chunk
+        //    boundaries (GemmArgs::vsplit) -- the same additions in the same order, no slabs.
         const int kt = a.K / 64;
-        if (B <= 8 && Hout * Wout <= 1024 && kt >= 16 && Cout % 4 == 0 && !h->no_splitk &&
-            (epi == EPI_BF16 || epi == EPI_BF16_RESID || epi == EPI_F32)) {
-            const int sk = kt >= 64 ? 16 : (kt >= 32 ? 8 : 4);
+        const int sk = (a.conv && Hout * Wout <= 1024 && kt >= 16 && Cout % 4 == 0 && !h->no_splitk &&
+                        (epi == EPI_BF16 || epi == EPI_BF16_RESID)) ? k_split(kt) : 1;
+        if (sk > 1 && B <= rqamd_vae::SPLIT_MAX_B) {
             const size_t need = (size_t)sk * a.M * Cout * 4;
-            if (need <= h->slab.bytes) {
-                a.epi = EPI_F32_PARTIAL; a.bias = nullptr; a.resid = nullptr; a.out = h->slab.p; a.splitk = sk;
-                err = rq_gemm_launch(a, bm, bn, st);
-                if (err) return;
-                err = rq_launch_splitk_reduce(h->slab.as<float>(), sk, a.M, Cout, b, epi == EPI_BF16_RESID ? resid : nullptr, dst,
-                                              epi == EPI_F32 ? 1 : 0, st);
-                return;
-            }
+            if (need > h->slab.bytes) { err = rq_fail(RQAMD_ERR_STATE, "vae: split-K slab of %zu bytes was not reserved", need); return; }
+            a.epi = EPI_F32_PARTIAL; a.bias = nullptr; a.resid = nullptr; a.out = h->slab.p; a.splitk = sk;
+            err = rq_gemm_launch(a, bm, bn, st);
+            if (err) return;
+            err = rq_launch_splitk_reduce(h->slab.as<float>(), sk, a.M, Cout, b, epi == EPI_BF16_RESID ? resid : nullptr, dst, 0, st);
+            return;
         }
+        a.vsplit = sk;
         err = rq_gemm_launch(a, bm, bn, st);
     }
     bool stat_fits(int H, int W) const { return (size_t)B * rq_conv_halo_stat_tiles(H, W) * 32 * 2 * 4 <= h->part.bytes; }
@@ -301,10 +315,22 @@ static int vae_prepare(rqamd_vae* h, int chunk) {
         RQ_TRY(h->part.reserve((size_t)chunk * per_img_parts * 32 * 2 * 4));
     }
     RQ_TRY(h->gnp.reserve((size_t)chunk * 2048 * 2 * 4));
-    // small-batch split-K slabs: 16 slabs x (8 images x 1024 pixels) x widest layer, fp32
-    RQ_TRY(h->slab.reserve((size_t)16 * 8 * 1024 * (size_t)(c.ch * c.ch_mult[c.n_levels - 1]) * 4));
     h->cap_elems = elems;
     h->chunk = chunk;
+    return RQAMD_OK;
+}
+
+// split-K slabs for a call of B <= SPLIT_MAX_B images: <= 16 chunks x (B images x 1024 pixels) x the widest layer, fp32 --
+// 32 MiB per image for the ImageNet / FFHQ shape.  Reserved on the first small call (never inside a graph capture); engines that
+// only ever run large batches do not pay for it.
+static int vae_prepare_slab(rqamd_vae* h, int B) {
+    if (B > rqamd_vae::SPLIT_MAX_B || h->no_splitk) return RQAMD_OK;
+    const rqamd_vae_config& c = h->cfg;
+    size_t cmax = 0;
+    for (int l = 0; l < c.n_levels; ++l) if ((size_t)c.ch * c.ch_mult[l] > cmax) cmax = (size_t)c.ch * c.ch_mult[l];
+    if ((size_t)c.z_channels * (c.double_z ? 2 : 1) > cmax) cmax = (size_t)c.z_channels * (c.double_z ? 2 : 1);
+    const size_t need = (size_t)16 * B * 1024 * cmax * 4;
+    if (need > h->slab.bytes) { RQ_TRY(h->slab.reserve(need)); h->gen++; }      // captured graphs point into the old slab
     return RQAMD_OK;
 }
 
@@ -406,6 +432,7 @@ static int vae_graph_run(rqamd_vae* h, bool dec, const float* in, int B, float* 
     const size_t M = rqamd_vae::GRAPH_MAX_B;
     const size_t o_din = 0, o_dout = o_din + M * lat, o_ein = o_dout + M * dpix, o_eout = o_ein + M * epix, total = o_eout + M * lat;
     RQ_TRY(vae_prepare(h, B > h->chunk ? B : h->chunk));          // allocation happens outside the capture
+    RQ_TRY(vae_prepare_slab(h, B));
     if (h->gio.bytes < total) { RQ_TRY(h->gio.reserve(total)); h->gen++; }
     char* io = (char*)h->gio.p;
     float* gin = (float*)(io + (dec ? o_din : o_ein));
@@ -452,6 +479,7 @@ extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float
         if (g != 1) return g;
     }
     RQ_TRY(vae_prepare(h, chunk));
+    RQ_TRY(vae_prepare_slab(h, batch % chunk ? batch % chunk : chunk));      // a tail chunk of <= SPLIT_MAX_B images divides K
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(decode_chunk(h, z_q + (size_t)b0 * lowres * lowres * c.embed_dim, n,
@@ -472,6 +500,7 @@ extern "C" int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* 
         if (g != 1) return g;
     }
     RQ_TRY(vae_prepare(h, chunk));
+    RQ_TRY(vae_prepare_slab(h, batch % chunk ? batch % chunk : chunk));
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(encode_chunk(h, x + (size_t)b0 * c.in_channels * c.resolution * c.resolution, n,

@@ -53,6 +53,11 @@ struct GemmArgs {
     const bf16_t* resid;
     int ldr;
     int splitk;
+    int vsplit;              // > 1 (conv kernels, bf16 epilogues, splitk == 1): "virtual split-K" -- the K loop runs as vsplit chunks of
+                             // K / 64 / vsplit tiles (an even count), each accumulated from zero and added to a running total in chunk
+                             // order: bit for bit what a real split into vsplit fp32 slabs + splitk_reduce computes, without the slabs.
+                             // It makes a conv's result independent of whether the engine divided its K loop over workgroups (few
+                             // images) or not (many) -- see engine_vae.hip.
     int accum;               // EPI_F32_PARTIAL with splitk == 1 only: out[m][n] = (out[m][n] + acc) + bias[n] -- the fp32 residual stream
                              // updated in place by the GEMM that produces the branch (same order of additions as slab + resid_ln)
     int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
@@ -438,8 +443,9 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 // stages filled by LDS-DMA (global_load_lds_dwordx4, 1 KB = 8 tile rows per wavefront instruction): no staging
 // registers, no ds_write pass; the XOR swizzle moves to the per-lane SOURCE address (the DMA writes lane-linear),
 // the loads are counted by hand (s_waitcnt vmcnt(N) before the barrier that publishes a stage).
-template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0>   // WGM x WGN wavefronts per workgroup
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0, int VS = 0>   // WGM x WGN wavefronts per workgroup
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
+    static_assert(!VS || (GL == 0 && MODE != 0), "virtual split-K: register-staged conv kernels only");
     constexpr int NTH = 64 * WGM * WGN;      // threads per workgroup
     constexpr int RP = NTH / 8;              // tile rows staged per pass (8 threads x 16 B per 64-wide row)
     constexpr bool CONV = MODE != 0;
@@ -734,8 +740,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
                 rq_syncthreads();
             }
             if (p.dbg & 4) { store_tile(0, ra0, rb0, mk0); store_tile(1, ra1, rb1, mk1); }
-        } else
-        for (int pi = 0; pi < npair; ++pi) {
+        } else {
+        auto pair = [&](int pi) {
             const int i = 2 * pi;
             // even tile in LDS buffer 0; set 0 is free, set 1 holds tile i+1
             mk0 = load_tile(kt0 + i + 2 < kt1 ? kt0 + i + 2 : last, ra0, rb0);
@@ -749,8 +755,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
             compute(1);
             store_tile(0, ra0, rb0, mk0);
             rq_syncthreads();
+        };
+        if constexpr (VS) {
+            // virtual split-K (GemmArgs::vsplit): the same pipelined pair loop, cut into chunks of ppc pairs; at a chunk boundary
+            // the accumulators move into the running total (chunk 0: assignment, as the slab reduce starts from slab 0) and restart
+            // from zero.  The boundary sits between two pair bodies, so the loads in flight across it are untouched.
+            f32x16 tot[MI][NI];
+            const int ppc = npair / p.vsplit;              // launcher: nk == 2 * ppc * vsplit
+            int pi = 0;
+            for (int c = 0; c < p.vsplit; ++c) {
+                for (int e = 0; e < ppc; ++e, ++pi) pair(pi);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            tot[i][j][r] = c == 0 ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r];
+                            acc[i][j][r] = 0.f;
+                        }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = tot[i][j];
+        } else {
+            for (int pi = 0; pi < npair; ++pi) pair(pi);
         }
-        if (nk & 1) compute(0);      // odd tile count: the last tile already sits in buffer 0
+        }
+        if (nk & 1) compute(0);      // odd tile count: the last tile already sits in buffer 0 (never with VS: nk is even)
     }
     }   // GL == 0
 

@@ -3,12 +3,12 @@
 #include <stdlib.h>
 #include "rq_common.h"
 
-template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0>
+template <int BM, int BN, int MODE, int TR, int WGM = 2, int WGN = 2, int GL = 0, int VS = 0>
 static int launch_c(const GemmArgs& a, hipStream_t stream) {
     const size_t smem = (size_t)(BM + BN) * 64 * 2 * (GL ? GL : 2);
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL, VS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
     GemmArgs g = a;
@@ -37,7 +37,7 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         nblocks = 8 * ((MT + 7) / 8) * NT;
     }
     dim3 grid(nblocks, 1, a.splitk);
-    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL>), grid, dim3(64 * WGM * WGN), smem, stream, g);
+    RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL, VS>), grid, dim3(64 * WGM * WGN), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
 // register-blocked 256x128 / 4-wave / BK 32 kernel (gemm.h): dense operands, K % 32 == 0
@@ -111,6 +111,7 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
     // transposed accumulators (TR = 1) for everything except wide fp32 rows (logits / fp32 activations)
     const bool tr = a.epi != EPI_F32;
     if (!a.conv) return tr ? launch_c<BM, BN, 0, 1>(a, stream) : launch_c<BM, BN, 0, 0>(a, stream);
+    if (a.vsplit > 1) return a.ups ? launch_c<BM, BN, 2, 1, 2, 2, 0, 1>(a, stream) : launch_c<BM, BN, 1, 1, 2, 2, 0, 1>(a, stream);
     if (a.ups) return tr ? launch_c<BM, BN, 2, 1>(a, stream) : launch_c<BM, BN, 2, 0>(a, stream);
     return tr ? launch_c<BM, BN, 1, 1>(a, stream) : launch_c<BM, BN, 1, 0>(a, stream);
 }
@@ -136,6 +137,10 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     }
     if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL)
         return rq_fail(RQAMD_ERR_INVALID, "gemm: split-K needs the partial-slab epilogue");
+    if (a.vsplit < 1) a.vsplit = 1;
+    if (a.vsplit > 1 && (!a.conv || a.splitk != 1 || (a.epi != EPI_BF16 && a.epi != EPI_BF16_RESID) || (a.K / 64) % (2 * a.vsplit) != 0 ||
+                         (bm == 256 && bn != 128) || bm > 256))
+        return rq_fail(RQAMD_ERR_INVALID, "gemm: virtual split-K needs a conv with a bf16 epilogue, one real split and an even number of K-tiles per chunk");
     if (a.accum && (a.epi != EPI_F32_PARTIAL || a.splitk != 1 || (a.N & 3) || (a.ldo & 3) || (bm == 64 && bn == 32)))
         return rq_fail(RQAMD_ERR_INVALID, "gemm: in-place accumulation needs the slab epilogue, one K split and N, ldo multiples of 4");
     if (bm == 64 && bn == 32) {       // skinny kernel (M <= 64): 32 weight rows per workgroup, in-workgroup split-K over 8 wavefronts
@@ -191,6 +196,7 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
     if (bm == 256 && bn == 128) {     // 8 wavefronts (4x2), 96 KiB LDS: half the weight staging per FLOP
         const bool tr = a.epi != EPI_F32;
         if (!a.conv) return tr ? launch_c<256, 128, 0, 1, 4, 2>(a, stream) : launch_c<256, 128, 0, 0, 4, 2>(a, stream);
+        if (a.vsplit > 1) return a.ups ? launch_c<256, 128, 2, 1, 4, 2, 0, 1>(a, stream) : launch_c<256, 128, 1, 1, 4, 2, 0, 1>(a, stream);
         if (a.ups) return tr ? launch_c<256, 128, 2, 1, 4, 2>(a, stream) : launch_c<256, 128, 2, 0, 4, 2>(a, stream);
         return tr ? launch_c<256, 128, 1, 1, 4, 2>(a, stream) : launch_c<256, 128, 1, 0, 4, 2>(a, stream);
     }

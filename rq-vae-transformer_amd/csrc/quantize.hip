@@ -216,6 +216,10 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
                 int oi = sRedI[w * QT_M + tid];
                 if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
+            // a row whose distances are all NaN / +inf (non-finite encoder output) never satisfies `d < best`: its index is still the
+            // 0x7fffffff seed.  torch.argmin returns 0 for such a row (first NaN / first of equal infinities); an unclamped seed
+            // would index the codebook ~2 TB out of bounds below.  (SPLIT: the combine kernel clamps after merging the splits.)
+            if (!SPLIT && (unsigned)ix >= (unsigned)K) ix = 0;
             if (SPLIT) {
                 if (v0 + tid < p.n_vec) {
                     p.part_v[(v0 + tid) * p.n_split + blockIdx.y] = v;
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(512) void rq_split_combine_kernel(RqQuantArgs p) {
             const int oi = p.part_i[vec * p.n_split + s2];
             if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
         }
+        if ((unsigned)ix >= (unsigned)p.K[dep]) ix = 0;        // all-NaN / all-inf row: torch.argmin's answer (see rq_quantize_kernel)
         if (useg == 0) p.codes[vec * p.depth + dep] = (int64_t)ix;
     }
     const float* q = p.cb[dep] + (long)ix * D;

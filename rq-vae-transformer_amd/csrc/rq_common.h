@@ -59,7 +59,13 @@ struct DevBuf {
         p = nullptr;
         bytes = 0;
         hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        if (e != hipSuccess) {
+            // the runtime keeps a failed call as its "last error" until somebody reads it: clear it here, or the next
+            // rq_check_launch (e.g. of the retried call, after the caller released cached memory) reports this stale failure
+            (void)hipGetLastError();
+            p = nullptr;
+            return rq_fail(e == hipErrorOutOfMemory ? RQAMD_ERR_NOMEM : RQAMD_ERR_HIP, "hipMalloc(%zu): %s", n, hipGetErrorString(e));
+        }
         bytes = n;
         return RQAMD_OK;
     }

@@ -17,7 +17,12 @@ ABI_VERSION = 2
 
 
 class RqamdError(RuntimeError):
-    pass
+    status = None
+
+
+class RqamdOutOfMemory(RqamdError):
+    """RQAMD_ERR_NOMEM: an engine workspace did not fit the free device memory"""
+    status = -5
 
 
 class VaeConfig(C.Structure):
@@ -109,6 +114,8 @@ def check(status):
             raise ValueError(msg)
         if status == -2:
             raise NotImplementedError(msg)
+        if status == -5:
+            raise RqamdOutOfMemory(f'librqamd: out of device memory: {msg}')
         raise RqamdError(f'librqamd status {status}: {msg}')
 
 
@@ -341,12 +348,13 @@ class _Engine:
 
     def _run(self, fn):
         """One native call on the engine's device.  The engines allocate their workspaces with hipMalloc, outside torch's
-        caching allocator: on a HIP (out-of-memory) failure the allocator's cached blocks are released and the call is
-        retried once -- the handle is left empty, not dangling, by a failed regrowth."""
+        caching allocator: on an out-of-memory failure (RQAMD_ERR_NOMEM only -- any other error is raised as it is) the
+        allocator's cached blocks are released and the call is retried once; the handle is left empty, not dangling, by a
+        failed regrowth, and the library clears HIP's sticky last-error after the failed hipMalloc."""
         with on_device_of(self.device):
             try:
                 return check(fn())
-            except RqamdError:
+            except RqamdOutOfMemory:
                 if self.device.type != 'cuda':
                     raise
                 torch.cuda.empty_cache()

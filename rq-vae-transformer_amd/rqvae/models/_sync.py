@@ -6,11 +6,27 @@ in-place version counter of every tensor) decides when they must be pushed again
 import torch
 
 
-def signature(module):
-    sig = []
-    for k, v in module.state_dict(keep_vars=True).items():
-        sig.append((k, v.data_ptr(), v._version, v.device, v.dtype))
-    return tuple(sig)
+def _walk(module, out):
+    for p in module._parameters.values():
+        if p is not None:
+            out.append(p)
+    for b in module._buffers.values():
+        if b is not None:
+            out.append(b)
+    for c in module._modules.values():
+        if c is not None:
+            _walk(c, out)
+
+
+def signature(*modules):
+    """(storage pointer, version counter, device, dtype) of every parameter and buffer below `modules`, in module-tree order.
+    A walk over the live module tree (so replaced Parameters / sub-modules are seen) without building state_dict's prefixed
+    names: ~0.25 ms for the 398 tensors of the RQ-VAE against 2.5 ms through state_dict -- it runs on every decode_code call of
+    the drivers' one-image-per-call loops."""
+    ts = []
+    for m in modules:
+        _walk(m, ts)
+    return tuple([(t.data_ptr(), t._version, t.device, t.dtype) for t in ts])
 
 
 def push_all(module, engine, skip_prefixes=()):

@@ -5,9 +5,13 @@ cloned not mutated, rows before start_loc are kept, per-depth top-k/top-p lists,
 but the 256-step loop runs inside librqamd's sampling engine (csrc/engine_rqt.hip): one C call enqueues
 the whole loop on a side stream, replaying one captured hipGraph per spatial position, with the
 sampler on the device (no host sync per step).  Weights are bf16, accumulation / residual stream /
-LayerNorm / softmax / logits fp32 (the reference's ``amp`` flag selects fp16 autocast; it is accepted
-and ignored here, BASELINE.json asks for bf16)."""
+LayerNorm / softmax / logits fp32.  Arguments of ``sample`` that cannot mean here what they mean upstream
+are never ignored silently: ``amp=True`` (fp16 autocast upstream) warns once that bf16 is the only compute
+dtype; ``cached=False`` runs a real uncached loop (every step recomputes all logits; the reference's own
+cross-check of its cache, transformers.py:352-356); ``is_tqdm`` / ``desc`` have nothing to report on (the
+whole loop is one asynchronous C call) and ``fast`` is unused by the reference itself."""
 import os
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -35,6 +39,7 @@ def _attr(d):
 
 
 class RQTransformer(Stage2Model):
+    _amp_warned = False
 
     def __init__(self, config):
         super().__init__()
@@ -212,16 +217,47 @@ class RQTransformer(Stage2Model):
             top_p_list = [min(top_p[i], 1.0) for i in range(D)]
         B = partial_sample.shape[0]
         device = partial_sample.device
+        if amp and not RQTransformer._amp_warned:
+            # the reference's amp=True is fp16 autocast (transformers.py:305,346); this engine has ONE compute dtype, bf16 GEMM
+            # operands with fp32 accumulation / residual stream / LayerNorm / softmax / logits (BASELINE.json), whatever amp says
+            warnings.warn('RQTransformer.sample(amp=True): librqamd computes in bf16 (fp32 accumulation) regardless of `amp`; '
+                          'there is no fp16 autocast path', stacklevel=2)
+            RQTransformer._amp_warned = True
         eng = self._eng()
         cbs = self._checked_codebooks(model_aux)
         xs = partial_sample.to(torch.long).contiguous()
         c = self._cond(cond, B, device)
         if self.sampler == 'torch':
+            if not cached:
+                raise NotImplementedError("sampler='torch' steps the cached engine; cached=False is available with the default sampler")
             return self._sample_torch_multinomial(eng, xs, c, cbs, start_loc, temperature, top_k_list, top_p_list)
         seed, offset = self._draw_rng(device, H * W * D)
+        if not cached:
+            return self._sample_uncached(eng, xs, c, cbs, start_loc, temperature, top_k_list, top_p_list, seed, offset)
         out = self._on_side_stream(device, lambda: eng.sample(xs, c, cbs, start_loc, temperature, top_k_list, top_p_list,
                                                               seed, offset, self.use_graph))
         return out
+
+    def _sample_uncached(self, eng, xs, cond, cbs, start_loc, temperature, top_k_list, top_p_list, seed, offset):
+        """``cached=False`` (transformers.py:352-356): nothing is carried from one step to the next -- every step recomputes the
+        logits of the whole code map from the codes drawn so far (one teacher-forced pass of the engine per step, 256 per
+        batch, as slow as the reference's own uncached loop) and samples position (h, w, d) from them with the draw the
+        cached path would make at that step (same Philox key: seed, offset + step).  It exists, as in the reference, as the
+        cross-check of the cache: the codes equal ``cached=True`` bit for bit (tests/test_gpu_parity.py)."""
+        from ... import _native
+        (H, W, D) = self.block_size
+        start = max(int(start_loc[0]) * W + int(start_loc[1]), 0)
+        xs = xs.clone()
+        for pos in range(start, H * W):
+            h, w = divmod(pos, W)
+            for d in range(D):
+                logits = self._on_side_stream(xs.device, lambda: eng.logits(xs, cond, cbs))[:, h, w, d].contiguous()
+                if self.vocab_size[d] < logits.shape[-1]:
+                    logits[:, self.vocab_size[d]:] = float('-inf')          # LogitMask, as the sampling path applies it
+                idx, _ = _native.sample_logits(logits, temperature, top_k_list[d], top_p_list[d], seed=seed,
+                                               offset=offset + pos * D + d)
+                xs[:, h, w, d] = idx
+        return xs
 
     def _sample_torch_multinomial(self, eng, xs, cond, cbs, start_loc, temperature, top_k_list, top_p_list):
         """``self.sampler = 'torch'`` (or RQAMD_SAMPLER=torch): the loop of transformers.py:346-364 driven from the host, one engine

@@ -31,13 +31,28 @@ class VQEmbedding(nn.Embedding):
 
     def code_norms(self):
         """||c||^2 per code (the codebook term of compute_distances, quantizations.py:51-52), cached per codebook
-        version: recomputed only after load_state_dict / .to(device) / an in-place edit of the weight."""
+        version: recomputed after load_state_dict / .to(device) / .float() (hooked below) and after any in-place edit that
+        bumps the tensor's version counter.  Writes through ``weight.data`` (``weight.data.copy_()``, EMA helpers that edit
+        ``.data``) do NOT bump it: call ``invalidate_code_norms()`` after such an edit."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.device)
         if getattr(self, '_norm_key', None) != key:
             self._norms = _native.rq_code_norms(self.codebook())
             self._norm_key = key
         return self._norms
+
+    def invalidate_code_norms(self):
+        """Forget the cached ||c||^2 (next quantize recomputes them): required after edits the version counter cannot see."""
+        self._norm_key = None
+        self._norms = None
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.invalidate_code_norms()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_code_norms()
+        return super()._apply(fn, *args, **kwargs)
 
     @torch.no_grad()
     def find_nearest_embedding(self, inputs):

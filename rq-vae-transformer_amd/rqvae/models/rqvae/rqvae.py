@@ -4,6 +4,9 @@ Parameters live in nn.Modules under the reference's state_dict names (398 keys f
 config), so reference checkpoints load with ``load_state_dict``.  encode / decode / decode_code /
 get_codes / forward run in librqamd (csrc/engine_vae.hip, csrc/quantize.hip) on the current HIP
 stream; results are bf16-compute approximations of the reference's fp32 (tolerances in tests/)."""
+import os
+import weakref
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -28,6 +31,55 @@ def _plain(cfg):
         else:
             out[k] = list(v)
     return out
+
+
+class _DecodeAhead:
+    """Speculative batched decode behind per-row ``decode_code`` calls.
+
+    Every caller in the reference decodes ONE image per call out of a batch of codes it already holds:
+    ``torch.cat([model_aux.decode_code(chunk) for chunk in codes.chunk(batch_size)])`` (measure_throughput/__main__.py:297-299),
+    ``torch.cat([model_vqvae.decode_code(pixels[i:i+1]) for i in range(pixels.size(0))])`` (main_sampling_fid.py:223,
+    main_sampling_txt2img.py).  A single 256x256 image cannot fill 256 CUs (2.0 ms per image against 0.30 ms inside a batch), but
+    the argument of such a call is a VIEW of the whole batch (``code._base``), so the rows the loop is about to ask for are
+    known: when a call asks for the row range that directly follows the previous call's on the same base tensor, the engine
+    decodes a window of the following rows in one batched call (1 row cold, then 8, 64, 512 ...: read-ahead, so a caller that
+    wants a single image of a large batch never pays for more than its own) and the next calls are handed row views of that
+    result.  This changes no value: RQVAE.decode is batch-invariant bit for bit (csrc/engine_vae.hip: every kernel choice and
+    summation order is a function of the layer, not of the batch), and a window is served only while the base tensor object,
+    its storage, its version counter, the decoder-side weights and the window's own version counter are what they were when
+    it was decoded (tests/test_gpu_parity.py::test_vae_decode_code_read_ahead).  RQAMD_DECODE_AHEAD=<max rows> (0 = off)."""
+    RAMP = 8
+
+    def __init__(self):
+        self.max_rows = int(os.environ.get('RQAMD_DECODE_AHEAD', 512))
+        self.clear()
+
+    def clear(self):
+        self.base_ref = None          # weakref to the tensor object the served views are views of
+        self.key = None               # (storage pointer, version, shape) of that tensor + signature of the decoder-side weights
+        self.lo = self.hi = 0         # rows [lo, hi) of the base are held in self.pixels
+        self.pixels = None
+        self.pix_version = 0
+        self.next_row = -1            # the row a sequential caller asks for next
+        self.window = 0               # rows decoded by the last engine call of this run
+        self.event = None
+        self.stream = None
+        self.hits = self.engine_calls = 0
+
+    @staticmethod
+    def rows_of(code):
+        """(base, first row, rows) when `code` is a contiguous row range of a larger contiguous batch of the same trailing
+        shape, else None."""
+        base = code._base
+        if base is None or base.dim() != code.dim() or code.dim() < 2 or base.shape[1:] != code.shape[1:]:
+            return None
+        if base.shape[0] <= code.shape[0] or code.shape[0] < 1 or not base.is_contiguous() or not code.is_contiguous():
+            return None
+        row = code[0].numel()
+        off = code.storage_offset() - base.storage_offset()
+        if row == 0 or off < 0 or off % row or off // row + code.shape[0] > base.shape[0]:
+            return None
+        return base, off // row, code.shape[0]
 
 
 class RQVAE(Stage1Model):
@@ -62,6 +114,7 @@ class RQVAE(Stage1Model):
         self._engine = None
         self._engine_sig = None
         self._side = SideStream()
+        self._ahead = _DecodeAhead()
 
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
@@ -114,9 +167,44 @@ class RQVAE(Stage1Model):
 
     @torch.no_grad()
     def decode_code(self, code):
-        """rqvae.py:105-109"""
+        """rqvae.py:105-109.  Per-row calls on views of one code batch -- the way every driver of the reference calls this --
+        are served from batched decodes of the rows that follow (see _DecodeAhead); values are identical either way."""
+        st = self._ahead
+        rows = st.rows_of(code) if st.max_rows > 0 else None
+        if rows is None:
+            return self._decode_code_now(code)
+        base, i0, n = rows
+        key = (base.data_ptr(), base._version, tuple(base.shape), signature(self.decoder, self.post_quant_conv, self.quantizer))
+        same = st.base_ref is not None and st.base_ref() is base and st.key == key
+        if same and st.pixels is not None and st.lo <= i0 and i0 + n <= st.hi and st.pixels._version == st.pix_version:
+            if code.is_cuda:
+                cur = torch.cuda.current_stream(code.device)
+                if cur != st.stream:
+                    cur.wait_event(st.event)
+            st.next_row = i0 + n
+            st.hits += 1
+            return st.pixels[i0 - st.lo:i0 - st.lo + n]
+        window = n
+        if same and i0 == st.next_row:                 # a sequential run: read ahead, RAMP x what the last engine call decoded
+            window = max(n, min(st.window * st.RAMP, st.max_rows, base.shape[0] - i0))
+        pixels = self._decode_code_now(base[i0:i0 + window])
+        st.base_ref, st.key = weakref.ref(base), key
+        st.lo, st.hi, st.pixels, st.pix_version = i0, i0 + window, pixels, pixels._version
+        st.next_row, st.window = i0 + n, window
+        if code.is_cuda:
+            st.stream = torch.cuda.current_stream(code.device)
+            st.event = torch.cuda.Event()
+            st.event.record(st.stream)
+        st.engine_calls += 1
+        return pixels[:n]
+
+    def _decode_code_now(self, code):
         z_q = self.quantizer.embed_code(code)
         return self.decode(z_q)
+
+    def clear_decode_cache(self):
+        """Drop the read-ahead window held for per-row decode_code calls (up to RQAMD_DECODE_AHEAD images of pixels)."""
+        self._ahead.clear()
 
     def get_recon_imgs(self, xs_real, xs_recon):
         """rqvae.py:111-117"""

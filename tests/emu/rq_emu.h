@@ -261,6 +261,7 @@ typedef void* hipGraphExec_t;
 typedef void* hipEvent_t;
 #define hipSuccess 0
 #define hipErrorNotSupported 801
+#define hipErrorOutOfMemory 2
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); memset(*p, 0xFF, n); return *p ? 0 : 2; }

@@ -375,6 +375,82 @@ def test_emu_vae_tiny(nat, golden):
     assert err.max() < 0.05 and err.mean() < 0.008
 
 
+def test_emu_vae_batch_invariance_across_split_k_forms(nat, golden):
+    """An image's pixels / latents do not depend on how many images shared its call: calls of <= 8 images divide the K loop of
+    the low-resolution convs over workgroups (fp32 slabs + splitk_reduce), larger calls fold the same chunks inside one
+    workgroup (GemmArgs::vsplit) -- the same additions in the same order, so rows of a 10-image call must equal the same
+    images decoded / encoded one, three and eight at a time BIT FOR BIT (the speculative batching behind
+    RQVAE.decode_code hands out rows of a batched decode in place of per-image calls)."""
+    g = golden('vae_tiny.npz')
+    hps, dd = C.VAE_TINY
+    params = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed']))
+    eng = _vae_engine(nat, hps, dd, params)
+    rng = np.random.default_rng(12)
+    cb = params['quantizer.codebooks.0.weight'][:-1]
+    codes = rng.integers(0, hps['n_embed'], (10, 8, 8, 4))
+    z_q = T(oracle.rq_embed_code(codes, [cb] * 4))
+    big = eng.decode(z_q).numpy()                                   # 10 images: virtual split-K
+    for lo, hi in ((0, 1), (3, 4), (1, 4), (2, 10), (9, 10)):       # 1 / 1 / 3 / 8 / 1 images: real split-K (graph replay up to 4)
+        np.testing.assert_array_equal(eng.decode(z_q[lo:hi].contiguous()).numpy(), big[lo:hi])
+    x = T(np.clip(rng.standard_normal((10, 3, 16, 16), dtype=np.float32), -1, 1))
+    zbig = eng.encode(x).numpy()
+    for lo, hi in ((0, 1), (4, 7), (2, 10)):
+        np.testing.assert_array_equal(eng.encode(x[lo:hi].contiguous()).numpy(), zbig[lo:hi])
+
+
+def test_emu_vae_decode_code_read_ahead(nat, golden):
+    """RQVAE.decode_code called one row at a time on views of a code batch (the reference drivers' loops,
+    measure_throughput/__main__.py:297-299, main_sampling_fid.py:223) is served from batched decodes of the rows that follow;
+    every row equals the cold single-image call bit for bit, and nothing stale is ever served."""
+    from rqvae.models.rqvae import RQVAE
+    g = golden('vae_tiny.npz')
+    hps, dd = C.VAE_TINY
+    params = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed']))
+    vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
+    vae.load_state_dict({k: T(v) for k, v in params.items()})
+    vae.eval()
+    rng = np.random.default_rng(21)
+    codes = T(rng.integers(0, hps['n_embed'], (12, 8, 8, 4)))
+    cold = [vae.decode_code(codes[i:i + 1].clone()) for i in range(12)]            # not views: one engine call each
+    st = vae._ahead
+    assert st.engine_calls == 0 and st.hits == 0
+    # main_sampling_fid.py:223
+    rows = [vae.decode_code(codes[i:i + 1]) for i in range(12)]
+    assert st.engine_calls == 3 and st.hits == 9                                    # 1 row cold, 8 ahead, the last 3
+    for a, b in zip(rows, cold):
+        assert torch.equal(a, b)
+    # measure_throughput/__main__.py:297-299
+    pixels = torch.cat([vae.decode_code(chunk) for chunk in codes.chunk(12)], dim=0)
+    assert torch.equal(pixels, torch.cat(cold, dim=0))
+    # an edit of the codes (version counter) is seen: nothing stale
+    calls = st.engine_calls
+    codes[5] = codes[0]
+    assert torch.equal(vae.decode_code(codes[5:6]), cold[0]) and st.engine_calls == calls + 1
+    # an in-place edit of a served window is never handed out again
+    w = vae.decode_code(codes[6:7])
+    assert torch.equal(w, cold[6])
+    w.add_(1.0)
+    assert torch.equal(vae.decode_code(codes[6:7]), cold[6])
+    # a different tensor object over equal contents starts cold (storage addresses can be recycled)
+    other = codes.clone()
+    calls = st.engine_calls
+    assert torch.equal(vae.decode_code(other[1:2]), cold[1]) and st.engine_calls == calls + 1
+    # a weight edit invalidates the window
+    vae.decode_code(other[2:3])
+    with torch.no_grad():
+        vae.decoder.conv_out.bias.add_(0.5)
+    np.testing.assert_allclose(vae.decode_code(other[3:4]).numpy(), cold[3].numpy() + 0.5, rtol=0, atol=1e-5)     # not the stale window
+    # the whole batch in one call takes the plain path; RQAMD_DECODE_AHEAD=0 / max_rows = 0 switches the read-ahead off
+    with torch.no_grad():
+        vae.decoder.conv_out.bias.sub_(0.5)
+    calls, hits = st.engine_calls, st.hits
+    assert torch.equal(vae.decode_code(codes[:4]), torch.cat([vae.decode_code(codes[i:i + 1].clone()) for i in range(4)]))
+    st.max_rows = 0
+    for i in range(3):
+        vae.decode_code(codes[i:i + 1])
+    assert st.hits == hits
+
+
 def test_emu_gemm_tiles_and_lds_dma(nat):
     """Decode-step GEMM through the diagnostics entry: register-staged and LDS-DMA staged (2 / 3 stages) operand paths,
     ragged M / N (clamped rows), odd and even K-tile counts, bf16 / fp32 / split-K epilogues, vs fp32 matmul."""
