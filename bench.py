@@ -4,12 +4,14 @@
 Workload (config.workload): BASELINE.json configs[2], the configuration the metric is quoted on --
 ImageNet-256 class-conditional RQ-Transformer 1.4B (E 1536 / 24 heads / 42 body + 6 head layers /
 V 16384, measure_throughput 'huge', reference measure_throughput/__main__.py:71-92) sampling 8x8x4
-codes, then RQ-VAE (104 M) decode_code to 256x256 pixels and the [0,1] clamp, exactly the timed body
-of the reference's throughput script (:295-301).  Random-init weights of that architecture
-(torch.manual_seed(0), module default inits), zero class condition, synthetic -- there is no network.
+codes, then RQ-VAE (104 M) decode_code to 256x256 pixels and the [0,1] clamp.  Random-init weights of that
+architecture (torch.manual_seed(0), module default inits), zero class condition, synthetic -- there is no network.
 
 One "step" = one batch of B images per GPU: sample -> decode -> clamp (-> pixel all-gather when N > 1,
-main_sampling_fid.py:226).  value = N * B * K / max-over-ranks time, inputs resident in HBM.
+main_sampling_fid.py:226).  value = N * B * K / max-over-ranks time, inputs resident in HBM.  The headline step calls
+``decode_code(codes)`` ONCE on the whole batch; the reference's throughput script decodes one image per call
+(``torch.cat([decode_code(chunk) for chunk in codes.chunk(B)])``, :297-299) -- that exact loop is timed separately, at
+the reference's own batches, as ``batch_sweep[*].driver_loop`` (it is served by the read-ahead of RQVAE.decode_code).
 
 Launching.  `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself
 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` re-executing this
@@ -17,9 +19,12 @@ file, one process per GPU, RCCL); under an external torchrun (RANK / WORLD_SIZE 
 that job.  The world size actually joined is what `n_gpus` reports.
 
 Extra objects on the JSON line: "roofline" for the dominant kernel (the bf16 MFMA weight-streaming GEMM of the
-decode step, timed live with HIP events on the engine's stream in a separate profiled pass), "batch_sweep" (the same
-measurement at the per-GPU batches of BASELINE configs[3] = 64 and of the reference's Fig. 4 = 500, each with its own
-roofline), "per_image_decode" (decode_code on ONE image per call, as the unchanged drivers call it), "roofline_rq"
+decode step, timed live with HIP events on the engine's stream in a separate profiled pass), "roofline_attn" (KV-cache
+bytes / decode-attention time, same pass), "roofline_decode" (RQ-VAE decoder conv FLOPs / decode time of the timed region),
+"step_frac_of_mfma_peak" (all algorithmic FLOPs of a step / step time / 2.5 PF), "verified" (post-timed-region check of
+the sampled codes), "batch_sweep" (the same measurement at the per-GPU batches SURVEY 8d names: 64 = BASELINE configs[3]
+per-GPU share, 100 / 200 / 500 = the reference's Fig. 4; each with its own roofline and the reference script's
+one-image-per-call loop as "driver_loop"), "per_image_decode" (that loop on its own), "per_image_recon", "roofline_rq"
 (the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the numpy oracle on the host cores, bounded
 sample, rank 0, N=1 only)."""
 import argparse
@@ -62,7 +67,7 @@ def parse_args(argv=None):
     # BASELINE.json configs[2]: top-k=1024 / top-p=0.95 (0 / 1.0 = the reference defaults top_k=None, top_p=None)
     ap.add_argument('--top-k', type=int, default=1024)
     ap.add_argument('--top-p', type=float, default=0.95)
-    ap.add_argument('--sweep', type=str, default='64,500', help='extra per-GPU batches measured after the timed region ("" = none)')
+    ap.add_argument('--sweep', type=str, default='64,100,200,500', help='extra per-GPU batches measured after the timed region ("" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
@@ -146,7 +151,7 @@ def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):
                       f'{t_dec:.2f} s/img'}
 
 
-def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model, B):
+def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model, B, cfg):
     """Profiled pass: every decode-step GEMM launch bracketed by HIP events on the engine's stream (graphs off for this pass)."""
     eng = ar._eng()
     eng.set_profile(True)
@@ -165,18 +170,21 @@ def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model
         roofline = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
     else:
         roofline = {'bound': 'mfma', 'achieved': tfl, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
-    traffic, traffic_src = None, None
-    for rnd in ('r02', 'r01'):
-        tp = os.path.join(ROOT, 'profiles', f'{rnd}_gemm_traffic_m{B}.json')
-        if model == 'huge' and os.path.exists(tp):
-            # PMC counters cannot be collected from inside the timed run; this is the committed result of
-            # scripts/gpu_pmc2.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM
-            # shapes at the same batch rows, launch-weighted like `achieved`
-            with open(tp) as f:
-                tj = json.load(f)
+    traffic, traffic_src, traffic_note = None, None, None
+    tp = os.path.join(ROOT, 'profiles', f'r03_gemm_traffic_m{B}.json')
+    if model == 'huge' and os.path.exists(tp):
+        # PMC counters cannot be collected from inside the timed run; this is the committed result of `scripts/gpu.sh pmc`
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM shapes at the same batch rows,
+        # launch-weighted like `achieved`.  It is stamped with a hash of the GEMM kernel sources it was measured on and is
+        # refused when they have changed since.
+        from rqvae import _native
+        with open(tp) as f:
+            tj = json.load(f)
+        if tj.get('kernel_sources_sha16') == _native.kernel_source_hash():
             traffic, traffic_src = tj['hbm_bytes_per_launch_weighted'], os.path.relpath(tp, ROOT)
-            break
-    roofline.update({'traffic': traffic, 'traffic_source': traffic_src, 'traffic_measured_in_run': False,
+        else:
+            traffic_note = f'{os.path.relpath(tp, ROOT)} was measured on other GEMM sources ({tj.get("kernel_sources_sha16")}): refused'
+    roofline.update({'traffic': traffic, 'traffic_source': traffic_src, 'traffic_measured_in_run': False, 'traffic_note': traffic_note,
                      'algorithmic_bytes_per_launch': pf['gemm_bytes'] / pf['gemm_launches'], 'kernel': 'decode-step bf16 MFMA GEMMs (gemm_* kernels)',
                      'launches_per_batch': pf['gemm_launches'], 'avg_launch_us': pf['gemm_ms_total'] * 1e3 / pf['gemm_launches'],
                      'algorithmic_GB_per_batch': pf['gemm_bytes'] / 1e9, 'algorithmic_TFLOP_per_batch': pf['gemm_flops'] / 1e12,
@@ -185,7 +193,136 @@ def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model
                               'epilogue, counted in algorithmic_bytes) when K is not split; RQAMD_NO_FUSE_RESID=1 restores the plain slab '
                               'epilogue (GEMM frac 0.42 instead of 0.40 at 10752 rows, 2.5 % fewer images/s)')
                              if not os.environ.get('RQAMD_NO_FUSE_RESID') else 'plain slab epilogues (RQAMD_NO_FUSE_RESID)'})
-    return roofline
+    # second roofline of the same pass: the decode-step attention reads the KV cache once per step (HBM-bound)
+    attn = None
+    if pf.get('attn_launches', 0) > 0 and pf['attn_ms_total'] > 0:
+        kvb = kv_bytes_per_image(cfg) * B
+        gb = kvb / (pf['attn_ms_total'] * 1e-3) / 1e9
+        attn = {'bound': 'hbm', 'achieved': gb, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gb / HBM_PEAK_GBS,
+                'kernel': 'attn_decode_kernel / attn_small_kernel (KV-cached MultiSelfAttention, attentions.py:60-104)',
+                'launches_per_batch': pf['attn_launches'], 'avg_launch_us': pf['attn_ms_total'] * 1e3 / pf['attn_launches'],
+                'algorithmic_GB_per_batch': kvb / 1e9, 'ms_per_batch': pf['attn_ms_total'],
+                'what': 'bf16 K and V of every cached key read once per step and layer; q / output traffic not counted'}
+    return roofline, attn
+
+
+def kv_bytes_per_image(cfg):
+    """bf16 K + V bytes the cached attention reads for one image: body step p attends p + cond_len keys in each body layer,
+    head step d attends d + 1 keys in each head layer (0.56 GB per image for the 1.4B model)."""
+    E, (H, W, D) = cfg['embed_dim'], cfg['block_size']
+    cl = max(cfg.get('block_size_cond', 1), 1)
+    body = sum(p + cl for p in range(H * W)) * cfg['body']['n_layer']
+    head = H * W * sum(d + 1 for d in range(D)) * cfg['head']['n_layer']
+    return (body + head) * E * 2 * 2
+
+
+def rqt_flops_per_image(cfg):
+    """2 * (weights touched per step) summed over the 64 body and 256 head steps of one image (GEMMs only)."""
+    E, V, (H, W, D) = cfg['embed_dim'], cfg['vocab_size'], cfg['block_size']
+    return 2.0 * (H * W * cfg['body']['n_layer'] * 12 * E * E + H * W * D * (cfg['head']['n_layer'] * 12 * E * E + E * V))
+
+
+def decoder_flops_per_image(dd, embed_dim):
+    """Convolution + attention-GEMM FLOPs of Decoder.forward + post_quant_conv for one image (modules.py:171-202), from the
+    ddconfig alone: 249.5 GFLOP for the released 256x256 shapes."""
+    ch, mult, nrb = dd['ch'], list(dd['ch_mult']), dd['num_res_blocks']
+    res = dd['resolution'] >> (len(mult) - 1)
+    fl = 0.0
+
+    def conv(cin, cout, k, hw):
+        return 2.0 * hw * hw * cin * cout * k * k
+
+    def resblock(cin, cout, hw):
+        f = conv(cin, cout, 3, hw) + conv(cout, cout, 3, hw)
+        return f + (conv(cin, cout, 1, hw) if cin != cout else 0.0)
+
+    def attn(c, hw):
+        t = hw * hw
+        return 4 * conv(c, c, 1, hw) + 2 * 2.0 * t * t * c
+    block_in = ch * mult[-1]
+    fl += conv(embed_dim, dd['z_channels'], 1, res) + conv(dd['z_channels'], block_in, 3, res)
+    fl += 2 * resblock(block_in, block_in, res) + attn(block_in, res)
+    for lvl in reversed(range(len(mult))):
+        block_out = ch * mult[lvl]
+        for _ in range(nrb + 1):
+            fl += resblock(block_in, block_out, res)
+            block_in = block_out
+            if res in dd['attn_resolutions']:
+                fl += attn(block_in, res)
+        if lvl != 0:
+            res *= 2
+            fl += conv(block_in, block_in, 3, res)
+    return fl + conv(block_in, dd['out_ch'], 3, res)
+
+
+def driver_loop(vae, ar, B, device, top_k, top_p, steps, warmup):
+    """The timed body of the reference's throughput script, verbatim (measure_throughput/__main__.py:293-301):
+        codes = model_ar.sample(empty_sample, model_aux=model_aux, cond=empty_cond)
+        chunks = codes.chunk(batch_size)
+        pixels = torch.cat([model_aux.decode_code(chunk) for chunk in chunks], dim=0)
+        _ = (0.5 * pixels + 0.5).clamp(0, 1)
+    with its own event placement (start / middle / end), on this package's models."""
+    es = torch.zeros((B,) + tuple(ar.block_size), device=device, dtype=torch.long)
+    ec = torch.zeros((B, ar.block_size_cond), device=device, dtype=torch.long)
+    st = vae._ahead
+    calls0, hits0 = st.engine_calls, st.hits
+    t_ar = t_dec = 0.0
+    el = 0.0
+    for it in range(warmup + steps):
+        if it == warmup:
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            calls0, hits0 = st.engine_calls, st.hits
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        codes = ar.sample(es, model_aux=vae, cond=ec, top_k=top_k, top_p=top_p)
+        ev[1].record()
+        chunks = codes.chunk(B)
+        pixels = torch.cat([vae.decode_code(chunk) for chunk in chunks], dim=0)
+        _ = (0.5 * pixels + 0.5).clamp(0, 1)
+        ev[2].record()
+        if it >= warmup:
+            ev[2].synchronize()
+            t_ar += ev[0].elapsed_time(ev[1])
+            t_dec += ev[1].elapsed_time(ev[2])
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t0
+    return {'images_per_sec': B * steps / el, 'ar_ms_per_image': t_ar / (steps * B), 'decode_ms_per_image': t_dec / (steps * B),
+            'decode_engine_calls_per_batch': (st.engine_calls - calls0) / steps, 'decode_calls_served_from_read_ahead': (st.hits - hits0) / steps,
+            'what': 'sample, then torch.cat([decode_code(chunk) for chunk in codes.chunk(B)]) and the clamp: '
+                    'measure_throughput/__main__.py:293-301 verbatim'}
+
+
+def verify_codes(vae, ar, codes, cond, top_k, top_p, n_rows=8):
+    """Correctness check of what the timed region produced (run after it): every code in range, and for n_rows rows spread
+    over the batch every one of the 256 sampled codes has non-zero probability under the filtered distribution (temperature 1,
+    top-k, top-p: the reference's sample_from_logits, utils.py:82-123, restated in oracle/sampler.py) of the teacher-forced
+    logits of that row -- computed through the same kernels the batch used (the diagnostics row-scale hook makes the kernel
+    selection see the full batch)."""
+    import oracle
+    from rqvae import _native
+    B, V = codes.shape[0], ar.vocab_size
+    in_range = bool(int(codes.min()) >= 0 and all(int(codes[..., d].max()) < V[d] for d in range(codes.shape[-1])))
+    rows = sorted(set(int(r) for r in np.linspace(0, B - 1, n_rows)))
+    sub = codes[rows].contiguous()
+    _native.dbg_set_row_scale(max(1, (B + len(rows) - 1) // len(rows)))
+    try:
+        logits = ar.teacher_forced_logits(sub, vae, cond=cond[rows].contiguous())
+    finally:
+        _native.dbg_set_row_scale(1)
+    logits = logits.cpu().numpy()
+    sub = sub.cpu().numpy()
+    H, W, D = sub.shape[1:]
+    outside = 0
+    for h in range(H):
+        for w in range(W):
+            for d in range(D):
+                pr = oracle.filtered_probs(logits[:, h, w, d], 1.0, top_k, top_p)
+                outside += int((pr[np.arange(len(rows)), sub[:, h, w, d]] <= 0).sum())
+    n = len(rows) * H * W * D
+    return {'verified': bool(in_range and outside <= max(1, n // 1000)), 'codes_in_range': in_range, 'rows_teacher_forced': len(rows),
+            'codes_checked': n, 'codes_outside_filtered_support': outside,
+            'what': 'post-timed-region: codes of the last timed step; filtered support via the oracle sampler on teacher-forced logits'}
 
 
 def timed_batch(vae, ar, B, device, top_k, top_p, steps, warmup):
@@ -216,20 +353,39 @@ def timed_batch(vae, ar, B, device, top_k, top_p, steps, warmup):
 
 def per_image_decode(vae, ar, device, n=64):
     """The unchanged drivers decode ONE image per call (measure_throughput/__main__.py:297-299,
-    main_sampling_fid.py:223): torch.cat([decode_code(codes[i:i+1]) for i in range(B)])."""
+    main_sampling_fid.py:223): torch.cat([decode_code(codes[i:i+1]) for i in range(B)]).  `ms_per_image`: that loop as the
+    drivers run it (row views of one code batch: served by the read-ahead of RQVAE.decode_code); `cold_ms_per_image`: the
+    same rows passed as independent tensors, one engine call (graph replay) per image."""
     V = ar.vocab_size[0]
     codes = torch.randint(0, V, (n,) + tuple(ar.block_size), device=device)
-    for i in range(4):
-        vae.decode_code(codes[i:i + 1])
+    warm = torch.randint(0, V, (n,) + tuple(ar.block_size), device=device)
+    for i in range(n):
+        vae.decode_code(warm[i:i + 1])
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = vae._ahead
+    calls0 = st.engine_calls
+    t0 = time.perf_counter()
     e0.record()
     pixels = torch.cat([vae.decode_code(codes[i:i + 1]) for i in range(n)], dim=0)
     pixels = (0.5 * pixels + 0.5).clamp(0, 1)
     e1.record()
     e1.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / n
     ms = e0.elapsed_time(e1) / n
-    return {'ms_per_image': ms, 'images_per_sec': 1e3 / ms, 'images': n,
+    calls = st.engine_calls - calls0
+    singles = [codes[i:i + 1].clone() for i in range(n)]
+    for i in range(4):
+        vae.decode_code(singles[i])
+    torch.cuda.synchronize(device)
+    e0.record()
+    cold = torch.cat([vae.decode_code(c) for c in singles], dim=0)
+    cold = (0.5 * cold + 0.5).clamp(0, 1)
+    e1.record()
+    e1.synchronize()
+    cold_ms = e0.elapsed_time(e1) / n
+    return {'ms_per_image': ms, 'wall_ms_per_image': wall, 'images_per_sec': 1e3 / ms, 'images': n, 'engine_calls': calls,
+            'cold_ms_per_image': cold_ms, 'bit_identical_to_cold': bool(torch.equal(pixels, cold)),
             'what': 'decode_code(codes[i:i+1]) one image per call + cat + clamp, as measure_throughput/__main__.py:297-299 does'}
 
 
@@ -440,10 +596,18 @@ def main(argv=None):
         rank_times = [float(x.item()) for x in allt]
         elapsed = max(rank_times)
 
+    # ---- correctness of what the timed region produced (codes of its last step), after the clock stopped
+    verify = None
+    if rank == 0 and not args.overlap and not args.no_profile and args.steps > 0:
+        try:
+            verify = verify_codes(vae, ar, codes, empty_cond, args.top_k, args.top_p)
+        except Exception as e:
+            verify = {'verified': False, 'error': repr(e)}
+
     # ---- roofline of the dominant kernel at the timed batch
-    roofline = None
+    roofline = roofline_attn = None
     if rank == 0 and not args.no_profile:
-        roofline = gemm_roofline(ar, vae, empty_sample, empty_cond, args.top_k, args.top_p, device, args.model, B)
+        roofline, roofline_attn = gemm_roofline(ar, vae, empty_sample, empty_cond, args.top_k, args.top_p, device, args.model, B, cfg)
 
     # ---- the same measurement at smaller per-GPU batches (BASELINE configs[3] per-GPU share, reference Fig. 4 batch)
     sweep = []
@@ -455,9 +619,13 @@ def main(argv=None):
             entry = {'batch_per_gpu': b, 'images_per_sec': ips, 'ar_ms_per_image': a_ms, 'decode_ms_per_image': d_ms,
                      'ar_ms_per_batch': a_ms * b}
             if not args.no_profile:
-                entry['roofline'] = gemm_roofline(ar, vae, es, ec, args.top_k, args.top_p, device, args.model, b)
-            sweep.append(entry)
+                entry['roofline'], entry['roofline_attn'] = gemm_roofline(ar, vae, es, ec, args.top_k, args.top_p, device, args.model, b, cfg)
             del es, ec
+            # the reference script's own loop (one image per decode_code call) at the same batch
+            dl = driver_loop(vae, ar, b, device, args.top_k, args.top_p, steps=3 if b >= 256 else 5, warmup=1)
+            dl['vs_batched'] = dl['images_per_sec'] / ips
+            entry['driver_loop'] = dl
+            sweep.append(entry)
 
     # ---- per-image decode (the drivers' call pattern), BASELINE's second metric (codes/sec) and the quantiser roofline
     pid = pir = enc = rqr = None
@@ -488,6 +656,18 @@ def main(argv=None):
     if rank == 0:
         n_img = world * B * args.steps
         value = n_img / elapsed
+        roofline_decode = step_frac = None
+        dfl = decoder_flops_per_image(vcfg['ddconfig'], vcfg['hparams']['embed_dim'])
+        if not args.overlap and t_dec > 0:
+            tf = dfl * B * args.steps / (t_dec * 1e-3) / 1e12
+            roofline_decode = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_BF16_PEAK_TFLOPS,
+                               'algorithmic_GFLOP_per_image': dfl / 1e9, 'ms_per_image': t_dec / (args.steps * B),
+                               'what': 'RQ-VAE decode_code + clamp of the timed region: conv / attention-GEMM FLOPs of Decoder.forward '
+                                       '(modules.py:171-202) over its device time (events around the decode half of every step)'}
+        step_frac = {'achieved_TFLOPs': (dfl + rqt_flops_per_image(cfg)) * value / world / 1e12,
+                     'frac': (dfl + rqt_flops_per_image(cfg)) * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                     'algorithmic_GFLOP_per_image': (dfl + rqt_flops_per_image(cfg)) / 1e9,
+                     'what': 'all GEMM + conv FLOPs of one image (transformer decode steps + RQ-VAE decoder) x images/s per GPU / 2.5 PF'}
         out = {
             'metric': f'256x256 images/sec, AR sampling + decode (RQ-Transformer {args.model}, 8x8x4 codes)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -506,7 +686,9 @@ def main(argv=None):
                                           'different batch / precision / hardware -- context, not a like-for-like ratio'},
             'ar_ms_per_image': t_ar / (args.steps * B) if not args.overlap else None,
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
-            'roofline': roofline, 'batch_sweep': sweep, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'verified': None if verify is None else verify['verified'], 'verify': verify,
+            'roofline': roofline, 'roofline_attn': roofline_attn, 'roofline_decode': roofline_decode,
+            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 2
+#define RQAMD_ABI_VERSION 3
 
 typedef enum {
     RQAMD_OK = 0,
@@ -179,6 +179,9 @@ int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream);
 int rqamd_rqt_set_profile(rqamd_rqt* h, int profile);
 int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_launches,
                           double* gemm_bytes_total, double* gemm_flops_total);
+/* the cached-attention launches (MultiSelfAttention.forward with the KV cache, attentions.py:60-104) of the same profiled call:
+ * total device time and launch count (the KV bytes they read are a function of the shapes: bench.py computes them). */
+int rqamd_rqt_get_profile_attn(rqamd_rqt* h, double* attn_ms_total, int64_t* attn_launches);
 
 /* ---- diagnostics ------------------------------------------------------------------------------
  * One raw launch of the engines' bf16 MFMA GEMM: out[M,N] = A[M,K] . W[N,K]^T (+bias), both operands bf16

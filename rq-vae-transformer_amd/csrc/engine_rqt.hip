@@ -35,6 +35,11 @@ struct GemmProfile {
     double bytes = 0, flops = 0;
     double ms_total = 0;
     int64_t launches = 0;
+    // the decode-step attention launches of the same call, bracketed the same way (second roofline: KV-cache bytes / this time)
+    std::vector<hipEvent_t> ev_attn;
+    size_t used_attn = 0;
+    double attn_ms_total = 0;
+    int64_t attn_launches = 0;
 };
 
 struct rqamd_rqt {
@@ -183,6 +188,7 @@ extern "C" int rqamd_rqt_destroy(rqamd_rqt* h) {
     if (!h) return RQAMD_OK;
     for (auto& g : h->gexec) if (g) (void)hipGraphExecDestroy(g);
     for (auto e : h->prof.ev) (void)hipEventDestroy(e);
+    for (auto e : h->prof.ev_attn) (void)hipEventDestroy(e);
     delete h;
     return RQAMD_OK;
 }
@@ -421,7 +427,14 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
         AttnDecodeArgs at{};
         at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
         at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
+        GemmProfile& pfl = h->prof;
+        if (pfl.on) {
+            if (pfl.used_attn + 2 > pfl.ev_attn.size())
+                for (int i = 0; i < 2; ++i) { hipEvent_t e; RQ_HIP(hipEventCreate(&e)); pfl.ev_attn.push_back(e); }
+            RQ_HIP(hipEventRecord(pfl.ev_attn[pfl.used_attn], st));
+        }
         RQ_TRY(rq_launch_attn_decode(at, st));
+        if (pfl.on) { RQ_HIP(hipEventRecord(pfl.ev_attn[pfl.used_attn + 1], st)); pfl.used_attn += 2; }
     }
     int ns = 1;
     RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj));
@@ -648,7 +661,7 @@ extern "C" int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int6
     for (int d = 0; d < h->D; ++d) { k.tk[d] = top_k[d]; k.tp[d] = top_p[d]; k.cb[d] = codebooks[d]; }
     if (!h->gvalid || memcmp(&k, &h->gkey, sizeof(k)) != 0) { h->gvalid = false; h->gkey = k; }
     RQ_LAUNCH(set_rng_kernel, dim3(1), dim3(64), 0, st, h->rng, seed, offset);
-    h->prof.used = 0; h->prof.bytes = 0; h->prof.flops = 0;
+    h->prof.used = 0; h->prof.bytes = 0; h->prof.flops = 0; h->prof.used_attn = 0;
     int start_idx = start_h * h->cfg.W + start_w;
     if (start_idx < 0) start_idx = 0;
     RQ_TRY(run_all(h, c, partial, cond, start_idx, use_graph != 0, codes_out, st));
@@ -662,6 +675,14 @@ extern "C" int rqamd_rqt_sample(rqamd_rqt* h, const int64_t* partial, const int6
         }
         h->prof.ms_total = ms;
         h->prof.launches = (int64_t)(h->prof.used / 2);
+        ms = 0;
+        for (size_t i = 0; i + 1 < h->prof.used_attn; i += 2) {
+            float t = 0.f;
+            RQ_HIP(hipEventElapsedTime(&t, h->prof.ev_attn[i], h->prof.ev_attn[i + 1]));
+            ms += t;
+        }
+        h->prof.attn_ms_total = ms;
+        h->prof.attn_launches = (int64_t)(h->prof.used_attn / 2);
     }
     return RQAMD_OK;
 }
@@ -746,6 +767,12 @@ extern "C" int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream
 extern "C" int rqamd_rqt_set_profile(rqamd_rqt* h, int profile) {
     if (!h) return rq_fail(RQAMD_ERR_INVALID, "null handle");
     h->prof.on = profile != 0;
+    return RQAMD_OK;
+}
+extern "C" int rqamd_rqt_get_profile_attn(rqamd_rqt* h, double* ms, int64_t* launches) {
+    if (!h) return rq_fail(RQAMD_ERR_INVALID, "null handle");
+    if (ms) *ms = h->prof.attn_ms_total;
+    if (launches) *launches = h->prof.attn_launches;
     return RQAMD_OK;
 }
 extern "C" int rqamd_rqt_get_profile(rqamd_rqt* h, double* ms, int64_t* launches, double* bytes, double* flops) {

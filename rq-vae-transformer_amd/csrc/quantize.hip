@@ -216,9 +216,11 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
                 int oi = sRedI[w * QT_M + tid];
                 if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
-            // a row whose distances are all NaN / +inf (non-finite encoder output) never satisfies `d < best`: its index is still the
-            // 0x7fffffff seed.  torch.argmin returns 0 for such a row (first NaN / first of equal infinities); an unclamped seed
-            // would index the codebook ~2 TB out of bounds below.  (SPLIT: the combine kernel clamps after merging the splits.)
+            // a row without a single finite distance (NaN / inf in the encoder output) never satisfies `d < best`: its index is still
+            // the 0x7fffffff seed, which would index the codebook ~2 TB out of bounds below.  Such a row gets code 0 -- what
+            // torch.argmin returns when the distances are all NaN or all +inf (first NaN / first of equal infinities); for a row that
+            // mixes NaN and inf distances torch returns its first NaN instead: garbage in either case, but always a valid index.
+            // (SPLIT: the combine kernel clamps after merging the splits.)
             if (!SPLIT && (unsigned)ix >= (unsigned)K) ix = 0;
             if (SPLIT) {
                 if (v0 + tid < p.n_vec) {
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(512) void rq_split_combine_kernel(RqQuantArgs p) {
             const int oi = p.part_i[vec * p.n_split + s2];
             if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
         }
-        if ((unsigned)ix >= (unsigned)p.K[dep]) ix = 0;        // all-NaN / all-inf row: torch.argmin's answer (see rq_quantize_kernel)
+        if ((unsigned)ix >= (unsigned)p.K[dep]) ix = 0;        // no finite distance in the row (see rq_quantize_kernel)
         if (useg == 0) p.codes[vec * p.depth + dep] = (int64_t)ix;
     }
     const float* q = p.cb[dep] + (long)ix * D;

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RqamdError(RuntimeError):
@@ -72,6 +72,7 @@ _SIGS = {
     'rqamd_rqt_set_profile': (C.c_int, [C.c_void_p, C.c_int]),
     'rqamd_rqt_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                         C.POINTER(C.c_double)]),
+    'rqamd_rqt_get_profile_attn': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -105,6 +106,17 @@ def lib():
                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
         _lib = _bind(LIB_PATH)
     return _lib
+
+
+def kernel_source_hash(files=('gemm.h', 'gemm.hip')):
+    """sha256[:16] over kernel sources under csrc/: stamps measurements that were taken out of run (PMC traffic files under
+    profiles/) with the kernels they were taken on, so that bench.py can refuse a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(_PKG, 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(status):
@@ -522,4 +534,7 @@ class RqtEngine(_Engine):
     def get_profile(self):
         ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         check(lib().rqamd_rqt_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)))
-        return dict(gemm_ms_total=ms.value, gemm_launches=n.value, gemm_bytes=by.value, gemm_flops=fl.value)
+        ams, an = C.c_double(), C.c_int64()
+        check(lib().rqamd_rqt_get_profile_attn(self._h, C.byref(ams), C.byref(an)))
+        return dict(gemm_ms_total=ms.value, gemm_launches=n.value, gemm_bytes=by.value, gemm_flops=fl.value,
+                    attn_ms_total=ams.value, attn_launches=an.value)

@@ -16,7 +16,10 @@ for name, N, K, epi in shapes:
     ws = [torch.randn((N, K), device='cuda').to(torch.bfloat16) for _ in range(6)]
     bias = torch.randn((N,), device='cuda')
     out = None
+    if epi == 4 and not os.environ.get('RQAMD_NO_FUSE_RESID'):
+        # proj / fc2 as the engine launches them when K is not split: the fp32 residual stream updated in place by the epilogue
+        epi, out = 4 + 2048, torch.randn((M, N), device='cuda')
     for i in range(6):
-        out = _native.dbg_gemm(a, ws[i], None if epi == 4 else bias, epi, 0, 0, 0, out=out)
+        out = _native.dbg_gemm(a, ws[i], None if epi == 4 else bias, epi, 0, 0, 0 if epi < 2048 else 1, out=out)
     torch.cuda.synchronize()
-    print(name, M, N, K, 'algorithmic bytes', N * K * 2 + M * K * 2 + M * N * (4 if epi >= 3 else 2))
+    print(name, M, N, K, 'algorithmic bytes', N * K * 2 + M * K * 2 + M * N * (8 if epi >= 2048 else 4 if epi >= 3 else 2))

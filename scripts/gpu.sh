@@ -13,7 +13,7 @@
 export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
-TAG=${RQ_TAG:-r02}
+TAG=${RQ_TAG:-r03}
 mkdir -p gpurun_out
 
 stats_md() {   # $1 = rocprof output dir, $2 = markdown file

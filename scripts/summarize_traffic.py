@@ -24,12 +24,18 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     print(c, 'gemm dispatches:', len(per[c]))
 n = min(len(per['FETCH_SIZE']), len(per['WRITE_SIZE']))
 assert n % 6 == 0 and n >= 30, n
-shapes = [('qkv', 4608, 1536, 2, 4224), ('proj (split-K slabs)', 1536, 1536, 4, 4224), ('fc1', 6144, 1536, 2, 4224),
-          ('fc2 (split-K slabs)', 1536, 6144, 4, 4224), ('classifier', 16384, 1536, 4, 256)]
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rq-vae-transformer_amd'))
+from rqvae import _native  # noqa: E402
+fused = not os.environ.get('RQAMD_NO_FUSE_RESID')
+rb = 8 if fused else 4          # residual epilogue: fp32 stream read + written in place; slab epilogue: one fp32 slab written
+shapes = [('qkv', 4608, 1536, 2, 4224), ('proj (in-place residual epilogue)' if fused else 'proj (split-K slab)', 1536, 1536, rb, 4224),
+          ('fc1', 6144, 1536, 2, 4224), ('fc2 (in-place residual epilogue)' if fused else 'fc2 (split-K slab)', 1536, 6144, rb, 4224),
+          ('classifier', 16384, 1536, 4, 256)]
 out = {'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over scripts/gemm_traffic.py on MI355X; '
                  'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950: FETCH_SIZE counts half of wide coalesced reads, '
                  'MI355X_MICROARCH.md HBM section; Infinity-Cache hits are included in this fabric-side counter)',
-       'batch_rows': M, 'shapes': []}
+       'batch_rows': M, 'kernel_sources_sha16': _native.kernel_source_hash(), 'kernel_sources': 'csrc/gemm.h + csrc/gemm.hip', 'shapes': []}
 tot = totw = 0
 for i, (name, N, K, ob, w) in enumerate(shapes):
     s0 = 6 * i

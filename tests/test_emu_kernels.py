@@ -86,6 +86,23 @@ def test_emu_rq_quantize_codebook_split(nat):
     assert none is None and torch.equal(c2, codes)
 
 
+def test_emu_rq_quantize_non_finite_rows(nat):
+    """all-NaN / all-inf distance rows -> code 0 (torch.argmin's answer), never the 0x7fffffff seed; both launch forms."""
+    rng = np.random.default_rng(15)
+    for n_vec, K in ((200, 300), (70, 1100)):
+        cb = rng.standard_normal((K, 64), dtype=np.float32)
+        x = rng.standard_normal((n_vec, 64), dtype=np.float32)
+        good, _ = nat.rq_quantize(T(x), [T(cb)] * 3)
+        x[3, 7] = np.nan
+        x[11, :] = np.inf
+        codes, _ = nat.rq_quantize(T(x), [T(cb)] * 3)
+        codes = codes.numpy()
+        assert (codes[[3, 11]] == 0).all()
+        keep = np.ones(n_vec, bool)
+        keep[[3, 11]] = False
+        assert np.array_equal(codes[keep], good.numpy()[keep])
+
+
 def test_emu_rq_soft_codes(nat, golden):
     """RQBottleneck.get_soft_codes against the reference fixture: softmax(-d / temp) per depth and codes."""
     g, gs = golden('rq_small.npz'), golden('rq_soft.npz')

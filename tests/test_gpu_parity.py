@@ -73,6 +73,28 @@ def test_rq_quantize_ragged_unshared(nat):
     assert nat.rq_quantize(torch.zeros((0, 128), device=DEV), [G(c) for c in cbs])[0].shape == (0, 3)
 
 
+def test_rq_quantize_non_finite_rows(nat):
+    """A vector whose distances are all NaN or all +inf (non-finite encoder output) gets code 0 at every depth -- what
+    torch.argmin returns for such a row in the reference (quantizations.py:64-69) -- instead of the 0x7fffffff seed of the
+    running minimum, which indexed the codebook 2 TB out of bounds.  Finite rows of the same launch are
+    unaffected.  Both launch forms: all depths in one launch (many vectors) and the codebook split (few vectors)."""
+    rng = np.random.default_rng(15)
+    for n_vec, K in ((6400, 512), (70, 2048)):
+        cb = rng.standard_normal((K, 64), dtype=np.float32)
+        x = rng.standard_normal((n_vec, 64), dtype=np.float32)
+        good, _ = nat.rq_quantize(G(x), [G(cb)] * 3)
+        x[3, 7] = np.nan
+        x[11, :] = np.inf
+        codes, quants = nat.rq_quantize(G(x), [G(cb)] * 3)
+        torch.cuda.synchronize()
+        codes = N(codes)
+        assert (codes[[3, 11]] == 0).all()
+        keep = np.ones(n_vec, bool)
+        keep[[3, 11]] = False
+        assert np.array_equal(codes[keep], N(good)[keep])
+        assert int(codes.min()) >= 0 and int(codes.max()) < K
+
+
 def test_rq_quantize_properties_large(nat):
     """256 images x 64 vectors, K=16384: size-independent properties (the oracle would take minutes)."""
     gen = torch.Generator(device=DEV).manual_seed(3)
@@ -304,6 +326,37 @@ def test_rqt_sample_semantics(nat, golden):
     assert torch.equal(o1, o2)
 
 
+def test_rqt_sample_uncached_equals_cached_and_amp_warns(nat, golden):
+    """sample(cached=False) (transformers.py:352-356, the reference's own cross-check of its KV cache): every step recomputes
+    the logits of the whole code map from the codes so far; with the cached path's draw at each step the codes must come out
+    IDENTICAL -- i.e. the cache changes nothing, bit for bit.  amp=True warns once (bf16 is the only compute dtype)."""
+    import warnings
+    from rqvae.models.rqtransformer import RQTransformer
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    cond = G(g['cond'], torch.long)[:2].contiguous()
+    partial = torch.zeros((2, 4, 4, 4), dtype=torch.long, device=DEV)
+    for kw in (dict(top_k=5, top_p=0.9), dict(), dict(temperature=0.7, top_k=[50, 20, 10, 5], top_p=[0.95])):
+        torch.cuda.manual_seed_all(77)
+        a = ar.sample(partial, vae, cond=cond, **kw)
+        torch.cuda.manual_seed_all(77)
+        b = ar.sample(partial, vae, cond=cond, cached=False, **kw)
+        assert torch.equal(a, b), kw
+    part2 = a.clone()
+    part2[:, 1:] = 0
+    torch.cuda.manual_seed_all(3)
+    c1 = ar.sample(part2, vae, cond=cond, start_loc=(1, 0), top_k=5)
+    torch.cuda.manual_seed_all(3)
+    c2 = ar.sample(part2, vae, cond=cond, start_loc=(1, 0), top_k=5, cached=False)
+    assert torch.equal(c1, c2) and torch.equal(c1[:, :1], a[:, :1])
+    RQTransformer._amp_warned = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ar.sample(partial, vae, cond=cond, amp=True)
+        ar.sample(partial, vae, cond=cond, amp=True)
+    assert sum('bf16' in str(x.message) for x in w) == 1
+
+
 def test_rqt_sample_torch_multinomial_mode(nat, golden):
     """ar.sampler = 'torch' (SURVEY §7 step 6): the sampling loop driven from the host, the draw by torch.multinomial on the
     filtered probabilities -- the reference's own call (rqvae/utils/utils.py:112).  Reproducible under the torch seed; every drawn
@@ -468,18 +521,19 @@ def test_vae_full_size_golden(nat, golden, tag, cfg):
 
 
 def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
-    """At 32 x 32 the 3x3 layers run as implicit GEMMs for a few images and through the halo kernel (fused GroupNorm, epilogue
-    statistics) once the batch fills the chip (engine_vae.hip: halo_here).  RQAMD_HALO_MIN_WGS=0 forces the large-batch choice on
-    one image: same golden tolerance as test_vae_full_size_golden, and close to the default path."""
+    """At 32 x 32 the 3x3 layers run through the halo kernel (fused GroupNorm, epilogue statistics) like the >= 64^2 ones, for
+    every batch size (engine_vae.hip: halo_here -- the choice is a function of the layer only).  RQAMD_HALO_LOWRES=0 selects
+    the implicit-GEMM form there (the round-2 small-batch choice): same golden tolerance, close to the default path; and a
+    batch of 64 copies decodes to the bits of the single-image call."""
     g = golden('vae_imagenet.npz')
     ref = g['decode_code'].astype(np.float32)
     vae0, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
     d0 = N(vae0.decode_code(G(g['codes'], torch.long)))
-    monkeypatch.setenv('RQAMD_HALO_MIN_WGS', '0')
+    monkeypatch.setenv('RQAMD_HALO_LOWRES', '0')
     vae1, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
     d1 = N(vae1.decode_code(G(g['codes'], torch.long)))
     err = np.abs(d1 - ref)
-    print('vae imagenet decode_code, halo kernel at 32^2: max err %.4f mean %.5f; vs default path max %.4f mean %.5f'
+    print('vae imagenet decode_code, implicit GEMM at 32^2: max err %.4f mean %.5f; vs default path max %.4f mean %.5f'
           % (err.max(), err.mean(), np.abs(d1 - d0).max(), np.abs(d1 - d0).mean()))
     assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
     assert np.abs(d1 - d0).mean() < 0.01
@@ -487,33 +541,76 @@ def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
     rng.integers(0, C.VAE_IMAGENET[0]['n_embed'], (1, 8, 8, 4))
     x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
     e = np.abs(N(vae1.encode(G(x))) - g['z_e'])
-    print('vae imagenet encode, halo kernel at 32^2: max err %.4f mean %.5f' % (e.max(), e.mean()))
+    print('vae imagenet encode, implicit GEMM at 32^2: max err %.4f mean %.5f' % (e.max(), e.mean()))
     assert e.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and e.mean() < 0.01
-    # the default engine reaches the same choice by itself once the batch fills the chip: 64 copies of the golden codes
     codes64 = G(g['codes'], torch.long).repeat(64, 1, 1, 1).contiguous()
     d64 = N(vae0.decode_code(codes64))
-    err = np.abs(d64 - ref[:1])
-    print('vae imagenet decode_code at batch 64 (default rule): max err %.4f mean %.5f' % (err.max(), err.mean()))
-    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
-    assert np.abs(d64 - d64[:1]).max() == 0.0                  # every copy decodes to the same bits
+    assert np.array_equal(d64, np.repeat(d0[:1], 64, axis=0))   # every copy decodes to the bits of the one-image call
 
 
 def test_vae_batch_invariance_and_chunking(nat, golden):
+    """An image's result does not depend on the batch, chunk or launch form it was computed in -- bit for bit: calls of <= 8
+    images divide the K loop of the low-resolution convs over workgroups (and replay a captured graph up to 4 images), larger
+    ones fold the same K chunks inside one workgroup (GemmArgs::vsplit); every other kernel choice depends on the layer only."""
     g = golden('vae_tiny.npz')
     vae, _, _, _ = _models(C.VAE_TINY, None, int(g['seed']), 0)
     rng = np.random.default_rng(2)
-    codes = G(rng.integers(0, 500, (133, 8, 8, 4)), torch.long)     # 133 > chunk of 128: two chunks
+    codes = G(rng.integers(0, 500, (133, 8, 8, 4)), torch.long)     # 133 > chunk of 128: a chunk of 128 + a tail of 5
     full = vae.decode_code(codes)
-    one = torch.cat([vae.decode_code(codes[i:i + 1]) for i in (0, 127, 128, 132)])
-    # rows 128..132 sit in a chunk of 5: small-batch mode (<= 8 images: split-K low-resolution convs, graph replay), the same
-    # mode as a single-image call -> bit-identical.  Rows 0..127 sit in a full chunk (no split-K): same arithmetic up to the
-    # fp32 summation order of those convs, i.e. equal up to a bf16 rounding flip here and there.
-    assert torch.equal(full[[128, 132]], one[2:])
-    assert float((full[[0, 127]] - one[:2]).abs().max()) < 0.03
-    full2 = vae.decode_code(codes[:128].contiguous())
-    assert torch.equal(full[:128], full2)                    # chunk placement does not matter
-    x = G(np.clip(rng.standard_normal((5, 3, 16, 16), dtype=np.float32), -1, 1))
-    assert torch.equal(vae.encode(x)[3:4], vae.encode(x[3:4].contiguous()))
+    one = torch.cat([vae.decode_code(codes[i:i + 1].clone()) for i in (0, 127, 128, 132)])      # clones: cold one-image calls
+    assert torch.equal(full[[0, 127, 128, 132]], one)
+    assert torch.equal(full[:128], vae.decode_code(codes[:128].contiguous()))
+    assert torch.equal(full[3:12], vae.decode_code(codes[3:12].contiguous()))
+    assert torch.equal(full[100:108], vae.decode_code(codes[100:108].contiguous()))
+    x = G(np.clip(rng.standard_normal((11, 3, 16, 16), dtype=np.float32), -1, 1))
+    z = vae.encode(x)
+    for lo, hi in ((3, 4), (0, 8), (2, 11)):
+        assert torch.equal(z[lo:hi], vae.encode(x[lo:hi].contiguous()))
+
+
+def test_vae_batch_invariance_full_size(nat, golden):
+    """The same property on the released ImageNet shape (256x256, every kernel family of the decoder / encoder in play)."""
+    g = golden('vae_imagenet.npz')
+    vae, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    rng = np.random.default_rng(3)
+    codes = G(rng.integers(0, 16384, (70, 8, 8, 4)), torch.long)
+    full = vae.decode_code(codes)                                               # 70 images: virtual split-K, eager
+    for lo, hi in ((0, 1), (69, 70), (5, 8), (20, 28), (30, 39)):               # graph replay / split-K slabs / virtual split-K
+        assert torch.equal(full[lo:hi], vae.decode_code(codes[lo:hi].clone())), (lo, hi)
+    x = G(np.clip(rng.standard_normal((10, 3, 256, 256), dtype=np.float32), -1, 1))
+    z = vae.encode(x)
+    for lo, hi in ((0, 1), (4, 7), (1, 9)):
+        assert torch.equal(z[lo:hi], vae.encode(x[lo:hi].contiguous())), (lo, hi)
+    assert torch.equal(vae.get_codes(x)[2:3], vae.get_codes(x[2:3].contiguous()))
+
+
+def test_vae_decode_code_read_ahead(nat, golden):
+    """The reference drivers decode ONE image per call out of the batch they sampled (measure_throughput/__main__.py:297-299:
+    torch.cat([decode_code(chunk) for chunk in codes.chunk(B)]); main_sampling_fid.py:223: decode_code(pixels[i:i+1])).  Those
+    calls are served from batched decodes of the rows that follow (RQVAE._ahead): each row must equal a COLD one-image
+    decode_code of the same codes bit for bit, with a handful of engine calls instead of one per image."""
+    g = golden('vae_imagenet.npz')
+    vae, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    rng = np.random.default_rng(8)
+    B = 150
+    codes = G(rng.integers(0, 16384, (B, 8, 8, 4)), torch.long)
+    st = vae._ahead
+    pixels = torch.cat([vae.decode_code(chunk) for chunk in codes.chunk(B)], dim=0)          # measure_throughput's loop
+    assert st.engine_calls == 4 and st.hits == B - 4, (st.engine_calls, st.hits)             # 1 cold, then 8, 64 and the last 77
+    for i in (0, 1, 8, 9, 72, 73, 74, 149):
+        assert torch.equal(pixels[i:i + 1], vae.decode_code(codes[i:i + 1].clone())), i      # cold call: not a view, no read-ahead
+    assert torch.equal(pixels, vae.decode_code(codes))                                       # and the plain batched call
+    loop = torch.cat([vae.decode_code(codes[i:i + 1]) for i in range(codes.size(0))], dim=0) # main_sampling_fid's loop
+    assert torch.equal(loop, pixels)
+    # the next batch of the driver loop: a new tensor, possibly at the recycled address of the old one
+    del codes
+    codes2 = G(rng.integers(0, 16384, (B, 8, 8, 4)), torch.long)
+    first = vae.decode_code(codes2[0:1])
+    assert torch.equal(first, vae.decode_code(codes2[0:1].clone()))
+    # an in-place edit of the codes is seen
+    vae.decode_code(codes2[1:2])
+    codes2[5] = codes2[0]
+    assert torch.equal(vae.decode_code(codes2[5:6]), first)
 
 
 def test_vae_per_image_driver_loops(nat, golden):
@@ -526,9 +623,9 @@ def test_vae_per_image_driver_loops(nat, golden):
     rng = np.random.default_rng(7)
     codes = G(rng.integers(0, 16384, (6, 8, 8, 4)), torch.long)
     full = vae.decode_code(codes)                                              # eager (6 > 4)
-    loop = torch.cat([vae.decode_code(codes[i:i + 1]) for i in range(6)], dim=0)   # graph replays
+    loop = torch.cat([vae.decode_code(codes[i:i + 1].clone()) for i in range(6)], dim=0)   # graph replays (cold calls)
     assert torch.equal(full, loop)
-    pair = torch.cat([vae.decode_code(codes[i:i + 2]) for i in range(0, 6, 2)], dim=0)
+    pair = torch.cat([vae.decode_code(codes[i:i + 2].clone()) for i in range(0, 6, 2)], dim=0)
     assert torch.equal(full, pair)
     x = G(np.clip(rng.standard_normal((5, 3, 256, 256), dtype=np.float32), -1, 1))
     out_b, loss_b, code_b = vae(x)
@@ -605,11 +702,11 @@ def test_conv_kernels_vs_torch(nat):
 
 
 def test_gemm_residual_epilogue(nat):
-    """Decode-step proj / fc2 at the benchmark's row count class: the in-place residual epilogue (epi 4 + 2048: out = (out + a w^T) + bias)
+    """Decode-step proj / fc2 at the benchmark's row counts (incl. the timed M = 10752): the in-place residual epilogue (epi 4 + 2048: out = (out + a w^T) + bias)
     of the 256 x 256 kernel gives the bits of the slab epilogue followed by the two additions resid_ln makes, on every launch, and the
     engine's own tile choice agrees with it to fp32 rounding."""
     g = torch.Generator(device=DEV).manual_seed(5)
-    for (M, N, K) in ((2304, 1536, 1536), (2050, 1536, 6144)):
+    for (M, N, K) in ((2304, 1536, 1536), (2050, 1536, 6144), (10752, 1536, 1536), (10752, 1536, 6144)):     # 10752 = bench.py's rows
         a = torch.randn((M, K), device=DEV, generator=g).to(torch.bfloat16)
         w = (0.05 * torch.randn((N, K), device=DEV, generator=g)).to(torch.bfloat16)
         bias = torch.randn((N,), device=DEV, generator=g)

@@ -132,3 +132,56 @@ def test_rqt_in1400m_through_the_benchmarked_kernels(golden):
     assert worst < 0.08 and mean < 0.012
     del out, ar
     torch.cuda.empty_cache()
+
+
+def test_rqt_in1400m_sample_through_the_benchmarked_kernels(golden):
+    """The timed configuration end to end: RQTransformer.sample on the full 1.4B model with bench.py's
+    sampling settings (top-k 1024 / top-p 0.95), kernel selection seeing the bench batch (2050 rows x 5 = 10250: 256 x 256
+    eight-phase GEMMs with the in-place residual epilogue, large-batch attention / LayerNorm / sampler variants):
+      * captured hipGraphs == eager launches, codes in range, seed-reproducible;
+      * rows of one class are independent draws (different Philox rows: different images);
+      * every sampled code has non-zero filtered probability under the teacher-forced logits of the same codes -- the logits
+        path whose values are pinned to the REFERENCE's in test_rqt_in1400m_through_the_benchmarked_kernels -- at every one of
+        the 256 steps, checked for the first / a middle / the last rows of the batch."""
+    from rqvae import _native
+    g = golden('rqt_in1400m.npz')
+    cfg = C.RQT_IN_1400M
+    ar = _load(cfg, int(g['seed']))
+    V, D = cfg['vocab_size'], cfg['block_size'][2]
+    cb = np.random.default_rng(int(g['cb_seed'])).standard_normal((V, 256), dtype=np.float32)
+    aux = Aux(cb, D)
+    B = 2050
+    cond = G(np.tile(g['cond'], (B // 2, 1)), torch.long)
+    part = torch.zeros((B, 8, 8, D), dtype=torch.long, device=DEV)
+    _native.dbg_set_row_scale(5)
+    try:
+        res = []
+        for graph in (True, False, True):
+            ar.use_graph = graph
+            torch.cuda.manual_seed_all(91)
+            res.append(ar.sample(part, aux, cond=cond, top_k=1024, top_p=0.95))
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+        out = res[0]
+        assert int(out.min()) >= 0 and int(out.max()) < V
+        assert not torch.equal(out[0], out[2])                    # same class, different Philox row: different images
+        rows = [0, 1, 1024, 1025, 2048, 2049]
+        sub = out[rows].contiguous()
+        logits = ar(sub, aux, cond=cond[rows].contiguous())       # teacher-forced, 6 rows x 5 = 30 rows: the small-batch kernels
+        big = ar(out, aux, cond=cond)                              # ... and through the bench kernels
+    finally:
+        _native.dbg_set_row_scale(1)
+    same = big[rows].cpu().numpy()                            # the logits the draws were made from (same kernels, same batch)
+    worst = float(np.abs(same - logits.cpu().numpy()).max())
+    print(f'rqt in1400m sample: teacher-forced logits of the sampled codes, bench kernels vs small-batch kernels: max diff {worst:.4f}')
+    assert worst < 0.05
+    zero = 0
+    for h in range(8):
+        for w in range(8):
+            for d in range(D):
+                pr = oracle.filtered_probs(same[:, h, w, d], 1.0, 1024, 0.95)
+                sel = pr[np.arange(len(rows)), sub[:, h, w, d].cpu().numpy()]
+                zero += int((sel <= 0).sum())
+    print(f'rqt in1400m sample: {zero} of {len(rows) * 64 * D} drawn codes outside the filtered support of their step\'s logits')
+    assert zero == 0
+    del big, ar
+    torch.cuda.empty_cache()
