@@ -33,21 +33,23 @@ def _plain(cfg):
     return out
 
 
-class _DecodeAhead:
-    """Speculative batched decode behind per-row ``decode_code`` calls.
+class _ReadAhead:
+    """Speculative batched execution behind per-row calls on views of one batch.
 
-    Every caller in the reference decodes ONE image per call out of a batch of codes it already holds:
+    Every caller in the reference hands the stage-1 model ONE image per call out of a batch it already holds:
     ``torch.cat([model_aux.decode_code(chunk) for chunk in codes.chunk(batch_size)])`` (measure_throughput/__main__.py:297-299),
     ``torch.cat([model_vqvae.decode_code(pixels[i:i+1]) for i in range(pixels.size(0))])`` (main_sampling_fid.py:223,
-    main_sampling_txt2img.py).  A single 256x256 image cannot fill 256 CUs (2.0 ms per image against 0.30 ms inside a batch), but
-    the argument of such a call is a VIEW of the whole batch (``code._base``), so the rows the loop is about to ask for are
-    known: when a call asks for the row range that directly follows the previous call's on the same base tensor, the engine
-    decodes a window of the following rows in one batched call (1 row cold, then 8, 64, 512 ...: read-ahead, so a caller that
-    wants a single image of a large batch never pays for more than its own) and the next calls are handed row views of that
-    result.  This changes no value: RQVAE.decode is batch-invariant bit for bit (csrc/engine_vae.hip: every kernel choice and
-    summation order is a function of the layer, not of the batch), and a window is served only while the base tensor object,
-    its storage, its version counter, the decoder-side weights and the window's own version counter are what they were when
-    it was decoded (tests/test_gpu_parity.py::test_vae_decode_code_read_ahead).  RQAMD_DECODE_AHEAD=<max rows> (0 = off)."""
+    main_sampling_txt2img.py), ``stage1_model(imgs[i:i+1])[0] for i in range(imgs.shape[0])`` (rqvae/metrics/fid.py:167-169).
+    A single 256x256 image cannot fill 256 CUs (2.0 ms per decoded image against 0.30 ms inside a batch), but the argument of
+    such a call is a VIEW of the whole batch (``arg._base``), so the rows the loop is about to ask for are known: when a call
+    asks for the row range that directly follows the previous call's on the same base tensor, the engine runs a window of the
+    following rows in one batched call (1 row cold, then 8, 64, 512 ...: read-ahead, so a caller that wants a single image of
+    a large batch never pays for more than its own) and the next calls are handed row views of that result.  This changes no
+    value: RQVAE.encode / decode and the quantiser are batch-invariant bit for bit (csrc/engine_vae.hip: every kernel choice
+    and summation order is a function of the layer, not of the batch), and a window is served only while the base tensor
+    object, its storage, its version counter, the weights involved and the window's own version counters are what they were
+    when it was computed (tests/test_gpu_parity.py::test_vae_decode_code_read_ahead, ::test_vae_forward_read_ahead).
+    RQAMD_DECODE_AHEAD=<max rows per window> (0 = off)."""
     RAMP = 8
 
     def __init__(self):
@@ -56,30 +58,63 @@ class _DecodeAhead:
 
     def clear(self):
         self.base_ref = None          # weakref to the tensor object the served views are views of
-        self.key = None               # (storage pointer, version, shape) of that tensor + signature of the decoder-side weights
-        self.lo = self.hi = 0         # rows [lo, hi) of the base are held in self.pixels
-        self.pixels = None
-        self.pix_version = 0
+        self.key = None               # (storage pointer, version, shape) of that tensor + signature of the weights involved
+        self.lo = self.hi = 0         # rows [lo, hi) of the base are held in self.results
+        self.results = None           # tuple of tensors, one row per held base row
+        self.versions = None
         self.next_row = -1            # the row a sequential caller asks for next
-        self.window = 0               # rows decoded by the last engine call of this run
+        self.window = 0               # rows computed by the last engine call of this run
         self.event = None
         self.stream = None
         self.hits = self.engine_calls = 0
 
     @staticmethod
-    def rows_of(code):
-        """(base, first row, rows) when `code` is a contiguous row range of a larger contiguous batch of the same trailing
+    def rows_of(arg):
+        """(base, first row, rows) when `arg` is a contiguous row range of a larger contiguous batch of the same trailing
         shape, else None."""
-        base = code._base
-        if base is None or base.dim() != code.dim() or code.dim() < 2 or base.shape[1:] != code.shape[1:]:
+        base = arg._base
+        if base is None or base.dim() != arg.dim() or arg.dim() < 2 or base.shape[1:] != arg.shape[1:]:
             return None
-        if base.shape[0] <= code.shape[0] or code.shape[0] < 1 or not base.is_contiguous() or not code.is_contiguous():
+        if base.shape[0] <= arg.shape[0] or arg.shape[0] < 1 or not base.is_contiguous() or not arg.is_contiguous():
             return None
-        row = code[0].numel()
-        off = code.storage_offset() - base.storage_offset()
-        if row == 0 or off < 0 or off % row or off // row + code.shape[0] > base.shape[0]:
+        row = arg[0].numel()
+        off = arg.storage_offset() - base.storage_offset()
+        if row == 0 or off < 0 or off % row or off // row + arg.shape[0] > base.shape[0]:
             return None
-        return base, off // row, code.shape[0]
+        return base, off // row, arg.shape[0]
+
+    def serve(self, arg, weights_signature, compute):
+        """Rows of compute(window of arg's base) for the rows `arg` views, or None when `arg` is not a row view of a larger
+        batch (the caller then runs the plain path).  compute(t) -> tuple of tensors with t.shape[0] rows each."""
+        rows = self.rows_of(arg) if self.max_rows > 0 else None
+        if rows is None:
+            return None
+        base, i0, n = rows
+        key = (base.data_ptr(), base._version, tuple(base.shape), base.dtype, weights_signature())
+        same = self.base_ref is not None and self.base_ref() is base and self.key == key
+        if same and self.results is not None and self.lo <= i0 and i0 + n <= self.hi and \
+                all(t._version == v for t, v in zip(self.results, self.versions)):
+            if arg.is_cuda:
+                cur = torch.cuda.current_stream(arg.device)
+                if cur != self.stream:
+                    cur.wait_event(self.event)
+            self.next_row = i0 + n
+            self.hits += 1
+            return tuple(t[i0 - self.lo:i0 - self.lo + n] for t in self.results)
+        window = n
+        if same and i0 == self.next_row:               # a sequential run: read ahead, RAMP x what the last engine call computed
+            window = max(n, min(self.window * self.RAMP, self.max_rows, base.shape[0] - i0))
+        results = tuple(compute(base[i0:i0 + window]))
+        self.base_ref, self.key = weakref.ref(base), key
+        self.lo, self.hi, self.results = i0, i0 + window, results
+        self.versions = tuple(t._version for t in results)
+        self.next_row, self.window = i0 + n, window
+        if arg.is_cuda:
+            self.stream = torch.cuda.current_stream(arg.device)
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+        self.engine_calls += 1
+        return tuple(t[:n] for t in results)
 
 
 class RQVAE(Stage1Model):
@@ -114,7 +149,8 @@ class RQVAE(Stage1Model):
         self._engine = None
         self._engine_sig = None
         self._side = SideStream()
-        self._ahead = _DecodeAhead()
+        self._ahead = _ReadAhead()             # decode_code on row views of a code batch
+        self._ahead_fwd = _ReadAhead()         # forward on row views of an image batch
 
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
@@ -132,11 +168,34 @@ class RQVAE(Stage1Model):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, xs):
-        """rqvae.py:74-78"""
-        z_e = self.encode(xs)
-        z_q, quant_loss, code = self.quantizer(z_e)
-        out = self.decode(z_q)
+        """rqvae.py:74-78.  The rFID loop calls this on one image at a time, ``stage1_model(imgs[i:i+1])[0]``
+        (rqvae/metrics/fid.py:167-169): such row views of an image batch are served from batched passes over the rows that
+        follow (see _ReadAhead), each row's (out, quant_loss, code) being what the one-image call returns, bit for bit."""
+        served = None
+        if not torch.is_grad_enabled() or not xs.requires_grad:
+            served = self._ahead_fwd.serve(xs, lambda: signature(self), self._forward_window)
+        if served is None:
+            z_e = self.encode(xs)
+            z_q, quant_loss, code = self.quantizer(z_e)
+            out = self.decode(z_q)
+            return out, quant_loss, code
+        out, code, x_code = served[0], served[1], served[2]
+        # the commitment loss of THIS call's rows (quantizations.py:283-295), from row views shaped like the one-image call's tensors
+        quant_loss = self.quantizer.compute_commitment_loss(x_code, list(served[3:]))
         return out, quant_loss, code
+
+    @torch.no_grad()
+    def _forward_window(self, xs):
+        """forward() over a window of images, keeping what a per-row commitment loss needs: (out, code, x in code shape,
+        quant_list...).  Same operations per row as the one-image call (quantizations.py:273-281)."""
+        q = self.quantizer
+        z_e = self.encode(xs)
+        x_code = q.to_code_shape(z_e)
+        quant_list, code = q.quantize(x_code)
+        z_q = q.to_latent_shape(quant_list[-1])
+        z_q = z_e + (z_q - z_e).detach()
+        out = self.decode(z_q)
+        return (out, code, x_code) + tuple(quant_list)
 
     @torch.no_grad()
     def encode(self, x):
@@ -168,43 +227,19 @@ class RQVAE(Stage1Model):
     @torch.no_grad()
     def decode_code(self, code):
         """rqvae.py:105-109.  Per-row calls on views of one code batch -- the way every driver of the reference calls this --
-        are served from batched decodes of the rows that follow (see _DecodeAhead); values are identical either way."""
-        st = self._ahead
-        rows = st.rows_of(code) if st.max_rows > 0 else None
-        if rows is None:
-            return self._decode_code_now(code)
-        base, i0, n = rows
-        key = (base.data_ptr(), base._version, tuple(base.shape), signature(self.decoder, self.post_quant_conv, self.quantizer))
-        same = st.base_ref is not None and st.base_ref() is base and st.key == key
-        if same and st.pixels is not None and st.lo <= i0 and i0 + n <= st.hi and st.pixels._version == st.pix_version:
-            if code.is_cuda:
-                cur = torch.cuda.current_stream(code.device)
-                if cur != st.stream:
-                    cur.wait_event(st.event)
-            st.next_row = i0 + n
-            st.hits += 1
-            return st.pixels[i0 - st.lo:i0 - st.lo + n]
-        window = n
-        if same and i0 == st.next_row:                 # a sequential run: read ahead, RAMP x what the last engine call decoded
-            window = max(n, min(st.window * st.RAMP, st.max_rows, base.shape[0] - i0))
-        pixels = self._decode_code_now(base[i0:i0 + window])
-        st.base_ref, st.key = weakref.ref(base), key
-        st.lo, st.hi, st.pixels, st.pix_version = i0, i0 + window, pixels, pixels._version
-        st.next_row, st.window = i0 + n, window
-        if code.is_cuda:
-            st.stream = torch.cuda.current_stream(code.device)
-            st.event = torch.cuda.Event()
-            st.event.record(st.stream)
-        st.engine_calls += 1
-        return pixels[:n]
+        are served from batched decodes of the rows that follow (see _ReadAhead); values are identical either way."""
+        served = self._ahead.serve(code, lambda: signature(self.decoder, self.post_quant_conv, self.quantizer),
+                                   lambda window: (self._decode_code_now(window),))
+        return self._decode_code_now(code) if served is None else served[0]
 
     def _decode_code_now(self, code):
         z_q = self.quantizer.embed_code(code)
         return self.decode(z_q)
 
     def clear_decode_cache(self):
-        """Drop the read-ahead window held for per-row decode_code calls (up to RQAMD_DECODE_AHEAD images of pixels)."""
+        """Drop the read-ahead windows held for per-row decode_code / forward calls (up to RQAMD_DECODE_AHEAD images each)."""
         self._ahead.clear()
+        self._ahead_fwd.clear()
 
     def get_recon_imgs(self, xs_real, xs_recon):
         """rqvae.py:111-117"""

@@ -466,6 +466,18 @@ def test_emu_vae_decode_code_read_ahead(nat, golden):
     for i in range(3):
         vae.decode_code(codes[i:i + 1])
     assert st.hits == hits
+    # the rFID loop (rqvae/metrics/fid.py:167-169): stage1_model(imgs[i:i+1])[0] on row views of an image batch
+    x = T(np.clip(rng.standard_normal((11, 3, 16, 16), dtype=np.float32), -1, 1))
+    cold_f = [vae(x[i:i + 1].clone()) for i in range(11)]
+    sf = vae._ahead_fwd
+    assert sf.engine_calls == 0
+    rows_f = [vae(x[i:i + 1]) for i in range(11)]
+    assert sf.engine_calls == 3 and sf.hits == 8                                    # 1 cold, 8 ahead, the last 2
+    for (o, l, c), (o0, l0, c0) in zip(rows_f, cold_f):
+        assert torch.equal(o, o0) and torch.equal(c, c0) and torch.equal(l, l0) and l.shape == l0.shape
+    full = vae(x)                                                                    # the plain batched call: rows agree, loss is the batch mean
+    assert torch.equal(full[0], torch.cat([r[0] for r in rows_f])) and torch.equal(full[2], torch.cat([r[2] for r in rows_f]))
+    np.testing.assert_allclose(float(full[1]), float(torch.stack([r[1] for r in rows_f]).mean()), rtol=1e-5)
 
 
 def test_emu_gemm_tiles_and_lds_dma(nat):

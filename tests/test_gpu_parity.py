@@ -613,6 +613,27 @@ def test_vae_decode_code_read_ahead(nat, golden):
     assert torch.equal(vae.decode_code(codes2[5:6]), first)
 
 
+def test_vae_forward_read_ahead(nat, golden):
+    """The rFID loop (rqvae/metrics/fid.py:167-169): ``stage1_model(imgs[i:i+1])[0] for i in range(imgs.shape[0])``.  Row views of
+    an image batch are served from batched encode -> quantise -> decode passes over the rows that follow; (out, quant_loss, code)
+    of every row equal the cold one-image call bit for bit."""
+    g = golden('vae_imagenet.npz')
+    vae, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    rng = np.random.default_rng(9)
+    n = 20
+    xs = G(np.clip(rng.standard_normal((n, 3, 256, 256), dtype=np.float32), 0, 1))
+    imgs = 2. * xs - 1.
+    st = vae._ahead_fwd
+    recon = [vae(imgs[i:i + 1]) for i in range(imgs.shape[0])]
+    assert st.engine_calls == 3 and st.hits == n - 3, (st.engine_calls, st.hits)      # 1 cold, 8 ahead, the last 11
+    for i in (0, 1, 2, 8, 9, 10, 19):
+        o, l, c = vae(imgs[i:i + 1].clone())                                          # cold: not a view
+        assert torch.equal(recon[i][0], o) and torch.equal(recon[i][2], c) and torch.equal(recon[i][1], l), i
+    out_b, loss_b, code_b = vae(imgs)
+    assert torch.equal(out_b, torch.cat([r[0] for r in recon])) and torch.equal(code_b, torch.cat([r[2] for r in recon]))
+    assert abs(float(loss_b) - float(torch.stack([r[1] for r in recon]).mean())) < 1e-5 * float(loss_b) + 1e-9
+
+
 def test_vae_per_image_driver_loops(nat, golden):
     """What the unchanged drivers do with the stage-1 model: decode ONE image per call and concatenate
     (measure_throughput/__main__.py:297-299, main_sampling_fid.py:223), and the rFID loop's `stage1_model(img)[0]` on one
