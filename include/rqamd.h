@@ -61,6 +61,22 @@ int rqamd_rq_soft_codes(const float* x, const float* const* codebooks, const flo
 /* rqamd_rq_code_norms <- the codebook_t.pow(2).sum(0) term of compute_distances (quantizations.py:51-52). */
 int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream);
 
+/* ---- EMA codebook update (stage-1 training; VQEmbedding._update_buffers / _update_embedding, quantizations.py:80-129) ----
+ * rqamd_rq_ema_accumulate <- :85-99: count_out[k] = number of vectors whose nearest code is k, sum_out[k][:] = their sum (the
+ *   reference's one_hot.sum(1) and one_hot @ vectors), x (n_vec, dim) fp32, idx (n_vec) int64, added in ascending vector order
+ *   (deterministic; no (n_embed x n_vec) one-hot matrix).  The caller all-reduces both over the ranks (:101-103) before
+ * rqamd_rq_ema_update <- :105-118: cluster_size_ema = decay * cluster_size_ema + (1 - decay) * count, embed_ema likewise with sum;
+ *   restart_vectors (n_embed, dim) fp32 or NULL: the dead-code restart with the caller's random vectors (usage = cluster_size_ema
+ *   >= 1; unused codes take the random vector and cluster size 1).  In place.
+ * rqamd_rq_ema_normalize <- :120-129: weight_out[k][:] = embed_ema[k][:] / (n (cluster_size_ema[k] + eps) / (n + n_embed eps)),
+ *   n = *n_total, a device scalar holding sum(cluster_size_ema) (computed by the caller). */
+int rqamd_rq_ema_accumulate(const float* x, const int64_t* idx, int64_t n_vec, int dim, int n_embed, float* count_out,
+                            float* sum_out, void* stream);
+int rqamd_rq_ema_update(float* cluster_size_ema, float* embed_ema, const float* count, const float* sum,
+                        const float* restart_vectors, int n_embed, int dim, float decay, void* stream);
+int rqamd_rq_ema_normalize(const float* cluster_size_ema, const float* embed_ema, const float* n_total, int n_embed, int dim,
+                           float eps, float* weight_out, void* stream);
+
 /* rqamd_rq_embed <- RQBottleneck.embed_code :297-311 (mode 0: sum over depth),
  * embed_code_with_depth :313-334 (mode 1: (n_vec, depth, dim)), and the depth-cumsum the sampler
  * feeds to head_mlp (transformers.py:157-160; mode 2).  codes (n_vec, depth) int64; out fp32.

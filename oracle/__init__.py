@@ -15,7 +15,7 @@ build container by ``tests/golden/make_golden.py`` (fixtures committed under
 from . import backend  # noqa: F401
 from .weights import make_params, rqvae_param_shapes, rqt_param_shapes  # noqa: F401
 from .rq import (compute_distances, rq_quantize, rq_embed_code,  # noqa: F401
-                 rq_embed_code_with_depth, rq_quantize_margins, rq_soft_codes)
+                 rq_embed_code_with_depth, rq_quantize_margins, rq_soft_codes, vq_ema_step, rq_quantize_train, ema_restart_candidates)
 from .sampler import top_k_logits, top_p_probs, filtered_probs  # noqa: F401
 from .transformer import RQTransformerOracle  # noqa: F401
 from .vae import RQVAEOracle  # noqa: F401

@@ -102,3 +102,61 @@ def rq_soft_codes(x, codebooks, temp=1.0):
         r = r - cb[k]
     soft = np.stack(softs, 1).reshape(*lead, len(codebooks), -1)
     return soft, np.stack(codes, 1).reshape(*lead, len(codebooks)).astype(np.int64)
+
+
+def vq_ema_step(weight, cluster_size_ema, embed_ema, vectors, decay=0.99, eps=1e-5, restart_vectors=None):
+    """One train-mode VQEmbedding.forward (quantizations.py:131-142) on `vectors` (N, D): nearest codes with the CURRENT
+    weights (:64-69), _update_buffers (:80-118: per-code counts and vector sums, EMA of both, dead-code restart from
+    `restart_vectors` (n_embed, D) -- the reference draws them with torch.rand_like / torch.randperm, :70-77,109-111 -- or
+    None for restart_unused_codes=False), embeds from the weights BEFORE the update (:138), _update_embedding (:120-129).
+    weight (K, D) without the padding row.  Returns (embeds, codes, new weight, new cluster_size_ema, new embed_ema)."""
+    w = np.asarray(weight, np.float32)
+    K, D = w.shape
+    v = np.asarray(vectors, np.float32).reshape(-1, D)
+    codes = compute_distances(v, w).argmin(-1)
+    count = np.bincount(codes, minlength=K).astype(np.float32)
+    vsum = np.zeros((K, D), np.float32)
+    np.add.at(vsum, codes, v)
+    cs = (np.asarray(cluster_size_ema, np.float32) * np.float32(decay) + np.float32(1 - decay) * count).astype(np.float32)
+    ee = (np.asarray(embed_ema, np.float32) * np.float32(decay) + np.float32(1 - decay) * vsum).astype(np.float32)
+    if restart_vectors is not None:
+        usage = (cs >= 1).astype(np.float32)
+        ee = ee * usage[:, None] + np.asarray(restart_vectors, np.float32) * (1 - usage[:, None])
+        cs = cs * usage + (1 - usage)
+    embeds = w[codes]
+    n = cs.sum(dtype=np.float32)
+    norm = n * (cs + np.float32(eps)) / (n + np.float32(K * eps))
+    return embeds, codes.astype(np.int64), (ee / norm[:, None]).astype(np.float32), cs.astype(np.float32), ee.astype(np.float32)
+
+
+def rq_quantize_train(x, weight, cluster_size_ema, embed_ema, depth, decay=0.99, eps=1e-5, restart_vectors=None):
+    """RQBottleneck.quantize in train mode with ONE shared EMA codebook (quantizations.py:199-205,237-271): the depth loop calls
+    the same VQEmbedding `depth` times, each call updating it from that depth's residuals before the next depth searches it.
+    restart_vectors: list (len depth) of (K, D) arrays or None.  Returns (quant_list, codes, weight, cluster_size_ema, embed_ema)."""
+    x = np.asarray(x, np.float32)
+    D = x.shape[-1]
+    residual = x.reshape(-1, D).copy()
+    agg = np.zeros_like(residual)
+    w, cs, ee = np.asarray(weight, np.float32), cluster_size_ema, embed_ema
+    quant_list, code_list = [], []
+    for d in range(depth):
+        rv = None if restart_vectors is None else restart_vectors[d]
+        quant, code, w, cs, ee = vq_ema_step(w, cs, ee, residual, decay, eps, rv)
+        residual = residual - quant
+        agg = agg + quant
+        quant_list.append(agg.reshape(x.shape).copy())
+        code_list.append(code.reshape(x.shape[:-1])[..., None])
+    return quant_list, np.concatenate(code_list, -1), w, cs, ee
+
+
+def ema_restart_candidates(vectors, n_embed, prng):
+    """numpy twin of VQEmbedding._tile_with_noise + the randperm pick (quantizations.py:70-77,107-111) on a shared fake random
+    stream `prng` (np.random.Generator): the fixture generator and the tests patch torch.rand_like / torch.randperm to draw
+    from the same stream, so that the reference, the oracle and the product on any device see the same restart vectors."""
+    v = np.asarray(vectors, np.float32)
+    if v.shape[0] < n_embed:
+        reps = (n_embed + v.shape[0] - 1) // v.shape[0]
+        std = np.ones(v.shape[1], np.float32) * np.float32(0.01 / np.sqrt(v.shape[1]))
+        v = np.tile(v, (reps, 1))
+        v = v + prng.random(v.shape, dtype=np.float32) * std
+    return v[prng.permutation(v.shape[0])][:n_embed]

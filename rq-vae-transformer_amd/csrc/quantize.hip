@@ -494,3 +494,110 @@ extern "C" int rqamd_rq_embed(const int64_t* codes, const float* const* codebook
     RQ_LAUNCH(rq_embed_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return rq_check_launch("rq_embed_kernel");
 }
+
+
+// =================================================================================================
+// EMA codebook update of stage-1 training (VQEmbedding._update_buffers / _update_embedding, quantizations.py:80-129).
+// The reference builds a dense (n_embed x n_vectors) one-hot matrix and multiplies it with the vectors (16384 x 8192 fp32 =
+// 512 MB per depth for a 128-image batch) to get per-code counts and vector sums; here a wavefront owns one code, scans the index
+// list 64 entries at a time (ballot) and adds the matching vectors in ascending vector order -- deterministic, no atomics,
+// nothing materialised.  The EMA / dead-code restart / normalisation steps are elementwise.
+__global__ __launch_bounds__(256) void rq_ema_accumulate_kernel(const float* x, const int64_t* idx, long n_vec, int D, int K,
+                                                                float* count_out, float* sum_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= K) return;
+    float acc[16];                                   // D <= 1024: lane owns dims lane, lane + 64, ...
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nd = (D + 63) / 64;
+    int count = 0;
+    for (long v0 = 0; v0 < n_vec; v0 += 64) {
+        const long v = v0 + lane;
+        const bool mine = v < n_vec && idx[v] == (int64_t)k;
+        unsigned long long mask = rq_ballot(mine);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float* row = x + (v0 + j) * D;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < nd && lane + 64 * i < D) acc[i] += row[lane + 64 * i];
+            ++count;
+        }
+    }
+    if (lane == 0) count_out[k] = (float)count;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < nd && lane + 64 * i < D) sum_out[(long)k * D + lane + 64 * i] = acc[i];
+}
+
+// cluster_size_ema.mul_(decay).add_(count, alpha = 1 - decay); embed_ema likewise; then (restart != null) the dead-code restart:
+// usage = cluster_size_ema >= 1; embed_ema = embed_ema * usage + restart * (1 - usage); cluster_size_ema = cluster_size_ema *
+// usage + (1 - usage)   (quantizations.py:103-118).  One thread per (code, dim).
+__global__ void rq_ema_update_kernel(float* cs_ema, float* embed_ema, const float* count, const float* sum, const float* restart,
+                                     int K, int D, float decay) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)K * D) return;
+    const int k = (int)(gid / D);
+    float cs = cs_ema[k] * decay + (1.0f - decay) * count[k];
+    float e = embed_ema[gid] * decay + (1.0f - decay) * sum[gid];
+    if (restart) {
+        const float usage = cs >= 1.0f ? 1.0f : 0.0f;
+        e = e * usage + restart[gid] * (1.0f - usage);
+        cs = cs * usage + (1.0f - usage);
+    }
+    embed_ema[gid] = e;      // cluster_size_ema[k] is read by every thread of the row: it is updated by rq_ema_cs_kernel, after this launch
+}
+__global__ void rq_ema_cs_kernel(float* cs_ema, const float* count, int K, float decay, int restart) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float cs = cs_ema[k] * decay + (1.0f - decay) * count[k];
+    if (restart) {
+        const float usage = cs >= 1.0f ? 1.0f : 0.0f;
+        cs = cs * usage + (1.0f - usage);
+    }
+    cs_ema[k] = cs;
+}
+
+// weight[k][:] = embed_ema[k][:] / (n * (cluster_size_ema[k] + eps) / (n + n_embed * eps)), n = sum(cluster_size_ema)
+// (quantizations.py:120-129); *n_total is a device scalar (the caller's cluster_size_ema.sum()).
+__global__ void rq_ema_normalize_kernel(const float* cs_ema, const float* embed_ema, const float* n_total, int K, int D, float eps,
+                                        float* weight) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)K * D) return;
+    const int k = (int)(gid / D);
+    const float n = *n_total;
+    const float norm = n * (cs_ema[k] + eps) / (n + (float)K * eps);
+    weight[gid] = embed_ema[gid] / norm;
+}
+
+extern "C" int rqamd_rq_ema_accumulate(const float* x, const int64_t* idx, int64_t n_vec, int dim, int n_embed, float* count_out,
+                                       float* sum_out, void* stream) {
+    if (!x || !idx || !count_out || !sum_out) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_accumulate: null argument");
+    if (n_vec < 0 || n_embed < 1 || dim < 1 || dim > 1024) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_ema_accumulate: n_vec >= 0, n_embed >= 1, 1 <= dim <= 1024 needed");
+    RQ_LAUNCH(rq_ema_accumulate_kernel, dim3((n_embed + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, idx, (long)n_vec, dim, n_embed, count_out, sum_out);
+    return rq_check_launch("rq_ema_accumulate_kernel");
+}
+
+extern "C" int rqamd_rq_ema_update(float* cluster_size_ema, float* embed_ema, const float* count, const float* sum, const float* restart_vectors,
+                                   int n_embed, int dim, float decay, void* stream) {
+    if (!cluster_size_ema || !embed_ema || !count || !sum) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_update: null argument");
+    if (n_embed < 1 || dim < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_update: bad shape");
+    const long n = (long)n_embed * dim;
+    // embed_ema first (it reads the OLD cluster_size_ema for the restart decision), then cluster_size_ema itself
+    RQ_LAUNCH(rq_ema_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, embed_ema, count, sum,
+              restart_vectors, n_embed, dim, decay);
+    RQ_TRY(rq_check_launch("rq_ema_update_kernel"));
+    RQ_LAUNCH(rq_ema_cs_kernel, dim3((n_embed + 255) / 256), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, count, n_embed, decay, restart_vectors ? 1 : 0);
+    return rq_check_launch("rq_ema_cs_kernel");
+}
+
+extern "C" int rqamd_rq_ema_normalize(const float* cluster_size_ema, const float* embed_ema, const float* n_total, int n_embed, int dim, float eps,
+                                      float* weight_out, void* stream) {
+    if (!cluster_size_ema || !embed_ema || !n_total || !weight_out) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_normalize: null argument");
+    const long n = (long)n_embed * dim;
+    RQ_LAUNCH(rq_ema_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, embed_ema, n_total,
+              n_embed, dim, eps, weight_out);
+    return rq_check_launch("rq_ema_normalize_kernel");
+}

@@ -48,6 +48,9 @@ _SIGS = {
     'rqamd_rq_soft_codes': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
                                       C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p]),
+    'rqamd_rq_ema_accumulate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rqamd_rq_ema_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'rqamd_rq_ema_normalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_sample_logits': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, C.c_uint64, C.c_uint64,
@@ -232,6 +235,33 @@ def rq_soft_codes(x, codebooks, norms, temp=1.0, stochastic=False, seed=0, offse
                                         int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(soft), ptr(codes), ptr(ws), ws.numel(),
                                         stream_of(x)))
     return soft, codes
+
+
+def rq_ema_accumulate(x, idx, n_embed):
+    """x (n_vec, dim) fp32, idx (n_vec) int64 -> (count (n_embed,), sum (n_embed, dim)) fp32: VQEmbedding._update_buffers' one-hot sums."""
+    n_vec, dim = x.shape
+    count = torch.empty((n_embed,), dtype=torch.float32, device=x.device)
+    vsum = torch.empty((n_embed, dim), dtype=torch.float32, device=x.device)
+    with on_device_of(x):
+        check(lib().rqamd_rq_ema_accumulate(ptr(x, torch.float32), ptr(idx, torch.int64), n_vec, dim, n_embed, ptr(count), ptr(vsum), stream_of(x)))
+    return count, vsum
+
+
+def rq_ema_update(cluster_size_ema, embed_ema, count, vsum, restart_vectors, decay):
+    """in place: the EMA step of the codebook statistics + (restart_vectors given) the dead-code restart."""
+    n_embed, dim = embed_ema.shape
+    with on_device_of(embed_ema):
+        check(lib().rqamd_rq_ema_update(ptr(cluster_size_ema, torch.float32), ptr(embed_ema, torch.float32), ptr(count, torch.float32),
+                                        ptr(vsum, torch.float32), ptr(restart_vectors, torch.float32), n_embed, dim, float(decay),
+                                        stream_of(embed_ema)))
+
+
+def rq_ema_normalize(cluster_size_ema, embed_ema, n_total, eps, weight_out):
+    """weight_out (n_embed, dim) <- embed_ema / normalised cluster size; n_total: device scalar = cluster_size_ema.sum()."""
+    n_embed, dim = embed_ema.shape
+    with on_device_of(embed_ema):
+        check(lib().rqamd_rq_ema_normalize(ptr(cluster_size_ema, torch.float32), ptr(embed_ema, torch.float32), ptr(n_total, torch.float32),
+                                           n_embed, dim, float(eps), ptr(weight_out, torch.float32), stream_of(embed_ema)))
 
 
 def rq_embed(codes, codebooks, mode):

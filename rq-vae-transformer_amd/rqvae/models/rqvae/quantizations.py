@@ -1,12 +1,13 @@
 """Residual quantiser: API mirror of rqvae/models/rqvae/quantizations.py of the reference
-(VQEmbedding :24-146, RQBottleneck :149-334, inference paths).  The nearest-codebook search, residual
-update and code->embedding lookups run in librqamd (csrc/quantize.hip); the EMA codebook update,
-dead-code restart (:80-129) are stage-1 *training* code and out of scope -- they raise
-NotImplementedError; get_soft_codes (:371-400) runs natively."""
+(VQEmbedding :24-146, RQBottleneck :149-400).  The nearest-codebook search, residual update, code->embedding
+lookups, get_soft_codes (:371-400) and -- in train mode -- the EMA codebook update with the dead-code restart
+(:80-129) run in librqamd (csrc/quantize.hip).  What stays out of scope is the rest of stage-1
+training (GAN trainer, losses, optimisers: SURVEY.md §2); a codebook without EMA (learned by gradient) raises."""
 from typing import Iterable
 
 import numpy as np
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from ... import _native
@@ -64,12 +65,55 @@ class VQEmbedding(nn.Embedding):
         return codes.reshape(shape[:-1])
 
     @torch.no_grad()
+    def _restart_candidates(self, vectors):
+        """quantizations.py:70-77,107-115: n_embed random input vectors (tiled with a little uniform noise when the batch
+        holds fewer vectors than codes), the same on every rank.  torch.rand_like / torch.randperm consume the generator in
+        the reference's order."""
+        n_embed, dim = self.n_embed, vectors.shape[1]
+        if vectors.shape[0] < n_embed:
+            reps = (n_embed + vectors.shape[0] - 1) // vectors.shape[0]
+            std = vectors.new_ones(dim) * 0.01 / np.sqrt(dim)
+            vectors = vectors.repeat(reps, 1)
+            vectors = vectors + torch.rand_like(vectors) * std
+        picked = vectors[torch.randperm(vectors.shape[0], device=vectors.device)][:n_embed].contiguous()
+        if dist.is_initialized():
+            dist.broadcast(picked, 0)
+        return picked
+
+    @torch.no_grad()
+    def _update_buffers(self, vectors, idxs):
+        """quantizations.py:80-118: per-code counts and vector sums of this batch (one native pass instead of the reference's
+        (n_embed x n_vectors) one-hot matmul), summed over the ranks, folded into the EMA statistics; unused codes restart."""
+        flat = vectors.detach().reshape(-1, vectors.shape[-1]).to(torch.float32).contiguous()
+        count, vsum = _native.rq_ema_accumulate(flat, idxs.reshape(-1).contiguous(), self.n_embed)
+        if dist.is_initialized():
+            dist.all_reduce(vsum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)
+        restart = self._restart_candidates(flat) if self.restart_unused_codes else None
+        _native.rq_ema_update(self.cluster_size_ema, self.embed_ema, count, vsum, restart, self.decay)
+
+    @torch.no_grad()
+    def _update_embedding(self):
+        """quantizations.py:120-129"""
+        n = self.cluster_size_ema.sum().reshape(1)
+        new_w = torch.empty_like(self.embed_ema)
+        _native.rq_ema_normalize(self.cluster_size_ema, self.embed_ema, n, self.eps, new_w)
+        self.weight[:-1].copy_(new_w)               # in place through torch: bumps the version counter every cache keys on
+        self.invalidate_code_norms()
+
+    @torch.no_grad()
     def forward(self, inputs):
-        """quantizations.py:131-142 (eval branch)."""
-        if self.training and self.ema:
-            raise NotImplementedError('EMA codebook updates (training) are outside the sampling path')
+        """quantizations.py:131-142: nearest codes with the current weights; in train mode the EMA statistics are updated from
+        this batch, the embeddings are looked up in the weights as they were, and the weights are refreshed afterwards."""
+        if self.training and not self.ema:
+            raise NotImplementedError('a codebook learned by gradient (ema=False) needs the training graph; only EMA codebooks are supported')
         embed_idxs = self.find_nearest_embedding(inputs)
-        return self.embed(embed_idxs), embed_idxs
+        if self.training:
+            self._update_buffers(inputs, embed_idxs)
+        embeds = self.embed(embed_idxs)
+        if self.training:
+            self._update_embedding()
+        return embeds, embed_idxs
 
     def embed(self, idxs):
         """quantizations.py:144-146"""
@@ -130,19 +174,23 @@ class RQBottleneck(nn.Module):
     def _norm_list(self):
         return [cb.code_norms() for cb in self.codebooks]
 
-    def _no_training(self):
-        # the reference's train-mode quantize() runs VQEmbedding.forward, which updates the EMA codebook statistics and
-        # restarts dead codes (quantizations.py:80-129,131-142); that is stage-1 training, not this path -- refuse loudly
-        # rather than quantise with codebooks that silently never update
-        if self.training and any(cb.ema for cb in self.codebooks):
-            raise NotImplementedError('RQBottleneck in train mode updates its EMA codebooks (stage-1 training, out of scope): '
-                                      'call .eval() for the sampling / reconstruction path')
-
     # ---- the hot path
     def quantize(self, x):
-        """quantizations.py:237-271 -> (quant_list: depth x (B,h,w,D) cumulative, codes (B,h,w,depth) int64)"""
-        self._no_training()
+        """quantizations.py:237-271 -> (quant_list: depth x (B,h,w,D) cumulative, codes (B,h,w,depth) int64).  eval: all depths
+        in one native launch.  train: the reference's depth loop over VQEmbedding.forward, because every call updates its
+        (possibly shared) EMA codebook before the next depth searches it."""
         B, h, w, embed_dim = x.shape
+        if self.training:
+            residual = x.detach().to(torch.float32).clone()
+            aggregated = torch.zeros_like(residual)
+            quant_list, code_list = [], []
+            for codebook in self.codebooks:
+                quant, code = codebook(residual)
+                residual.sub_(quant)
+                aggregated.add_(quant)
+                quant_list.append(aggregated.clone())
+                code_list.append(code.unsqueeze(-1))
+            return quant_list, torch.cat(code_list, dim=-1)
         flat = x.detach().reshape(-1, embed_dim).to(torch.float32).contiguous()
         codes, quants = _native.rq_quantize(flat, self.codebook_list(), want_quants=True, norms=self._norm_list())
         quant_list = [quants[i].reshape(B, h, w, embed_dim) for i in range(quants.shape[0])]

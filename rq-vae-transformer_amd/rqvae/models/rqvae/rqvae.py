@@ -172,7 +172,7 @@ class RQVAE(Stage1Model):
         (rqvae/metrics/fid.py:167-169): such row views of an image batch are served from batched passes over the rows that
         follow (see _ReadAhead), each row's (out, quant_loss, code) being what the one-image call returns, bit for bit."""
         served = None
-        if not torch.is_grad_enabled() or not xs.requires_grad:
+        if not self.quantizer.training and (not torch.is_grad_enabled() or not xs.requires_grad):      # (train mode updates the EMA codebook per call)
             served = self._ahead_fwd.serve(xs, lambda: signature(self), self._forward_window)
         if served is None:
             z_e = self.encode(xs)
@@ -215,6 +215,8 @@ class RQVAE(Stage1Model):
     def get_codes(self, xs):
         """rqvae.py:91-95"""
         z_e = self.encode(xs)
+        if self.quantizer.training:                 # the reference goes through quantizer.forward here, EMA update included
+            return self.quantizer(z_e)[2]
         return self.quantizer.get_codes_only(self.quantizer.to_code_shape(z_e))
 
     @torch.no_grad()

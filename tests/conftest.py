@@ -24,3 +24,17 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+@pytest.fixture
+def fake_torch_rng(monkeypatch):
+    """torch.rand_like / torch.randperm drawing from a seeded numpy stream (what tests/golden/make_golden.py:gen_ema did to the
+    reference), so that the dead-code restart of the EMA codebook update is replayable on any device."""
+    import numpy as np
+    import torch
+
+    def install(seed):
+        prng = np.random.default_rng(seed)
+        monkeypatch.setattr(torch, 'randperm', lambda n, device=None: torch.from_numpy(prng.permutation(n)).to(device or 'cpu'))
+        monkeypatch.setattr(torch, 'rand_like', lambda t: torch.from_numpy(prng.random(tuple(t.shape), dtype=np.float32)).to(t.device))
+    return install

@@ -297,6 +297,67 @@ def gen_rqt_variants():
         save(f'rqt_var_{tag}.npz', seed=47, vae_seed=31, codes=codes.astype(np.int32), cond=cond.astype(np.int32), logits=logits)
 
 
+def gen_ema():
+    """Train-mode quantiser of the reference:
+      * RQBottleneck.quantize, depth 4, ONE shared EMA codebook updated after every depth (restart_unused_codes=False), two
+        batches -- the EMA statistics, the refreshed weights and the codes each depth finds in them;
+      * single VQEmbedding.forward steps with the dead-code restart, on 384 vectors (>= n_embed) and on 128 (< n_embed: the
+        tile-with-noise branch), torch.rand_like / torch.randperm replaced by a seeded numpy stream so that any device can
+        replay the draws.  (Restarted codewords are copies of input vectors: searching them again with the same inputs is
+        ambiguous at fp32 distance noise, in the reference too, so the restart is pinned one step at a time.)"""
+    from rqvae.models.rqvae.quantizations import RQBottleneck, VQEmbedding
+    K, Dm, seed, decay = 300, 64, 71, 0.9
+    rng = np.random.default_rng(seed)
+    cb = rng.standard_normal((K, Dm), dtype=np.float32)
+    cs0 = rng.uniform(0.0, 3.0, K).astype(np.float32)
+    xs = [rng.standard_normal((6, 8, 8, Dm), dtype=np.float32), rng.standard_normal((2, 8, 8, Dm), dtype=np.float32)]
+    x_many = rng.standard_normal((384, Dm), dtype=np.float32)
+    x_few = rng.standard_normal((128, Dm), dtype=np.float32)
+    real = torch.randperm, torch.rand_like
+
+    def fake(prng):
+        torch.randperm = lambda n, device=None: torch.from_numpy(prng.permutation(n))
+        torch.rand_like = lambda t: torch.from_numpy(prng.random(tuple(t.shape), dtype=np.float32))
+
+    def load(vq):
+        vq.weight.data.copy_(torch.from_numpy(np.concatenate([cb, np.zeros((1, Dm), np.float32)])))
+        vq.embed_ema.copy_(torch.from_numpy(cb * cs0[:, None]))
+        vq.cluster_size_ema.copy_(torch.from_numpy(cs0))
+    out = dict(seed=seed, K=K, D=Dm, decay=np.float32(decay))
+    rq = RQBottleneck([8, 8, Dm], [8, 8, 4], K, decay=decay, shared_codebook=True, restart_unused_codes=False).train()
+    vq = rq.codebooks[0]
+    load(vq)
+    for b, x in enumerate(xs):
+        quant_list, codes = rq.quantize(torch.from_numpy(x))
+        out.update({f'codes{b}': codes.numpy().astype(np.int32), f'quant_last{b}': quant_list[-1].numpy(),
+                    f'weight{b}': vq.weight[:-1].numpy().copy(), f'cs{b}': vq.cluster_size_ema.numpy().copy(),
+                    f'ee{b}': vq.embed_ema.numpy().copy()})
+    try:
+        for tag, xv, sd in (('many', x_many, seed + 1), ('few', x_few, seed + 2)):
+            one = VQEmbedding(K, Dm, decay=decay, restart_unused_codes=True).train()
+            load(one)
+            fake(np.random.default_rng(sd))
+            emb, code = one(torch.from_numpy(xv))
+            out.update({f'{tag}_codes': code.numpy().astype(np.int32), f'{tag}_embeds': emb.numpy(), f'{tag}_weight': one.weight[:-1].numpy().copy(),
+                        f'{tag}_cs': one.cluster_size_ema.numpy().copy(), f'{tag}_ee': one.embed_ema.numpy().copy()})
+    finally:
+        torch.randperm, torch.rand_like = real
+    # the oracle replays all of it
+    w, cs, ee = cb, cs0, cb * cs0[:, None]
+    for b, x in enumerate(xs):
+        ql, codes, w, cs, ee = oracle.rq_quantize_train(x, w, cs, ee, 4, decay, 1e-5, None)
+        assert np.array_equal(codes, out[f'codes{b}'])
+        print(f'  ema[batch {b}] oracle vs ref: quants {rel(ql[-1], out[f"quant_last{b}"]):.2e}, weight {rel(w, out[f"weight{b}"]):.2e}, '
+              f'cluster_size_ema {rel(cs, out[f"cs{b}"]):.2e}, embed_ema {rel(ee, out[f"ee{b}"]):.2e}')
+    for tag, xv, sd in (('many', x_many, seed + 1), ('few', x_few, seed + 2)):
+        rv = oracle.ema_restart_candidates(xv, K, np.random.default_rng(sd))
+        quant, code, w1, cs1, ee1 = oracle.vq_ema_step(cb, cs0, cb * cs0[:, None], xv, decay, 1e-5, rv)
+        assert np.array_equal(code, out[f'{tag}_codes']) and np.array_equal(quant, out[f'{tag}_embeds'])
+        print(f'  ema[restart, {len(xv)} vectors] oracle vs ref: weight {rel(w1, out[f"{tag}_weight"]):.2e}, embed_ema '
+              f'{rel(ee1, out[f"{tag}_ee"]):.2e}; restarted codes {(out[f"{tag}_cs"] == 1).sum()}')
+    save('rq_ema.npz', **out)
+
+
 def gen_param_counts():
     counts = {}
     for name in C.PARAM_COUNTS_M:
@@ -313,11 +374,11 @@ def gen_param_counts():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'rqt_var', 'counts']
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'rqt_var', 'ema', 'counts']
     for w in which:
         print(f'[{w}]')
         if w.startswith('rqt_big:'):                      # e.g. rqt_big:txt32,txt64
             gen_rqt_big(w.split(':', 1)[1].split(','))
             continue
         {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
-         'counts': gen_param_counts}[w]()
+         'ema': gen_ema, 'counts': gen_param_counts}[w]()

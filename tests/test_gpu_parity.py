@@ -95,6 +95,63 @@ def test_rq_quantize_non_finite_rows(nat):
         assert int(codes.min()) >= 0 and int(codes.max()) < K
 
 
+def test_rq_ema_update_golden(nat, golden, fake_torch_rng):
+    """Train-mode quantiser: the product's EMA codebook update + dead-code restart (csrc/quantize.hip: rq_ema_* kernels behind
+    VQEmbedding.forward / RQBottleneck.quantize in train mode, quantizations.py:80-142,237-271) against the REFERENCE's outputs
+    (tests/golden/rq_ema.npz).  Codes and gathered embeddings bit-exact; EMA statistics / refreshed weights to fp32 summation
+    order (the reference sums a batch's vectors per code inside an sgemm, here in ascending vector order)."""
+    from rqvae.models.rqvae.quantizations import RQBottleneck, VQEmbedding
+    g = golden('rq_ema.npz')
+    K, Dm, seed, decay = int(g['K']), int(g['D']), int(g['seed']), float(g['decay'])
+    rng = np.random.default_rng(seed)
+    cb = rng.standard_normal((K, Dm), dtype=np.float32)
+    cs0 = rng.uniform(0.0, 3.0, K).astype(np.float32)
+    xs = [rng.standard_normal((6, 8, 8, Dm), dtype=np.float32), rng.standard_normal((2, 8, 8, Dm), dtype=np.float32)]
+    x_many = rng.standard_normal((384, Dm), dtype=np.float32)
+    x_few = rng.standard_normal((128, Dm), dtype=np.float32)
+
+    def load(vq):
+        with torch.no_grad():
+            vq.weight.copy_(G(np.concatenate([cb, np.zeros((1, Dm), np.float32)])))
+            vq.embed_ema.copy_(G(cb * cs0[:, None]))
+            vq.cluster_size_ema.copy_(G(cs0))
+    rq = RQBottleneck([8, 8, Dm], [8, 8, 4], K, decay=decay, shared_codebook=True, restart_unused_codes=False).to(DEV).train()
+    vq = rq.codebooks[0]
+    load(vq)
+    for b, x in enumerate(xs):
+        quant_list, codes = rq.quantize(G(x))
+        assert np.array_equal(N(codes), g[f'codes{b}'])
+        np.testing.assert_allclose(N(quant_list[-1]), g[f'quant_last{b}'], rtol=0, atol=2e-6)
+        for got, key in ((vq.weight[:-1], 'weight'), (vq.cluster_size_ema, 'cs'), (vq.embed_ema, 'ee')):
+            np.testing.assert_allclose(N(got), g[f'{key}{b}'], rtol=2e-5, atol=2e-6)
+    # eval mode afterwards searches the refreshed codebook (cached ||c||^2 invalidated by the update)
+    rq.eval()
+    ql_e, codes_e = rq.quantize(G(xs[0]))
+    oq, oc = oracle.rq_quantize(xs[0], [N(vq.weight[:-1])] * 4)
+    gaps, _ = oracle.rq_quantize_margins(xs[0], [N(vq.weight[:-1])] * 4)
+    clear = np.minimum.accumulate(gaps > 1e-3, axis=-1)
+    assert np.array_equal(N(codes_e)[clear], oc[clear]) and clear.mean() > 0.99
+    for tag, xv, sd in (('many', x_many, seed + 1), ('few', x_few, seed + 2)):
+        one = VQEmbedding(K, Dm, decay=decay, restart_unused_codes=True).to(DEV).train()
+        load(one)
+        fake_torch_rng(sd)
+        emb, code = one(G(xv))
+        assert np.array_equal(N(code), g[f'{tag}_codes']) and np.array_equal(N(emb), g[f'{tag}_embeds'])
+        assert np.array_equal(N(one.cluster_size_ema) == 1, g[f'{tag}_cs'] == 1)                 # the same codes restarted
+        for got, key in ((one.weight[:-1], 'weight'), (one.cluster_size_ema, 'cs'), (one.embed_ema, 'ee')):
+            np.testing.assert_allclose(N(got), g[f'{tag}_{key}'], rtol=2e-5, atol=2e-6)
+    # the kernel alone, ragged sizes: counts and sums vs numpy
+    n_vec, Kk, Dd = 777, 45, 192
+    xv = rng.standard_normal((n_vec, Dd), dtype=np.float32)
+    idx = rng.integers(0, Kk, n_vec)
+    idx[idx == 7] = 8                                                                              # an unused code
+    count, vsum = nat.rq_ema_accumulate(G(xv), G(idx.astype(np.int64)), Kk)
+    assert np.array_equal(N(count), np.bincount(idx, minlength=Kk).astype(np.float32)) and N(count)[7] == 0
+    want = np.zeros((Kk, Dd), np.float64)
+    np.add.at(want, idx, xv.astype(np.float64))
+    np.testing.assert_allclose(N(vsum), want, rtol=0, atol=2e-5)
+
+
 def test_rq_quantize_properties_large(nat):
     """256 images x 64 vectors, K=16384: size-independent properties (the oracle would take minutes)."""
     gen = torch.Generator(device=DEV).manual_seed(3)

@@ -129,6 +129,32 @@ def test_oracle_vs_reference_real_widths(golden, tag):
         assert np.abs(out[1][:, g['cond_pos']] - g['cond_logits'].astype(np.float32)).max() < 2e-3
 
 
+def test_rq_ema_update(golden):
+    """train-mode quantiser (EMA codebook update + dead-code restart, quantizations.py:80-142,237-271) vs the reference's outputs"""
+    g = golden('rq_ema.npz')
+    K, Dm, seed, decay = int(g['K']), int(g['D']), int(g['seed']), float(g['decay'])
+    rng = np.random.default_rng(seed)
+    cb = rng.standard_normal((K, Dm), dtype=np.float32)
+    cs0 = rng.uniform(0.0, 3.0, K).astype(np.float32)
+    xs = [rng.standard_normal((6, 8, 8, Dm), dtype=np.float32), rng.standard_normal((2, 8, 8, Dm), dtype=np.float32)]
+    x_many = rng.standard_normal((384, Dm), dtype=np.float32)
+    x_few = rng.standard_normal((128, Dm), dtype=np.float32)
+    w, cs, ee = cb, cs0, cb * cs0[:, None]
+    for b, x in enumerate(xs):
+        ql, codes, w, cs, ee = oracle.rq_quantize_train(x, w, cs, ee, 4, decay, 1e-5, None)
+        assert np.array_equal(codes, g[f'codes{b}'])
+        np.testing.assert_allclose(ql[-1], g[f'quant_last{b}'], rtol=0, atol=2e-6)
+        for got, key in ((w, 'weight'), (cs, 'cs'), (ee, 'ee')):
+            np.testing.assert_allclose(got, g[f'{key}{b}'], rtol=1e-5, atol=1e-6)
+    for tag, xv, sd in (('many', x_many, seed + 1), ('few', x_few, seed + 2)):
+        rv = oracle.ema_restart_candidates(xv, K, np.random.default_rng(sd))
+        quant, code, w1, cs1, ee1 = oracle.vq_ema_step(cb, cs0, cb * cs0[:, None], xv, decay, 1e-5, rv)
+        assert np.array_equal(code, g[f'{tag}_codes']) and np.array_equal(quant, g[f'{tag}_embeds'])
+        assert np.array_equal(cs1 == 1, g[f'{tag}_cs'] == 1) and (cs1 == 1).sum() > 50        # the same codes restarted
+        for got, key in ((w1, 'weight'), (cs1, 'cs'), (ee1, 'ee')):
+            np.testing.assert_allclose(got, g[f'{tag}_{key}'], rtol=1e-5, atol=1e-6)
+
+
 def test_param_counts():
     """README.md:38-47 of the reference: structural known answers."""
     with open(os.path.join(GOLDEN, 'param_counts.json')) as f:
