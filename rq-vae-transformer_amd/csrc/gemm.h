@@ -1329,3 +1329,194 @@ int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 // picks (BM, BN, splitk) for a weight-streaming decode GEMM; returns splitk actually used via args
 // glds (may be null): receives the number of LDS-DMA stages to use (0 = register-staged operands)
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds);
+
+
+// -------------------------------------------------------------------------------------------------
+// Weight-streaming GEMM for the small-batch decode steps (M <= 128 rows per m-tile: the per-GPU batches of 64 / 100 that
+// SURVEY 8d names).  At these sizes a GEMM is one pass over W with almost no arithmetic, and what decides its time is how
+// many bytes a workgroup keeps in flight and how long its dependent chain per K-tile is (scripts/micro/weight_stream.hip,
+// profiles/r03_weight_stream.txt: the qkv weights stream in 9.6 us with 2 K-tiles of 64 rows in flight per workgroup --
+// what gemm_bf16_kernel<64, 64> does and takes -- in 5.3 us with 4, in 4.1 us with 32-row tiles and 8; the layout of W in
+// memory makes no difference).  The tiled kernels add a workgroup barrier, an LDS round trip and a chain of four dependent
+// MFMAs per K-tile on top (~600 cycles x 24 K-tiles); the round-2 skinny kernel avoided LDS but fetched the activations in
+// fragment layout straight from L2 (32 scattered 32-byte pieces per instruction) and lost at 64 rows.
+// Here: a workgroup owns 32 weight rows and BM activation rows; its FOUR wavefronts each take every fourth K-tile and run
+// WITHOUT workgroup barriers -- each wavefront has a private ring of NS LDS slots { A tile [BM][64], W tile [32][64] }
+// filled by its own LDS-DMA instructions (coalesced 1-KB bursts, no staging registers), waits with counted vmcnt, reads
+// its fragments, refills the slot and runs 4 MFMAs per 32-row block (independent accumulator chains per block).  12 slots of
+// 12 KB (BM = 64: 144 KB in flight per workgroup) or 8 of 20 KB (BM = 128).  The four partial tiles are summed through LDS
+// in wavefront order (deterministic) by all 256 threads, which apply the epilogue and write row-contiguous 16 / 32-byte
+// pieces.  blockIdx.z = split-K slice (fp32 partial slabs, residual-producing GEMMs).  The arithmetic of an output element
+// (K-tiles of a slice dealt round-robin to four accumulators, MFMA order inside a tile, reduction order) does not depend on
+// BM, so the 64- and 128-row forms agree bit for bit.
+template <int BM>
+__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
+    constexpr int BN = 32, BK = 64, NW = 4;
+    constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, SLOT = A_BYTES + W_BYTES;
+    constexpr int NS = BM == 64 ? 3 : 2;               // slots per wavefront
+    constexpr int A_G = BM / 8, W_G = BN / 8, PER = A_G + W_G;      // 1-KB (8-row) DMA groups per K-tile
+    constexpr int MI = BM / 32;
+    constexpr int RS = BN + 1;                         // row stride (floats) of a partial tile in LDS
+    static_assert(NW * NS * SLOT <= 160 * 1024 && NW * BM * RS * 4 <= NW * NS * SLOT, "LDS budget");
+    RQ_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rq_uniform(tid >> 6);
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int kt_total = p.K / BK;
+    const int per = (kt_total + p.splitk - 1) / p.splitk;
+    const int kt0 = blockIdx.z * per;
+    const int kt1 = (kt0 + per < kt_total) ? kt0 + per : kt_total;
+    const int nk = kt1 - kt0;
+    const int n_mine = nk > wave ? (nk - wave + NW - 1) / NW : 0;     // this wavefront's K-tiles: kt0 + wave + 4 i
+
+    const char* gA = (const char*)p.A;
+    const char* gW = (const char*)p.W;
+    const rq_lds_t lds_w = rq_lds_addr(smem) + (rq_lds_t)(wave * NS * SLOT);
+    // DMA: lane (lr, lc) of 8-row group g fills LDS position (row 8 g + lr, chunk lc); the 16-byte-chunk swizzle
+    // chunk ^ ((row >> 1) & 7) of the fragment reads is applied to the per-lane SOURCE address
+    const int lr = lane >> 3, lc = lane & 7;
+    unsigned ga[A_G], gb[W_G];
+#pragma unroll
+    for (int g = 0; g < A_G; ++g) {
+        const int row = 8 * g + lr;
+        int m = m0 + row;
+        m = m < p.M - 1 ? m : p.M - 1;
+        ga[g] = ((unsigned)m * (unsigned)p.lda + (unsigned)((lc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+#pragma unroll
+    for (int g = 0; g < W_G; ++g) {
+        const int row = 8 * g + lr;
+        int n = n0 + row;
+        n = n < p.N - 1 ? n : p.N - 1;
+        gb[g] = ((unsigned)n * (unsigned)p.K + (unsigned)((lc ^ ((row >> 1) & 7)) << 3)) * 2u;
+    }
+    auto issue = [&](int i, int slot) {
+        const unsigned kb = (unsigned)(kt0 + wave + i * NW) * (BK * 2);
+        const rq_lds_t base = lds_w + (rq_lds_t)(slot * SLOT);
+#pragma unroll
+        for (int g = 0; g < A_G; ++g) rq_glds16(base + (rq_lds_t)(g * 1024), gA + (ga[g] + kb));
+#pragma unroll
+        for (int g = 0; g < W_G; ++g) rq_glds16(base + (rq_lds_t)(A_BYTES + g * 1024), gW + (gb[g] + kb));
+    };
+    // fragment reads: row = 32 i + (lane & 31), chunk 2 ks + (lane >> 5), swizzled
+    const int frow = lane & 31, fk = lane >> 5;
+    unsigned rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rd[ks] = (unsigned)(frow * (BK * 2) + (((ks * 2 + fk) ^ ((frow >> 1) & 7)) << 4));
+
+    f32x16 acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+#pragma unroll
+    for (int s0 = 0; s0 < NS; ++s0)
+        if (s0 < n_mine) issue(s0, s0);
+    // what the epilogue needs from global memory (bias, and the fp32 residual rows of the in-place update) is requested now, under the
+    // streaming loop: fetched after it, each was a dependent L2 / HBM round trip (~1.5 us) at the very end of a ~7-us kernel
+    const float* bias = p.bias;
+    if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
+    const int epi = p.epi;
+    const bool accum = epi == EPI_F32_PARTIAL && p.accum;
+    if (epi == EPI_F32_PARTIAL && !accum) bias = nullptr;
+    const int c0 = (tid & 3) * 8;
+    float bv[8], xr[BM / 64][8];
+    {
+        const int n = n0 + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < p.N) ? bias[n + e] : 0.f;
+#pragma unroll
+        for (int rr = 0; rr < BM / 64; ++rr) {
+            const int m = m0 + (tid >> 2) + 64 * rr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[rr][e] = (accum && m < p.M && n + e < p.N) ? ((const float*)p.out)[(long)m * p.ldo + n + e] : 0.f;
+        }
+    }
+    int slot = 0;
+    for (int i = 0; i < n_mine; ++i) {
+        const int newer = n_mine - 1 - i;            // tiles issued after tile i that may still be in flight (at most NS - 1)
+        if (NS >= 3 && newer >= 2) rq_wait_vmcnt<2 * PER>();
+        else if (newer >= 1) rq_wait_vmcnt<PER>();
+        else rq_wait_vmcnt<0>();
+        const char* sb = (const char*)smem + (wave * NS + slot) * SLOT;
+        bf16x8 af[MI][4], bfr[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi][ks] = as_bf16x8(ld128(sb + rd[ks] + mi * (32 * BK * 2)));
+            bfr[ks] = as_bf16x8(ld128(sb + A_BYTES + rd[ks]));
+        }
+        rq_wait_lgkmcnt<0>();                        // the fragments are in registers: the slot may be refilled
+        rq_sched_barrier();
+        if (i + NS < n_mine) issue(i + NS, slot);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = rq_mfma_32x32x16_bf16(af[mi][ks], bfr[ks], acc[mi]);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+
+    // ---- cross-wavefront reduction (wavefront order) + epilogue
+    rq_syncthreads();                                // every wavefront is done with its ring
+    float* sRed = (float*)smem;                      // [NW][BM][RS]
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            sRed[(wave * BM + row) * RS + frow] = acc[mi][r];
+        }
+    rq_syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < BM / 64; ++rr) {
+        const int row = (tid >> 2) + 64 * rr;
+        const int m = m0 + row, n = n0 + c0;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = sRed[row * RS + c0 + e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += sRed[(w * BM + row) * RS + c0 + e];
+            v[e] = a;
+        }
+        const bool full = n + 7 < p.N;
+        if (epi <= EPI_BF16_RESID) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            if (epi == EPI_BF16_GELU) {
+                float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+                rq_gelu4(lo, p.gelu_v2);
+                rq_gelu4(hi, p.gelu_v2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+            }
+            if (epi == EPI_BF16_RESID)
+                for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+            if (full && (p.ldo & 7) == 0) {
+                rq_u128 u;
+                u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+                st128(o, u);
+            } else {
+                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = f32_to_bf16(v[e]);
+            }
+        } else {
+            float* o = (float*)p.out + ((epi == EPI_F32_PARTIAL && !accum) ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
+            if (full && (p.ldo & 3) == 0) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
+                    hi[e] = accum ? (xr[rr][4 + e] + v[4 + e]) + bv[4 + e] : v[4 + e] + bv[4 + e];
+                }
+                *(f32x4*)o = lo;
+                *(f32x4*)(o + 4) = hi;
+            } else {
+                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
+            }
+        }
+    }
+}
+

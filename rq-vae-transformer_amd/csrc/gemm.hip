@@ -106,6 +106,17 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
     return rq_check_launch("gemm_p8_kernel");
 }
 
+// weight-streaming kernel for small batches (gemm.h): dense operands, 32 weight rows x BM activation rows per workgroup
+template <int BM>
+static int launch_stream(const GemmArgs& a, hipStream_t stream) {
+    constexpr size_t smem = (size_t)4 * (BM == 64 ? 3 : 2) * ((BM + 32) * 64 * 2);
+    static RqDeviceOnce attr_once;
+    if (attr_once.first())
+        (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    RQ_LAUNCH(gemm_stream_kernel<BM>, dim3((a.N + 31) / 32, (a.M + BM - 1) / BM, a.splitk), dim3(256), smem, stream, a);
+    return rq_check_launch("gemm_stream_kernel");
+}
+
 template <int BM, int BN>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     // transposed accumulators (TR = 1) for everything except wide fp32 rows (logits / fp32 activations)
@@ -143,6 +154,10 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         return rq_fail(RQAMD_ERR_INVALID, "gemm: virtual split-K needs a conv with a bf16 epilogue, one real split and an even number of K-tiles per chunk");
     if (a.accum && (a.epi != EPI_F32_PARTIAL || a.splitk != 1 || (a.N & 3) || (a.ldo & 3) || (bm == 64 && bn == 32)))
         return rq_fail(RQAMD_ERR_INVALID, "gemm: in-place accumulation needs the slab epilogue, one K split and N, ldo multiples of 4");
+    if ((bm == 66 || bm == 130) && bn == 32) {      // tile codes 66x32 / 130x32: the weight-streaming kernel on 64 / 128 activation rows
+        if (a.conv) return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm stream: dense operands only");
+        return bm == 66 ? launch_stream<64>(a, stream) : launch_stream<128>(a, stream);
+    }
     if (bm == 64 && bn == 32) {       // skinny kernel (M <= 64): 32 weight rows per workgroup, in-workgroup split-K over 8 wavefronts
         if (a.conv || a.M > 64 || a.K % a.splitk != 0 || (a.K / a.splitk) % 512 != 0)
             return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm skinny: dense operands, M <= 64 and (K / splitk) %% 512 == 0 needed");
@@ -215,8 +230,28 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     // 7.8 vs 10.2 us, fc1 7.9 vs 13.6; M = 32: 8.8 vs 10.5, 9.4 vs 12.6) and ties or loses elsewhere (M = 64: qkv 11.2 vs 11.0;
     // split-K slab GEMMs 11.1 vs 7.8) -- at this size a launch is ~7 us of fixed cost around 2-3 us of streaming, whatever the
     // kernel, so the small-batch regime stays launch-latency bound.
-    static const bool no_skinny = getenv("RQAMD_NO_SKINNY") != nullptr;      // A/B switch
-    if (!no_skinny && !allow_splitk && (long)M_rows * g_rq_row_scale <= 32 && K % 512 == 0 && N >= 256 && N < 16384) {
+    // Weight-streaming kernel (gemm_stream_kernel) for <= 128 rows: 32 weight rows per workgroup, four barrier-free wavefronts with
+    // private LDS-DMA rings.  Interleaved A/B with rotating weights (profiles/r03_gemm_stream_ab.txt, MI355X): 64 rows: qkv 10.6 ->
+    // 7.4 us, fc1 11.8 -> 7.6, proj 7.0 -> 6.8, fc2 8.5 -> 7.9 (one layer 37.9 -> 29.7 us); 8 rows: level with the round-2 skinny
+    // kernel it replaces (30.6 -> 29.2); 65..128 rows (128-row form): qkv 10.6 -> 9.5, fc1 12.2 -> 10.5, proj / fc2 +0.7 / +1.5 (one
+    // layer 40.6 -> 40.0) -- taken for ALL four there so that a row's result does not depend on which side of 64 its batch falls (the
+    // two forms agree bit for bit).  Not for the classifier (N = 16384: every workgroup re-reads the activations, 16.6 -> 19.7 us) and
+    // not beyond 128 rows (the activation tile outgrows the per-CU fill rate: 256 rows 52 -> 64 us per layer).
+    // Split-K (slab GEMMs): as many slices as keep (N / 32) x slices within one round of 256 CUs -- the kernel holds 144-160 KB of
+    // LDS, one workgroup per CU (fc2: 4 slices 7.9 us, 8 slices 11.3) -- a function of (N, K) only.
+    static const bool no_stream = getenv("RQAMD_NO_STREAM") != nullptr;      // A/B switch
+    if (!no_stream && M <= 128 && K % 64 == 0 && N < 16384 && N >= 64) {
+        *bm = M <= 64 ? 66 : 130; *bn = 32;
+        int sk = 1;
+        if (allow_splitk) {
+            const int nt = (N + 31) / 32, kt = K / 64;
+            while (sk < 8 && nt * (sk * 2) <= 256 && kt % (sk * 2) == 0 && kt / (sk * 2) >= 4) sk *= 2;
+        }
+        *splitk = sk;
+        return;
+    }
+    static const bool skinny = getenv("RQAMD_SKINNY") != nullptr;      // the round-2 skinny kernel, kept selectable for A/B runs
+    if (skinny && !allow_splitk && (long)M_rows * g_rq_row_scale <= 32 && K % 512 == 0 && N >= 256 && N < 16384) {
         *bm = 64; *bn = 32; *splitk = 1;
         return;
     }

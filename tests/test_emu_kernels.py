@@ -620,6 +620,44 @@ def test_emu_gemm_skinny(nat):
             assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * np.abs(ref).max(), (M, N, K)
 
 
+def test_emu_gemm_stream(nat):
+    """Small-batch weight-streaming kernel (gemm_stream_kernel: four barrier-free wavefronts with private LDS-DMA rings, every
+    fourth K-tile each, LDS reduction): 64- and 128-row forms, ragged M / N, several m-tiles, K-tile counts that leave
+    wavefronts with unequal (or no) work, every epilogue family incl. split-K slabs and the in-place residual update; the two
+    forms agree bit for bit on shared rows."""
+    rng = np.random.default_rng(23)
+    for (M, N, K) in ((64, 96, 512), (37, 70, 1536), (1, 64, 128), (128, 64, 384), (200, 100, 640)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+        scale = np.abs(ref).max()
+        outs = {}
+        for bm in (66, 130):
+            out = nat.dbg_gemm(a, w, bias, epi=3, bm=bm, bn=32, splitk=1).numpy()
+            assert np.abs(out - ref).max() < 2e-3 * scale, (M, N, K, bm)
+            outs[bm] = out
+            out = nat.dbg_gemm(a, w, bias, epi=0, bm=bm, bn=32, splitk=1).float().numpy()
+            assert np.abs(out - ref).max() < 1e-2 * scale, (M, N, K, bm)
+            if K >= 512:
+                out = nat.dbg_gemm(a, w, None, epi=4, bm=bm, bn=32, splitk=2).numpy().sum(0)
+                assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * scale, (M, N, K, bm)
+            if N % 4 == 0:
+                x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+                xs = x0.clone()
+                nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=bm, bn=32, splitk=1, out=xs)
+                slab = nat.dbg_gemm(a, w, None, epi=4, bm=bm, bn=32, splitk=1)[0]
+                assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm)
+        assert np.array_equal(outs[66], outs[130]), (M, N, K)
+    # GELU epilogue vs torch
+    a = torch.from_numpy(rng.standard_normal((48, 256)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
+    bias = T(rng.standard_normal(64).astype(np.float32))
+    ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
+    out = nat.dbg_gemm(a, w, bias, epi=1, bm=66, bn=32, splitk=1).float().numpy()
+    assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
+
+
 def test_emu_conv_halo(nat):
     """halo-reuse 3x3 conv (csrc/conv_halo.hip): plain, with fused GroupNorm+SiLU on the input, with residual, one and two
     channel chunks; against the oracle's conv2d / silu on the bf16-rounded operands."""
