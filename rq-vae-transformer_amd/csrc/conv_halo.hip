@@ -1303,15 +1303,13 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (halo_persistent(ups)) {
+    if (ups && halo_persistent(ups)) {      // (the persistent forms of the plain / fused convs measured 0 ... -3 % and spilled: not compiled)
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
         static int cus_per_xcd[16];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (pk_once.first()) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
             (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
@@ -1320,9 +1318,7 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
         const int slots = ((n_mt + 7) / 8) * NT;
         int wpx = g_conv_halo_dbg_wpx > 0 ? g_conv_halo_dbg_wpx : cus_per_xcd[dev & 15];
         if (wpx > slots) wpx = slots;
-        if (ups) RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 1>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
-        else if (a.gn) RQ_LAUNCH((conv3x3_halo_pk_kernel<1, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
-        else RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 1>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
         return rq_check_launch("conv3x3_halo_pk_kernel");
     }
     if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1>), dim3(nblocks), dim3(NTHR), smem, s, a);

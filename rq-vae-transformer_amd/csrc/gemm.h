@@ -1439,6 +1439,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         if (NS >= 3 && newer >= 2) rq_wait_vmcnt<2 * PER>();
         else if (newer >= 1) rq_wait_vmcnt<PER>();
         else rq_wait_vmcnt<0>();
+        rq_wave_sync();                              // every lane's share of the tile has landed
         const char* sb = (const char*)smem + (wave * NS + slot) * SLOT;
         bf16x8 af[MI][4], bfr[4];
 #pragma unroll
@@ -1448,6 +1449,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
             bfr[ks] = as_bf16x8(ld128(sb + A_BYTES + rd[ks]));
         }
         rq_wait_lgkmcnt<0>();                        // the fragments are in registers: the slot may be refilled
+        rq_wave_sync();
         rq_sched_barrier();
         if (i + NS < n_mine) issue(i + NS, slot);
 #pragma unroll

@@ -197,10 +197,6 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
                 if (gl == 2) return tr ? launch_rb<256, 1, 2>(a, stream) : launch_rb<256, 0, 2>(a, stream);
                 return tr ? launch_rb<256, 1, 3>(a, stream) : launch_rb<256, 0, 3>(a, stream);
             }
-            if (bm == 129 && bn == 128) {     // tile code 129x128: 128x128 tile on half-depth stages (three workgroups per CU)
-                if (gl == 2) return tr ? launch_rb<128, 1, 2>(a, stream) : launch_rb<128, 0, 2>(a, stream);
-                return tr ? launch_rb<128, 1, 3>(a, stream) : launch_rb<128, 0, 3>(a, stream);
-            }
 #undef RQ_GL_CASE
         }
     }

@@ -93,6 +93,8 @@ static __device__ __forceinline__ void rq_glds16_s(unsigned lds_base, const void
 template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 template <int N> static __device__ __forceinline__ void rq_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
 static __device__ __forceinline__ void rq_barrier_raw() { __builtin_amdgcn_s_barrier(); }
+// lockstep point of one wavefront (no instruction: a wavefront IS in lockstep; the host emulator, whose lanes are fibers, meets here)
+static __device__ __forceinline__ void rq_wave_sync() { __builtin_amdgcn_wave_barrier(); }
 // pins instruction order at this point (hipcc otherwise sinks independent global loads below LDS writes)
 #define rq_sched_barrier() __builtin_amdgcn_sched_barrier(0)
 #define rq_setprio(x) __builtin_amdgcn_s_setprio(x)

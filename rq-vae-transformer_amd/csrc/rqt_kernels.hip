@@ -36,6 +36,19 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
             t[sl][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (q < E4) t[sl][i] = *(const f32x4*)(p.slabs + sl * slab_stride + base + q * 4);
         }
+    // everything else the kernel reads is requested now as well -- bias / addvec / gamma / beta fetched where they are used were
+    // three more dependent round trips (~1.4 us each on this part) in a kernel that is nothing but latency at small batches
+    // (8448 launches of ~5 us per 64-image batch)
+    f32x4 bv[4], av[4], gv[4], bev[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i, qc = q < E4 ? q : 0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        bv[i] = p.bias ? *(const f32x4*)(p.bias + qc * 4) : z;
+        av[i] = p.addvec ? *(const f32x4*)(p.addvec + qc * 4) : z;
+        gv[i] = p.gamma ? *(const f32x4*)(p.gamma + qc * 4) : z;
+        bev[i] = p.gamma ? *(const f32x4*)(p.beta + qc * 4) : z;
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -43,8 +56,8 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) v[i] += t[sl][i];
         if (q < E4) {
-            if (p.bias) v[i] += *(const f32x4*)(p.bias + q * 4);
-            if (p.addvec) v[i] += *(const f32x4*)(p.addvec + q * 4);
+            if (p.bias) v[i] += bv[i];
+            if (p.addvec) v[i] += av[i];
             if (p.x_out) *(f32x4*)(p.x_out + base + q * 4) = v[i];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void resid_ln_kernel(ResidLnArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int q = tid + 256 * i;
         if (q < E4) {
-            const f32x4 g = *(const f32x4*)(p.gamma + q * 4), b = *(const f32x4*)(p.beta + q * 4);
+            const f32x4 g = gv[i], b = bev[i];
             const uint32_t lo = pack_bf16x2((v[i][0] - mean) * rstd * g[0] + b[0], (v[i][1] - mean) * rstd * g[1] + b[1]);
             const uint32_t hi = pack_bf16x2((v[i][2] - mean) * rstd * g[2] + b[2], (v[i][3] - mean) * rstd * g[3] + b[3]);
             *(uint32_t*)(p.y + base + q * 4) = lo;
@@ -430,11 +443,15 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
 template <int NJ, bool DYN>
 static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t s) {
     const dim3 blk(256);
-    if (pairs_per_wave == 2) {
-        RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
-    } else {
-        RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    // two pairs per wavefront exist only where rq_launch_attn_decode can ask for them (<= 4 register blocks, contexts <= 64):
+    // the long-context forms with two pairs were never launched but were compiled, with 104 spilled registers at 32 blocks
+    if constexpr (!DYN && NJ <= 4) {
+        if (pairs_per_wave == 2) {
+            RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+            return;
+        }
     }
+    RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
 }
 
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {

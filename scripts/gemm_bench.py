@@ -43,8 +43,8 @@ if __name__ == '__main__':
         for name, N, K, epi in shapes:
             best = None
             rows = []
-            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128), (257, 128), (129, 128)):
-                for gl in ((64, 96) if bm in (257, 129) else (0, 64, 96) if bm >= 128 and os.environ.get('RQ_GL', '1') != '0' else (0,)):   # LDS-DMA staging: +64 / +96
+            for bm, bn in ((64, 64), (64, 128), (128, 64), (128, 128), (256, 128), (257, 128)):
+                for gl in ((64, 96) if bm == 257 else (0, 64, 96) if bm >= 128 and os.environ.get('RQ_GL', '1') != '0' else (0,)):   # LDS-DMA staging: +64 / +96
                     for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
                         try:
                             us, tf, gbs, err = bench(M, N, K, epi + gl, bm, bn, sk)

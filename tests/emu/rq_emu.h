@@ -130,12 +130,13 @@ static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
     memcpy(dst, gsrc, 16);
 }
 static inline void rq_glds16_s(uintptr_t lds_base, const void* sbase, unsigned voff) { rq_glds16(lds_base, (const char*)sbase + voff); }
-// A wavefront executes in lockstep: when it passes an s_waitcnt, every lane has issued everything before it.  The emulator runs
-// lanes as fibers, so the waits are modelled as wave-wide rendezvous (a 1-byte exchange) -- kernels whose wavefronts hand data
-// to each other through LDS without a workgroup barrier (gemm_stream_kernel's private LDS-DMA rings) rely on exactly that.
-static inline void rq_emu_wave_rendezvous() { unsigned char z = 0; (void)rqemu::wave_exchange(&z, 1); }
-template <int N> static inline void rq_wait_vmcnt() { rq_emu_wave_rendezvous(); }
-template <int N> static inline void rq_wait_lgkmcnt() { rq_emu_wave_rendezvous(); }
+template <int N> static inline void rq_wait_vmcnt() {}
+template <int N> static inline void rq_wait_lgkmcnt() {}
+// A wavefront executes in lockstep: past any point of the program every lane has issued everything before it.  The emulator runs
+// lanes as fibers, so kernels whose lanes hand data to each other through LDS WITHOUT a workgroup barrier (gemm_stream_kernel's
+// wavefront-private LDS-DMA rings) mark those points with rq_wave_sync(): a wave-wide rendezvous here (a 1-byte exchange), nothing
+// but a scheduling fence on the GPU.
+static inline void rq_wave_sync() { unsigned char z = 0; (void)rqemu::wave_exchange(&z, 1); }
 static inline void rq_barrier_raw() { rqemu::block_barrier(); }
 #define rq_sched_barrier() ((void)0)
 #define rq_setprio(x) ((void)0)
