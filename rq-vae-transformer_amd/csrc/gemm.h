@@ -760,20 +760,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
             // virtual split-K (GemmArgs::vsplit): the same pipelined pair loop, cut into chunks of ppc pairs; at a chunk boundary
             // the accumulators move into the running total (chunk 0: assignment, as the slab reduce starts from slab 0) and restart
             // from zero.  The boundary sits between two pair bodies, so the loads in flight across it are untouched.
+            // One flat loop over the pairs (the nested chunk / pair loops of the first version cost 14-16 % on these kernels: 2-3
+            // pairs per chunk left the software pipeline little to run on between loop boundaries); the fold hangs off the END of a
+            // pair body, where both ways into the next iteration carry the same loads in flight.  tot starts at zero: chunk 0 is
+            // then 0 + acc -- except that (+0) + (-0) = +0 where the slab reduce, which starts FROM slab 0, keeps -0; the sign of
+            // an exact zero is restored below so that the two forms stay bit-identical.
             f32x16 tot[MI][NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tot[i][j][r] = -0.f;      // (-0) + x == x for every x, including x = -0 and x = +0
             const int ppc = npair / p.vsplit;              // launcher: nk == 2 * ppc * vsplit
-            int pi = 0;
-            for (int c = 0; c < p.vsplit; ++c) {
-                for (int e = 0; e < ppc; ++e, ++pi) pair(pi);
+            int left = ppc;
+            for (int pi = 0; pi < npair; ++pi) {
+                pair(pi);
+                if (--left == 0) {
+                    left = ppc;
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
+                        for (int j = 0; j < NI; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            tot[i][j][r] = c == 0 ? acc[i][j][r] : tot[i][j][r] + acc[i][j][r];
-                            acc[i][j][r] = 0.f;
-                        }
+                            for (int r = 0; r < 16; ++r) {
+                                tot[i][j][r] += acc[i][j][r];
+                                acc[i][j][r] = 0.f;
+                            }
+                }
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
