@@ -25,8 +25,9 @@ bytes / decode-attention time, same pass), "roofline_decode" (RQ-VAE decoder con
 the sampled codes), "batch_sweep" (the same measurement at the per-GPU batches SURVEY 8d names: 64 = BASELINE configs[3]
 per-GPU share, 100 / 200 / 500 = the reference's Fig. 4; each with its own roofline and the reference script's
 one-image-per-call loop as "driver_loop"), "per_image_decode" (that loop on its own), "per_image_recon", "roofline_rq"
-(the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the numpy oracle on the host cores, bounded
-sample, rank 0, N=1 only)."""
+(the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the REFERENCE's own modules -- oracle/_ref -- on the
+host cores, one full batch of 16 images, kind "reference"; the numpy oracle port only when oracle/_ref is absent; rank 0,
+N=1 only)."""
 import argparse
 import json
 import os
@@ -120,6 +121,33 @@ def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     if distenv is not None and distenv.world_size > 1:
         pixels = gather_pixels(distenv, pixels)
     return codes, pixels
+
+
+def cpu_baseline_reference(model, top_k, top_p, batch=16):
+    """kind "reference": the REFERENCE's own modules (oracle/_ref: byte-compiled from /root/reference by oracle/build_ref.py,
+    which the build step runs; they travel with the snapshot) on this box's host cores, in a process of their own (their package
+    is also called `rqvae`): RQTransformer.sample -- the reference's Python loop on torch CPU kernels, fp32 -- and the throughput
+    script's one-image-per-call decode + clamp (measure_throughput/__main__.py:293-301) for ONE full batch of `batch` images of
+    the benchmarked model shape.  Nothing is extrapolated.  None when oracle/_ref is absent."""
+    ref_dir = os.path.join(ROOT, 'oracle', '_ref')
+    if not os.path.isdir(os.path.join(ref_dir, 'rqvae')):
+        return None
+    from rqvae import presets
+    arch, vname = presets.RQTRANSFORMER[model]
+    payload = {'rqt': arch, 'vae': {k: presets.RQVAE[vname][k] for k in ('hparams', 'ddconfig')}}
+    cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py'), '--arch', json.dumps(payload), '--batch', str(batch),
+           '--top-k', str(top_k or 0), '--top-p', str(top_p if top_p is not None else 1.0)]
+    env = dict(os.environ)
+    env['HIP_VISIBLE_DEVICES'] = ''                     # the reference leg is a CPU run
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f'oracle/ref_cpu_baseline.py failed: {r.stderr[-400:]}')
+    d = json.loads(lines[-1])
+    return {'value': d['images_per_sec'], 'unit': 'images/sec', 'cores': int(d['threads']), 'kind': 'reference',
+            'sample': f"the reference's own RQTransformer.sample + per-image RQVAE.decode_code + clamp (oracle/_ref), fp32 on torch CPU "
+                      f"kernels: one full batch of {d['batch']} images, top-k {top_k} / top-p {top_p}: {d['ar_s']:.1f} s sampling + "
+                      f"{d['decode_s']:.1f} s decode; nothing extrapolated"}
 
 
 def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):
@@ -661,7 +689,9 @@ def main(argv=None):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(vae, ar, cfg, vcfg)
+            cpu = cpu_baseline_reference(args.model, args.top_k, args.top_p)
+            if cpu is None:                                   # no oracle/_ref on this box: the oracle port, bounded + scaled
+                cpu = cpu_baseline(vae, ar, cfg, vcfg)
         except Exception as e:  # the baseline is reported, never required
             cpu = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e!r}'}
 
