@@ -26,8 +26,8 @@ the sampled codes), "batch_sweep" (the same measurement at the per-GPU batches S
 per-GPU share, 100 / 200 / 500 = the reference's Fig. 4; each with its own roofline and the reference script's
 one-image-per-call loop as "driver_loop"), "per_image_decode" (that loop on its own), "per_image_recon", "roofline_rq"
 (the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the REFERENCE's own modules -- oracle/_ref -- on the
-host cores, one full batch of 16 images, kind "reference"; the numpy oracle port only when oracle/_ref is absent; rank 0,
-N=1 only)."""
+host cores, a bounded sample of a 16-image batch scaled to the metric's unit, kind "reference"; the numpy oracle port only when
+oracle/_ref is absent; rank 0, N=1 only)."""
 import argparse
 import json
 import os
@@ -123,31 +123,38 @@ def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     return codes, pixels
 
 
-def cpu_baseline_reference(model, top_k, top_p, batch=16):
+def cpu_baseline_reference(model, top_k, top_p, batch=16, positions=8, n_dec=4, threads=16):
     """kind "reference": the REFERENCE's own modules (oracle/_ref: byte-compiled from /root/reference by oracle/build_ref.py,
     which the build step runs; they travel with the snapshot) on this box's host cores, in a process of their own (their package
-    is also called `rqvae`): RQTransformer.sample -- the reference's Python loop on torch CPU kernels, fp32 -- and the throughput
-    script's one-image-per-call decode + clamp (measure_throughput/__main__.py:293-301) for ONE full batch of `batch` images of
-    the benchmarked model shape.  Nothing is extrapolated.  None when oracle/_ref is absent."""
+    is also called `rqvae`).  Bounded sample of the benchmarked workload (~10-30 s of CPU work): RQTransformer.sample -- the
+    reference's Python loop on torch CPU kernels, fp32, KV cache on -- over the LAST `positions` of the 64 spatial positions of a
+    batch of `batch` images (start_loc: the reference prefills the prefix in its first cached step), scaled to 64 positions,
+    plus the throughput script's one-image-per-call decode_code + clamp (measure_throughput/__main__.py:297-300) of `n_dec`
+    images.  `threads` torch threads: with all 128 hardware threads of the box the same code is ~10x slower (a full 16-image
+    batch took 488 s + 47.5 s there: every small op pays a 128-way fork/join).  None when oracle/_ref is absent."""
     ref_dir = os.path.join(ROOT, 'oracle', '_ref')
     if not os.path.isdir(os.path.join(ref_dir, 'rqvae')):
         return None
     from rqvae import presets
     arch, vname = presets.RQTRANSFORMER[model]
     payload = {'rqt': arch, 'vae': {k: presets.RQVAE[vname][k] for k in ('hparams', 'ddconfig')}}
+    threads = max(1, min(threads, os.cpu_count() or threads))
     cmd = [sys.executable, os.path.join(ROOT, 'oracle', 'ref_cpu_baseline.py'), '--arch', json.dumps(payload), '--batch', str(batch),
-           '--top-k', str(top_k or 0), '--top-p', str(top_p if top_p is not None else 1.0)]
+           '--top-k', str(top_k or 0), '--top-p', str(top_p if top_p is not None else 1.0), '--positions', str(positions),
+           '--decode', str(n_dec), '--threads', str(threads)]
     env = dict(os.environ)
     env['HIP_VISIBLE_DEVICES'] = ''                     # the reference leg is a CPU run
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    env['OMP_NUM_THREADS'] = str(threads)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     if r.returncode != 0 or not lines:
         raise RuntimeError(f'oracle/ref_cpu_baseline.py failed: {r.stderr[-400:]}')
     d = json.loads(lines[-1])
     return {'value': d['images_per_sec'], 'unit': 'images/sec', 'cores': int(d['threads']), 'kind': 'reference',
-            'sample': f"the reference's own RQTransformer.sample + per-image RQVAE.decode_code + clamp (oracle/_ref), fp32 on torch CPU "
-                      f"kernels: one full batch of {d['batch']} images, top-k {top_k} / top-p {top_p}: {d['ar_s']:.1f} s sampling + "
-                      f"{d['decode_s']:.1f} s decode; nothing extrapolated"}
+            'sample': f"the reference's own modules (oracle/_ref), fp32 on torch CPU kernels, {d['threads']} threads: RQTransformer.sample over the "
+                      f"last {d['positions']} of {d['of_positions']} spatial positions of a batch of {d['batch']} (prefix prefilled by its first "
+                      f"cached step; top-k {top_k} / top-p {top_p}) = {d['ar_s']:.1f} s, scaled x{d['of_positions'] / d['positions']:.0f} -> "
+                      f"{d['ar_s_per_image']:.2f} s/img; per-image RQVAE.decode_code + clamp of {d['decoded']} images = {d['decode_s_per_image']:.2f} s/img"}
 
 
 def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):

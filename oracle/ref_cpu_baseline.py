@@ -20,6 +20,9 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--top-k', type=int, default=0)
     ap.add_argument('--top-p', type=float, default=1.0)
+    ap.add_argument('--positions', type=int, default=0, help='sample only the last N spatial positions (start_loc; the prefix is prefilled in one pass); 0 = all')
+    ap.add_argument('--decode', type=int, default=0, help='decode only the first N images of the batch; 0 = all')
+    ap.add_argument('--threads', type=int, default=0)
     a = ap.parse_args()
     stub = types.ModuleType('omegaconf')            # the one import the model files make that this image lacks (configs.py:18)
     stub.OmegaConf = type('OmegaConf', (), {})
@@ -42,6 +45,8 @@ def main():
     def to_cfg(d):
         return Cfg({k: to_cfg(v) if isinstance(v, dict) else v for k, v in d.items()})
     arch = json.loads(a.arch)
+    if a.threads > 0:
+        torch.set_num_threads(a.threads)
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     vae = RQVAE(**arch['vae']['hparams'], ddconfig=arch['vae']['ddconfig'], checkpointing=False).eval()
@@ -51,14 +56,24 @@ def main():
     empty_cond = torch.zeros(B, ar.block_size_cond, dtype=torch.long)
     top_k = a.top_k if a.top_k > 0 else None
     top_p = a.top_p if a.top_p < 1.0 else None
+    H, W, D = ar.block_size
+    n_pos = a.positions if 0 < a.positions < H * W else H * W
+    first = H * W - n_pos
+    n_dec = a.decode if 0 < a.decode < B else B
     t0 = time.time()
-    codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=top_k, top_p=top_p)
+    # start_loc: the reference skips the positions before it and prefills them (whatever partial_sample holds there) in the first
+    # cached step (transformers.py:346-350) -- a bounded sample of the 64-position loop: n_pos positions + one prefill pass
+    codes = ar.sample(empty_sample, model_aux=vae, cond=empty_cond, top_k=top_k, top_p=top_p, start_loc=(first // W, first % W))
     t1 = time.time()
-    pixels = torch.cat([vae.decode_code(chunk) for chunk in codes.chunk(B)], dim=0)
+    pixels = torch.cat([vae.decode_code(chunk) for chunk in codes[:n_dec].chunk(n_dec)], dim=0)
     _ = (0.5 * pixels + 0.5).clamp(0, 1)
     t2 = time.time()
-    print(json.dumps({'batch': B, 'ar_s': t1 - t0, 'decode_s': t2 - t1, 'images_per_sec': B / (t2 - t0), 'threads': torch.get_num_threads(),
-                      'pixels_shape': list(pixels.shape), 'codes_in_range': bool(int(codes.min()) >= 0 and int(codes.max()) < arch['rqt']['vocab_size'])}))
+    ar_s_img = (t1 - t0) * (H * W / n_pos) / B          # seconds per image, scaled from n_pos positions (+ the prefill) to H * W
+    dec_s_img = (t2 - t1) / n_dec
+    print(json.dumps({'batch': B, 'positions': n_pos, 'of_positions': H * W, 'decoded': n_dec, 'ar_s': t1 - t0, 'decode_s': t2 - t1,
+                      'images_per_sec': 1.0 / (ar_s_img + dec_s_img), 'ar_s_per_image': ar_s_img, 'decode_s_per_image': dec_s_img,
+                      'threads': torch.get_num_threads(), 'pixels_shape': list(pixels.shape),
+                      'codes_in_range': bool(int(codes.min()) >= 0 and int(codes.max()) < arch['rqt']['vocab_size'])}))
 
 
 if __name__ == '__main__':
