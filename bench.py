@@ -26,7 +26,7 @@ the sampled codes), "batch_sweep" (the same measurement at the per-GPU batches S
 per-GPU share, 100 / 200 / 500 = the reference's Fig. 4; each with its own roofline and the reference script's
 one-image-per-call loop as "driver_loop"), "per_image_decode" (that loop on its own), "per_image_recon", "roofline_rq"
 (the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the REFERENCE's own modules -- oracle/_ref -- on the
-host cores, a bounded sample of a 16-image batch scaled to the metric's unit, kind "reference"; the numpy oracle port only when
+host cores, a bounded sample of a 32-image batch scaled to the metric's unit, kind "reference"; the numpy oracle port only when
 oracle/_ref is absent; rank 0, N=1 only)."""
 import argparse
 import json
@@ -123,7 +123,7 @@ def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
     return codes, pixels
 
 
-def cpu_baseline_reference(model, top_k, top_p, batch=16, positions=8, n_dec=4, threads=16):
+def cpu_baseline_reference(model, top_k, top_p, batch=32, positions=16, n_dec=8, threads=16):
     """kind "reference": the REFERENCE's own modules (oracle/_ref: byte-compiled from /root/reference by oracle/build_ref.py,
     which the build step runs; they travel with the snapshot) on this box's host cores, in a process of their own (their package
     is also called `rqvae`).  Bounded sample of the benchmarked workload (~10-30 s of CPU work): RQTransformer.sample -- the
