@@ -21,7 +21,12 @@ OUT = os.path.join(HERE, '_ref')
 # the modules the sampling path imports (rqvae.models -> rqvae.utils.utils, rqvae.optimizer.loss); nothing of the trainers,
 # datasets or metrics
 WANT = ['rqvae/__init__.py', 'rqvae/models/**/*.py', 'rqvae/utils/__init__.py', 'rqvae/utils/utils.py',
-        'rqvae/optimizer/*.py']
+        'rqvae/optimizer/*.py',
+        # the reference's throughput DRIVER, unchanged: tests/test_gpu_reference_driver.py runs its bytecode on the MI355X on top
+        # of this repo's rqvae package (rqamd_run.py -m measure_throughput with RQVAE_REFERENCE_ROOT=oracle/_ref)
+        'measure_throughput/__main__.py']
+# data files the compiled modules open next to themselves: parsed here and re-emitted (JSON is YAML), not copied
+DATA = ['measure_throughput/rq_defaults.yaml']
 
 
 def build(verbose=True):
@@ -39,6 +44,13 @@ def build(verbose=True):
             os.makedirs(os.path.dirname(dst), exist_ok=True)
             py_compile.compile(src, cfile=dst, dfile=rel, doraise=True, optimize=0)
             n += 1
+    import json
+    import yaml
+    for rel in DATA:
+        with open(os.path.join(REF, rel)) as f:
+            parsed = yaml.safe_load(f)
+        with open(os.path.join(OUT, rel), 'w') as f:
+            json.dump(parsed, f)
     with open(os.path.join(OUT, 'README'), 'w') as f:
         f.write('byte-compiled modules of kakaobrain/rq-vae-transformer (see oracle/build_ref.py); build output, not source\n')
     if verbose:
