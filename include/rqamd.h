@@ -192,7 +192,8 @@ int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream);
 /* timing hook for bench.py: average device time (ms) of the engine's weight-streaming GEMM launches
  * during the last rqamd_rqt_sample call is not observable from outside the stream, so the engine can
  * bracket every GEMM launch of one call with HIP events (profile != 0 disables graphs for that call). */
-int rqamd_rqt_set_profile(rqamd_rqt* h, int profile);
+int rqamd_rqt_set_profile(rqamd_rqt* h, int profile);   /* 0 off; 1 events around every GEMM / attention launch (eager); 2 skip the
+                                                          * GEMM launches (graphs on): pass time minus this = the GEMMs' time in situ */
 int rqamd_rqt_get_profile(rqamd_rqt* h, double* gemm_ms_total, int64_t* gemm_launches,
                           double* gemm_bytes_total, double* gemm_flops_total);
 /* the cached-attention launches (MultiSelfAttention.forward with the KV cache, attentions.py:60-104) of the same profiled call:

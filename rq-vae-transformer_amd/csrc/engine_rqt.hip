@@ -40,6 +40,10 @@ struct GemmProfile {
     size_t used_attn = 0;
     double attn_ms_total = 0;
     int64_t attn_launches = 0;
+    // profile == 2: the decode-step GEMM launches are SKIPPED (graphs stay on; everything else runs, on garbage).  The time of a
+    // sampling pass minus the time of the same pass without its GEMMs is what the GEMMs cost inside the captured graphs --
+    // bracketing every launch with events (profile == 1) runs eagerly and adds the dispatch latency of two markers to a ~7-us kernel.
+    bool skip_gemm = false;
 };
 
 struct rqamd_rqt {
@@ -386,6 +390,7 @@ static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, in
     a.glds = gl;
     if (n_slabs) *n_slabs = sk;
     GemmProfile& pf = h->prof;
+    if (pf.skip_gemm) return RQAMD_OK;
     if (pf.on) {
         if (pf.used + 2 > pf.ev.size()) {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; RQ_HIP(hipEventCreate(&e)); pf.ev.push_back(e); }
@@ -766,7 +771,9 @@ extern "C" int rqamd_rqt_step_end(rqamd_rqt* h, int64_t* codes_out, void* stream
 
 extern "C" int rqamd_rqt_set_profile(rqamd_rqt* h, int profile) {
     if (!h) return rq_fail(RQAMD_ERR_INVALID, "null handle");
-    h->prof.on = profile != 0;
+    h->prof.on = profile == 1;
+    if (h->prof.skip_gemm != (profile == 2)) h->gvalid = false;      // the captured graphs hold (or lack) the GEMM nodes
+    h->prof.skip_gemm = profile == 2;
     return RQAMD_OK;
 }
 extern "C" int rqamd_rqt_get_profile_attn(rqamd_rqt* h, double* ms, int64_t* launches) {

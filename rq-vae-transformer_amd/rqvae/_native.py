@@ -558,8 +558,10 @@ class RqtEngine(_Engine):
         self._step = None
         return out
 
-    def set_profile(self, on):
-        check(lib().rqamd_rqt_set_profile(self._h, int(bool(on))))
+    def set_profile(self, mode):
+        """0 / False: off; 1 / True: HIP events around every GEMM / attention launch (eager launches); 2: skip the GEMM launches (graphs
+        stay on) -- a sampling pass timed with and without them gives the GEMMs' time inside the graphs."""
+        check(lib().rqamd_rqt_set_profile(self._h, int(mode)))
 
     def get_profile(self):
         ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
