@@ -722,8 +722,12 @@ def main(argv=None):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline_reference(args.model, args.top_k, args.top_p)
-            if cpu is None:                                   # no oracle/_ref on this box: the oracle port, bounded + scaled
+            try:
+                cpu = cpu_baseline_reference(args.model, args.top_k, args.top_p)
+            except Exception as e:                            # e.g. bytecode of another CPython: say so, use the port
+                print(f'bench.py: reference CPU leg failed ({e!r}); falling back to the oracle port', file=sys.stderr)
+                cpu = None
+            if cpu is None:                                   # no usable oracle/_ref on this box: the oracle port, bounded + scaled
                 cpu = cpu_baseline(vae, ar, cfg, vcfg)
         except Exception as e:  # the baseline is reported, never required
             cpu = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e!r}'}
