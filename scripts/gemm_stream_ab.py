@@ -11,7 +11,8 @@ import torch  # noqa: E402
 from rqvae import _native  # noqa: E402
 
 dev = 'cuda'
-SHAPES = (('qkv', 4608, 1536, 0), ('proj', 1536, 1536, 4), ('fc1', 6144, 1536, 1), ('fc2', 1536, 6144, 4), ('cls', 16384, 1536, 3))
+E = int(os.environ.get('RQ_E', 1536))      # 1536: the 1.4B model; 2560: the 3.8B model (BASELINE configs[3]); 1024: the 355M model
+SHAPES = (('qkv', 3 * E, E, 0), ('proj', E, E, 4), ('fc1', 4 * E, E, 1), ('fc2', E, 4 * E, 4), ('cls', 16384 if E != 1024 else 2048, E, 3))
 
 
 def timed(fn, reps=60):
@@ -40,20 +41,20 @@ for M in [int(x) for x in os.environ.get('RQ_MS', '8,64,100,128,256,500').split(
         res = []
         out_old = _native.dbg_gemm(a, ws[0], b, epi, 0, 0, 0)
         t_old = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, 0, 0, 0, out=out_old))
-        bm = 66 if M <= 64 else 130
         best = None
-        for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
-            if (K // 64) % sk:
-                continue
-            out = _native.dbg_gemm(a, ws[0], b, epi, bm, 32, sk)
-            got = out.float().sum(0) if epi == 4 else out.float()
-            err = ((got - ref).abs().max() / ref.abs().max()).item()
-            t = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, bm, 32, sk, out=out))
-            res.append(f'sk{sk}:{t:5.1f}')
-            if best is None or t < best[0]:
-                best = (t, sk, err)
+        for bm in ((66,) if M <= 64 else (130,)):
+            for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
+                if (K // 64) % sk:
+                    continue
+                out = _native.dbg_gemm(a, ws[0], b, epi, bm, 32, sk)
+                got = out.float().sum(0) if epi == 4 else out.float()
+                err = ((got - ref).abs().max() / ref.abs().max()).item()
+                t = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, bm, 32, sk, out=out))
+                res.append(f'{bm}sk{sk}:{t:5.1f}')
+                if best is None or t < best[0]:
+                    best = (t, f'{bm}/sk{sk}', err)
         tot_old += t_old if name != 'cls' else 0
         tot_new += best[0] if name != 'cls' else 0
-        print(f'M={M:4d} {name:5s} N={N:5d} K={K:5d}: tiled/auto {t_old:6.1f} us | stream {best[0]:6.1f} us (sk{best[1]}, err {best[2]:.1e}; '
+        print(f'M={M:4d} {name:5s} N={N:5d} K={K:5d}: tiled/auto {t_old:6.1f} us | stream {best[0]:6.1f} us ({best[1]}, err {best[2]:.1e}; '
               f'{N * K * 2 / best[0] / 1e6:5.2f} TB/s of weights) [{" ".join(res)}]', flush=True)
-    print(f'M={M:4d}: GEMMs of one layer: {tot_old:6.1f} -> {tot_new:6.1f} us', flush=True)
+    print(f'M={M:4d}: GEMMs of one layer (E = {E}, weights {12 * E * E * 2 / 1e6:.0f} MB): {tot_old:6.1f} -> {tot_new:6.1f} us', flush=True)
