@@ -11,6 +11,11 @@ Pinning: the reference ships no tests or golden vectors, so the
 oracle is pinned against outputs of the reference itself, imported on CPU in the
 build container by ``tests/golden/make_golden.py`` (fixtures committed under
 ``tests/golden/``; ``tests/test_oracle_golden.py`` re-checks them on every run).
+
+``oracle/_ref/`` (git-ignored build output of ``oracle/build_ref.py``) holds the reference's own modules and its
+throughput driver as sourceless bytecode; it is used only by ``bench.py``'s ``cpu_baseline`` leg (through
+``oracle/ref_cpu_baseline.py``, a process of its own) and by ``tests/test_gpu_reference_driver.py`` /
+``tests/test_oracle_ref.py``.  Importing this package never touches it.
 """
 from . import backend  # noqa: F401
 from .weights import make_params, rqvae_param_shapes, rqt_param_shapes  # noqa: F401
