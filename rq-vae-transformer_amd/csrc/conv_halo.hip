@@ -32,6 +32,25 @@ struct ConvHaloArgs {
     int B, H, W, Cin, Cout;
 };
 
+// SiLU of an argument that arrives pre-multiplied by log2 e (the GroupNorm scale / shift are scaled once per chunk):
+// t = a log2 e  ->  a / (1 + e^-a) = t / (log2 e + log2 e * 2^-t): fma, v_exp (negated input), fma, v_rcp, mul -- one VALU
+// instruction per element less than a * rcp(1 + exp2(-log2e * a)), in the issue-bound fused tap loop.
+#define RQ_LOG2E 1.4426950408889634f
+static __device__ __forceinline__ float rq_silu_l2(float t) { return t * rq_fast_rcp(fmaf(rq_fast_exp2(-t), RQ_LOG2E, RQ_LOG2E)); }
+
+// GroupNorm partial sums of one 16-byte piece (8 bf16 channels) on its way out of the epilogue: sum and sum of squares per
+// channel PAIR straight from the packed words (v_dot2c_f32_bf16: acc += lo * lo' + hi * hi' in fp32, products of two bf16 are
+// exact) -- 8 instructions per piece instead of 8 unpacks + 8 adds + 8 fmas (the statistics were ~2400 cycles of a fused tile's
+// epilogue, profiles/r02_conv_halo_barrier_timeline.txt).
+static __device__ __forceinline__ void rq_stats_piece(const rq_u128& u, float (&sum)[4], float (&sq)[4]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sum[e] = rq_dot2_bf16(w[e], 0x3f803f80u, sum[e]);
+        sq[e] = rq_dot2_bf16(w[e], w[e], sq[e]);
+    }
+}
+
 constexpr int HT_H = 8, HT_W = 32;                 // output tile
 constexpr int HP_W = HT_W + 2;                     // halo patch of the plain conv: 34 x 10 = 340 pixels
 constexpr int H_BN = 128;
@@ -73,7 +92,7 @@ __device__ unsigned long long g_conv_trace[8 * 64];
 #else
 #define RQ_CT(slot) do { } while (0)
 #endif
-template <int FUSE_GN, int UPS>
+template <int FUSE_GN, int UPS, int RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     constexpr int TH = HT_H, NTH = 512, RPW = 2, NJ = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3, W_SLOTS = 3;
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
@@ -103,58 +122,99 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
     const int n0 = nt * H_BN;
 
+    // ---- The tile's first five weight units and its first patch are requested BEFORE the rest of the set-up.  The kernel
+    // issued its first global load as instruction ~310 (patch descriptors with their divisions, LDS offsets, the bias, fragment
+    // addresses all came first), and a workgroup's second four wavefronts -- the losers of the SIMD's issue arbitration -- got
+    // through that code ~6000 cycles after the first four: the prologue barrier waited ~9000 cycles of a 40 000-cycle tile for
+    // THEIR loads (barrier timeline, profiles/r03_conv_halo_ab2_timeline.txt).  The loads only need the tile coordinates.
+    const char* gX = (const char*)p.x;
+    const char* gWt = (const char*)p.w;
+    // weight staging: 128 rows x 8 chunks = 1024 chunks, W_IT per thread
+    const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row + (NTH / 8) i
+    unsigned w_goff[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) w_goff[i] = (unsigned)(((long)(n0 + w_row + (NTH / 8) * i) * 9 * p.Cin + w_c8 * 8) * 2);
+    auto load_w = [&](int c, int tap, rq_u128* rw) {
+        const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
+    };
+    rq_u128 rh[H_IT], rw[W_SETS][W_IT], r01[2][W_IT];
+    // weight units 0..4 of the tile (0, 1 go to LDS before the first barrier; 2, 3, 4 wait in register sets 2, 0, 1)
+    load_w(0, 0, r01[0]);
+    load_w(0, 1, r01[1]);
+    load_w(0, 2, rw[2]);
+    load_w(0, 3, rw[0]);
+    load_w(0, 4, rw[1]);
+    rq_sched_barrier();
+
     // ---- halo staging bookkeeping (loop-invariant), ONE packed register per piece: source pixel index inside the image
     // (16 bits: H * W <= 65536, clamped into the image so that every load is readable), LDS offset in 16-byte units
-    // (13 bits), "inside the image" (bit 29: else the piece is stored as zeros) and "piece exists" (bit 30)
+    // (13 bits), "inside the image" (bit 29: else the piece is stored as zeros) and "piece exists" (bit 30).  Piece `it` is
+    // 16-byte chunk tid & 7 of patch pixel (tid >> 3) + 64 it: one division for piece 0, then steps of 64 pixels.
     unsigned hd[H_IT];
     const int Hs = UPS ? p.H >> 1 : p.H, Ws = UPS ? p.W >> 1 : p.W;                       // source image
-#pragma unroll
-    for (int it = 0; it < H_IT; ++it) {
-        const int q = tid + NTH * it;
-        const int hp = q >> 3, c8 = q & 7;
-        const bool in = hp < HP_N;
-        const int hy = hp / PW, hx = hp - hy * PW;
-        const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
-        const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
-        const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
-        const unsigned loff16 = in ? halo_lds_off<PW>(hy, hx, c8) >> 4 : 0u;
-        hd[it] = (unsigned)(cy * Ws + cx) | (loff16 << 16) | (ok ? 1u << 29 : 0u) | (in ? 1u << 30 : 0u);
-    }
     const unsigned x_img = (unsigned)((long)img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);   // bytes; < 4 GiB (launcher)
     const unsigned cin2 = (unsigned)p.Cin * 2u;
+    const int hp0 = tid >> 3, hy0 = hp0 / PW, hx0 = hp0 - hy0 * PW;
+    // pass 1: the clamped source pixel of every piece, and its load on the way at once (chunk 0)
+    {
+        int hy = hy0, hx = hx0;
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
+            const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
+            hd[it] = (unsigned)(cy * Ws + cx);
+            rh[it] = ld128(gX + (x_img + hd[it] * cin2));
+            hy += (NTH / 8) / PW; hx += (NTH / 8) % PW;
+            if (hx >= PW) { hx -= PW; ++hy; }
+        }
+    }
+    const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
+    // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7)
+    f32x4 gs[4];
+    auto load_gs = [&](int c) {
+        if (FUSE_GN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2) * RQ_LOG2E;
+        }
+    };
+    load_gs(0);
+    rq_sched_barrier();
+    // pass 2: LDS offset and flags
+    {
+        int hp = hp0, hy = hy0, hx = hx0;
+        const int c8 = tid & 7;
+#pragma unroll
+        for (int it = 0; it < H_IT; ++it) {
+            const bool in = hp < HP_N;
+            const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
+            const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            const unsigned loff16 = in ? halo_lds_off<PW>(hy, hx, c8) >> 4 : 0u;
+            hd[it] |= (loff16 << 16) | (ok ? 1u << 29 : 0u) | (in ? 1u << 30 : 0u);
+            hp += NTH / 8; hy += (NTH / 8) / PW; hx += (NTH / 8) % PW;
+            if (hx >= PW) { hx -= PW; ++hy; }
+        }
+    }
     auto h_in = [&](int it) { return (hd[it] >> 30) & 1u; };
     auto h_ok = [&](int it) { return (hd[it] >> 29) & 1u; };
     auto h_loff = [&](int it) { return ((hd[it] >> 16) & 0x1fffu) << 4; };
     auto h_goff = [&](int it) { return x_img + (hd[it] & 0xffffu) * cin2; };
-    // weight staging: 128 rows x 8 chunks = 1024 chunks, W_IT per thread
-    const int w_row = tid >> 3, w_c8 = tid & 7;    // rows w_row + (NTH / 8) i
-    unsigned w_goff[W_IT], w_loff[W_IT];
+    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
+
+    unsigned w_loff[W_IT];
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         const int r = w_row + (NTH / 8) * i;
-        w_goff[i] = (unsigned)(((long)(n0 + r) * 9 * p.Cin + w_c8 * 8) * 2);
         w_loff[i] = (unsigned)(r * 128 + ((w_c8 ^ ((r >> 1) & 7)) << 4));
     }
-    const char* gX = (const char*)p.x;
-    const char* gWt = (const char*)p.w;
-    const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
-
-    // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7)
-    f32x4 gs[4];
-    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
-    auto load_gs = [&](int c) {
-        if (FUSE_GN) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
-        }
-    };
     // one 16-byte piece of the patch: registers -> (GroupNorm + SiLU) -> LDS.  The fused form is spread over
     // the taps of a chunk (one piece per tap) so that its VALU / transcendental work issues under the MFMAs;
     // done in one lump before the barrier it cost +73 % on the 128->128 @256^2 layer.
     auto halo_piece_value = [&](const rq_u128* rh, int it) -> rq_u128 {
         rq_u128 v = rh[it];
         if (FUSE_GN) {
-            // 8 channels of this image: y = silu(x * scale + shift) = a / (1 + 2^(-a log2 e))
+            // 8 channels of this image: y = silu(x * scale + shift), (scale, shift) pre-multiplied by log2 e (rq_silu_l2)
             float f[8];
             f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
             f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
@@ -164,8 +224,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
             for (int e = 0; e < 8; e += 2) {
                 const f32x4 ss = gs[e >> 1];                              // (scale, shift) x 2 channels
                 const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
-                f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
-                f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+                f[e] = rq_silu_l2(a);
+                f[e + 1] = rq_silu_l2(b);
             }
             v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
             v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
@@ -174,20 +234,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         return v;
     };
     // a quarter of that: channels 2e, 2e+1 of piece `it` (one 32-bit word), for the k-step regions of the tap loop
+    auto halo_word = [&](rq_u128* rh, int it, int e) -> uint32_t& { return e == 0 ? rh[it].x : e == 1 ? rh[it].y : e == 2 ? rh[it].z : rh[it].w; };
     auto halo_piece_word = [&](rq_u128* rh, int it, int e) {
-        uint32_t& w = e == 0 ? rh[it].x : e == 1 ? rh[it].y : e == 2 ? rh[it].z : rh[it].w;
+        uint32_t& w = halo_word(rh, it, e);
         if (FUSE_GN) {
             const f32x4 ss = gs[e];                                       // (scale, shift) x 2 channels
             const float a = fmaf(__uint_as_float(w << 16), ss[0], ss[1]), b = fmaf(__uint_as_float(w & 0xffff0000u), ss[2], ss[3]);
-            w = pack_bf16x2(a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a)),
-                            b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b)));
+            w = pack_bf16x2(rq_silu_l2(a), rq_silu_l2(b));
         }
         if (!h_ok(it)) w = 0u;                     // zero padding of the (normalised) input
-    };
-    auto load_w = [&](int c, int tap, rq_u128* rw) {
-        const unsigned kb = (unsigned)(tap * p.Cin + c * 64) * 2u;
-#pragma unroll
-        for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
     };
     auto store_w = [&](int wslot, const rq_u128* rw) {
 #pragma unroll
@@ -240,24 +295,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // g - 5 that fetches it to the start of tap g - 2 that stores it into LDS slot g % 3 (9 taps per chunk keep both
     // rotations static under the unrolled tap loop): the L2 round trip (~1 us under load) is longer than a tap.
     const int NC = p.Cin / 64, last_c = NC - 1;
-    rq_u128 rh[H_IT], rw[W_SETS][W_IT];
     auto load_unit = [&](int c, int tap, rq_u128* r) {      // unit (c, tap), tap may run into the next chunk; false: past the end
         if (tap >= 9) { tap -= 9; ++c; }
         if (c > last_c) return false;
         load_w(c, tap, r);
         return true;
     };
-    // prologue: patch of chunk 0, weight units 0..4 (0, 1 go to LDS now; 2, 3, 4 wait in register sets 2, 0, 1)
+    // prologue: patch of chunk 0 and weight units 0, 1 (requested at the top of the kernel) go to LDS
     {
-        rq_u128 r01[2][W_IT];
-#pragma unroll
-        for (int it = 0; it < H_IT; ++it) load_halo_piece(0, rh, it);
-        load_gs(0);
-        load_w(0, 0, r01[0]);
-        load_w(0, 1, r01[1]);
-        load_w(0, 2, rw[2]);
-        load_w(0, 3, rw[0]);
-        load_w(0, 4, rw[1]);
         RQ_CT(0);
 #pragma unroll
         for (int it = 0; it < H_IT; ++it)
@@ -272,9 +317,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // patch registers are idle, so the epilogue starts with the data in hand
     constexpr int CPR = H_BN / 8;
     constexpr int R_IT = TPX * CPR / NTH;          // 8
-    static_assert(R_IT <= 8, "one residual piece per tap");
+    static_assert(R_IT == 8, "two residual pieces per tap in the first four taps of the last chunk");
     rq_u128 rr[R_IT];
     const bf16_t* rsrc = p.resid;
+    // Piece k of thread tid is 16-byte chunk (tid & 15) of pixel (tid >> 4) of tile row k -- of the residual tile and, in the
+    // epilogue, of the output tile (same [B][H][W][Cout] layout): one base offset and a row step.  (Written as cidx = tid +
+    // NTH k -> (ml, nl) -> (ty, tx) -> pix the compiler derived every piece's address separately: ~120 VALU instructions in one
+    // lump at the start of the last chunk and again in the epilogue.)
+    static_assert(CPR == 16 && NTH / CPR == HT_W && R_IT == TH, "piece k = tile row k");
+    const unsigned io_off0 = (unsigned)((((long)img * p.H + ty0) * p.W + tx0 + (tid >> 4)) * p.Cout + n0 + (tid & 15) * 8) * 2u;   // bytes; < 4 GiB (launcher)
+    const unsigned io_step = (unsigned)p.W * (unsigned)p.Cout * 2u;
     // one chunk of the reduction; LAST (compile time): no next patch to stage -- fetch the residual instead
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -304,12 +356,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                     if (t_load == tap) load_halo_piece(c + 1, rh, it);
                 }
             }
-            if (LAST && tap >= 1 && p.resid) {             // uniform
-                const int k = tap - 1;
-                const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-                const int ty = ml / HT_W, tx = ml - ty * HT_W;
-                const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-                rr[k] = ld128(rsrc + pix * p.Cout + n0 + nl);
+            if (LAST && RES && tap < R_IT / 2) {           // (a template parameter, not `if (p.resid)`: behind a run-time branch the
+                                                           // compiler's vmcnt for this tap's store_w assumed no residual loads in
+                                                           // flight and so also waited for the weight tile fetched two taps ago)
+                // two pieces per tap in the FIRST four taps: the tile is an old activation (HBM, not the L2), and a piece fetched
+                // in tap 8 was still on its way when the epilogue wanted it (~1200 cycles of the epilogue, barrier timeline in
+                // profiles/r03_conv_halo_barrier_timeline.txt)
+                rr[2 * tap] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap) * io_step));
+                rr[2 * tap + 1] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap + 1) * io_step));
             }
             rq_sched_barrier();
             // ---- four k-step regions: reads of the next k-step (the last one: of the coming tap's first k-step -- its slot and
@@ -324,18 +378,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 if (false) {}
                 else
 #endif
+                // (the accumulators are made opaque at the head of every region for the same reason as the patch words below:
+                // an MFMA is register-only, and before instruction selection nothing kept it from rising above the region's
+                // fragment reads -- or above the previous sched_barrier: the reads of k-step ks + 1 then came out BEHIND the MFMAs
+                // of k-step ks, back to back with those of ks + 2, and the next MFMA waited out a full LDS round trip)
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) rq_opaque_acc(acc[i][j]);
                 if (ks < 3) load_frags(hbuf, tap % W_SLOTS, ky, kx, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
                 else if (tap < 8) load_frags(hbuf, (tap + 1) % W_SLOTS, (tap + 1) / 3, (tap + 1) % 3, 0, fa[0], fb[0]);
                 else if (!LAST) load_frags(hbuf ^ 1, 0, 0, 0, 0, fa[0], fb[0]);
                 mfma_step(ks & 1);
+                // The word's arithmetic is pinned INSIDE this region by making its input opaque here and its result opaque before
+                // the region closes: left alone, hipcc hoisted the whole tap's GroupNorm + SiLU (pure register arithmetic, which no
+                // sched_barrier holds back before instruction selection) to the top of the tap, or sank it below the last MFMA --
+                // 70-150 VALU / transcendental instructions in one lump with the matrix pipe idle on both wavefronts of the SIMD
+                // (disassembly before / after: profiles/r03_conv_halo_isa_interleave.txt).
+                if (FUSE_GN && ptap) rq_opaque_u(halo_word(rh, pi, ks));
                 if (ptap) halo_piece_word(rh, pi, ks);
+                if (FUSE_GN && ptap) rq_opaque_u(halo_word(rh, pi, ks));
                 // issue order inside the region: the fragment reads FIRST (a full k-step of MFMAs covers their latency), then the
-                // MFMAs, each carrying a slice of the piece's VALU work
+                // MFMAs, each carrying a slice of the piece's VALU work (10 VALU + 4 transcendental instructions per word)
                 rq_sched_group(0x100, RPW + NJ);
 #pragma unroll
                 for (int m = 0; m < RPW * NJ; ++m) {
                     rq_sched_group(0x008, 1);
-                    if (FUSE_GN && ptap) rq_sched_group(0x002, 7);
+                    if (FUSE_GN && ptap) { rq_sched_group(0x002, 3); rq_sched_group(0x400, 1); }
                 }
                 rq_sched_barrier();
             }
@@ -353,22 +422,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     static_assert(TPX * LDR + 4096 <= 160 * 1024, "epilogue tile must fit the CU's LDS (the launcher allocates max(staging, epilogue))");
     char* sT = (char*)smem;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
-    if (p.resid) {
+    if (RES) {
         // the residual tile (fetched as row-contiguous 16-byte pieces during the last taps) waits in the LDS tile, where
         // the lane that owns an 8-byte slot adds it in fp32 before the single rounding and overwrites it in place (the
         // per-lane 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
 #pragma unroll
-        for (int k = 0; k < R_IT; ++k) {
-            const int cidx = tid + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-            st128(sT + ml * LDR + nl * 2, rr[k]);
-        }
+        for (int k = 0; k < R_IT; ++k) st128(sT + ((tid >> 4) + HT_W * k) * LDR + (tid & 15) * 16, rr[k]);
         rq_syncthreads();
     }
     // the lane's residual values, ALL read before the first packed value is written back: each 8-byte slot is read and then
     // overwritten in place, and the compiler will not move a later read above an earlier write to the same tile -- slot by slot
     // that was 32 serialised LDS round trips (~2 800 cycles of a fused + residual tile's epilogue)
     uint32_t rres[RPW][NJ][4][2];
-    if (p.resid) {
+    if (RES) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
@@ -395,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (p.resid) {
+                if (RES) {
                     const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
                     v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
                     v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
@@ -413,36 +479,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // taken here from the rounded bf16 values on their way out (what a separate gn_stats pass would read back from
     // HBM: ~30 us per image over the decoder): per-thread (sum, sumsq) over its 8 pixels, folded to the 1-2 groups
     // its 8 channels belong to, reduced over the 32 threads of the same chunk, one partial per (tile, group).
-    float gs_[8], gq_[8];
+    float gs_[4], gq_[4];                           // (sum, sum of squares) per channel PAIR of the thread's 8 channels
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
-#pragma unroll 4
-    for (int cidx = tid; cidx < TPX * CPR; cidx += NTH) {
-        const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-        const int ty = ml / HT_W, tx = ml - ty * HT_W;
-        const long pix = ((long)img * p.H + ty0 + ty) * p.W + tx0 + tx;
-        const rq_u128 u = ld128(sT + ml * LDR + nl * 2);
-        st128(p.out + pix * p.Cout + n0 + nl, u);
-        if (p.stats) {
-            float f[8];
-            f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-            f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-            f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-            f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    for (int e = 0; e < 4; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { gs_[e] += f[e]; gq_[e] = fmaf(f[e], f[e], gq_[e]); }
-        }
+    for (int k = 0; k < R_IT; ++k) {
+        const rq_u128 u = ld128(sT + ((tid >> 4) + HT_W * k) * LDR + (tid & 15) * 16);
+        st128((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
+        if (p.stats) rq_stats_piece(u, gs_, gq_);
     }
     if (p.stats) {                                  // uniform
         __shared__ float sred[NTH / 64][16][4];
         const int gsz = p.Cout / 32;                // channels per group: 4, 8 or 16 (Cout = 128, 256, 512)
         float a0, q0, a1, q1;                       // pair 0 = channels 0..3 (gsz 4) or 0..7; pair 1 = channels 4..7 (gsz 4)
         if (gsz == 4) {
-            a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]); q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
-            a1 = (gs_[4] + gs_[5]) + (gs_[6] + gs_[7]); q1 = (gq_[4] + gq_[5]) + (gq_[6] + gq_[7]);
+            a0 = gs_[0] + gs_[1]; q0 = gq_[0] + gq_[1];
+            a1 = gs_[2] + gs_[3]; q1 = gq_[2] + gq_[3];
         } else {
-            a0 = ((gs_[0] + gs_[1]) + (gs_[2] + gs_[3])) + ((gs_[4] + gs_[5]) + (gs_[6] + gs_[7]));
-            q0 = ((gq_[0] + gq_[1]) + (gq_[2] + gq_[3])) + ((gq_[4] + gq_[5]) + (gq_[6] + gq_[7]));
+            a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]);
+            q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
             a1 = 0.f; q1 = 0.f;
         }
         // lanes l, l^16, l^32, l^48 hold the same chunk
@@ -499,7 +554,7 @@ static_assert(PK_P0 + PK_TILE + PK_RED <= PK_P1, "epilogue tile over P0 + spare"
 
 struct HaloTile { int img, ty0, tx0, n0, trem; };
 
-template <int FUSE_GN, int UPS>
+template <int FUSE_GN, int UPS, int RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p, int wpx) {
     constexpr int TH = HT_H, NTH = 512, RPW = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3;
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
@@ -593,7 +648,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     auto load_gs = [&](int c) {
         if (FUSE_GN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2) * RQ_LOG2E;
         }
     };
     auto load_halo = [&](int c, rq_u128* rh) {
@@ -613,8 +668,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
             for (int e = 0; e < 8; e += 2) {
                 const f32x4 ss = gs[e >> 1];
                 const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
-                f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
-                f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+                f[e] = rq_silu_l2(a);
+                f[e + 1] = rq_silu_l2(b);
             }
             v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
             v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
@@ -653,22 +708,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                     for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bv[e];
             }
     };
+    // one tap: four k-steps on two fragment sets in ping-pong (the reads of k-step ks + 1 are issued ahead of the MFMAs of k-step
+    // ks, held there by opaque accumulators as in conv3x3_halo_kernel; with one set every k-step waited out its own LDS round trip)
     auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
         const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * PK_PSTRIDE);
         const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[RPW], bfr[2];
+        bf16x8 af[2][RPW], bfr[2][2];
+        auto load_frags = [&](int ks, bf16x8* a, bf16x8* b) {
             const char* hb = sH + (ha ^ (unsigned)(ks << 5));
             const char* wb = sW + (wa ^ (unsigned)(ks << 5));
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
+            for (int i = 0; i < RPW; ++i) a[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
+            for (int j = 0; j < 2; ++j) b[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
+        };
+        load_frags(0, af[0], bfr[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int i = 0; i < RPW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[j], af[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j) rq_opaque_acc(acc[i][j]);
+            if (ks < 3) load_frags(ks + 1, af[(ks + 1) & 1], bfr[(ks + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j]);
+            if (ks < 3) rq_sched_group(0x100, RPW + 2);
+            rq_sched_group(0x008, 2 * RPW);
+            rq_sched_barrier();
         }
     };
 
@@ -706,6 +774,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     int wbuf = 0, hbuf = 0;
 
     int tid_o = tid;                               // opaque per-tile copy of the thread index (see the tile loop)
+    unsigned io_off0 = 0;                          // byte offset of this thread's piece 0 of the current tile's residual / output
+    const unsigned io_step = (unsigned)p.W * (unsigned)p.Cout * 2u;
 #ifdef RQ_CONV_TRACE
     int trace_tile = 0;
 #define RQ_CTP(slot) do { if (blockIdx.x == (RQ_CONV_TRACE & 255) && trace_tile == 2 && lane == 0 && (slot) < 64) g_conv_trace[wave * 64 + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -737,15 +807,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 const int t_use = FIRST + it / PPT, t_load = t_use >= 3 ? t_use - 3 : 0;
                 if (t_load == tap) load_halo_piece(LAST ? 0 : c + 1, rh, it);
             }
-            if (LAST && tap >= 1 && p.resid) {
-#pragma unroll
-                for (int k = tap - 1; k < tap && k < R_IT; ++k) {
-                    const int cidx = tid_o + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-                    const int ty = ml / HT_W, tx = ml - ty * HT_W;
-                    const long pix = ((long)cur.img * p.H + cur.ty0 + ty) * p.W + cur.tx0 + tx;
-                    rr[k] = ld128(p.resid + pix * p.Cout + cur.n0 + nl);
-                }
-            }
+            if (LAST && RES && tap >= 1) rr[tap - 1] = ld128((const char*)p.resid + (io_off0 + (unsigned)(tap - 1) * io_step));
             rq_sched_barrier();
             const bool ptap = tap >= FIRST;
 #pragma unroll
@@ -754,10 +816,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 if (ptap && it < H_IT) rh[it < H_IT ? it : 0] = halo_piece_value(rh, it < H_IT ? it : 0);
             }
             compute(hbuf, wbuf, ky, kx);
-            if (FUSE_GN && ptap) {
-#pragma unroll
-                for (int g = 0; g < 8 * RPW; ++g) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 7); }
-            }
             store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -777,6 +835,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         // the epilogue's addressing is the same for every tile; recomputed from an opaque copy of the thread index each
         // round, or the compiler hoists ~100 registers of loop-invariant offsets across the main loop (and spills them)
         rq_opaque(tid_o);
+        // piece k of a thread = 16-byte chunk (tid & 15) of pixel (tid >> 4) of tile row k, residual and output alike
+        static_assert(CPR == 16 && NTH / CPR == HT_W && R_IT == TH, "piece k = tile row k");
+        io_off0 = (unsigned)((((long)cur.img * p.H + cur.ty0) * p.W + cur.tx0 + (tid_o >> 4)) * p.Cout + cur.n0 + (tid_o & 15) * 8) * 2u;
         RQ_CTP(1);
         for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
         run_chunk(NC - 1, std::true_type{});
@@ -785,12 +846,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         char* sT = (char*)smem + PK_P0 + (hbuf == 0 ? PK_PATCH : 0);
         const int lane_o = tid_o & 63, wave_o = tid_o >> 6, wm_o = wave_o >> 1, wn_o = wave_o & 1;
         float* sred = (float*)(sT + PK_TILE);       // [8][16][4]
-        if (p.resid) {
+        if (RES) {
 #pragma unroll
-            for (int k = 0; k < R_IT; ++k) {
-                const int cidx = tid_o + NTH * k, ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-                st128(sT + ml * PK_LDR + nl * 2, rr[k]);
-            }
+            for (int k = 0; k < R_IT; ++k) st128(sT + ((tid_o >> 4) + HT_W * k) * PK_LDR + (tid_o & 15) * 16, rr[k]);
             rq_syncthreads();
         }
 #pragma unroll
@@ -805,7 +863,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                    if (p.resid) {
+                    if (RES) {
                         const uint32_t* rp = (const uint32_t*)(sT + ml * PK_LDR + nl * 2);
                         const uint32_t r0 = rp[0], r1 = rp[1];
                         v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
@@ -822,35 +880,24 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         if (has_next) acc_from_bias(nxt.n0);
         rq_syncthreads();
         RQ_CTP(61);
-        float gs_[8], gq_[8];
+        float gs_[4], gq_[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
-#pragma unroll 4
-        for (int cidx = tid_o; cidx < TPX * CPR; cidx += NTH) {
-            const int ml = cidx / CPR, nl = (cidx - ml * CPR) * 8;
-            const int ty = ml / HT_W, tx = ml - ty * HT_W;
-            const long pix = ((long)cur.img * p.H + cur.ty0 + ty) * p.W + cur.tx0 + tx;
-            const rq_u128 u = ld128(sT + ml * PK_LDR + nl * 2);
-            st128(p.out + pix * p.Cout + cur.n0 + nl, u);
-            if (p.stats) {
-                float f[8];
-                f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-                f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-                f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-                f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+        for (int e = 0; e < 4; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { gs_[e] += f[e]; gq_[e] = fmaf(f[e], f[e], gq_[e]); }
-            }
+        for (int k = 0; k < R_IT; ++k) {
+            const rq_u128 u = ld128(sT + ((tid_o >> 4) + HT_W * k) * PK_LDR + (tid_o & 15) * 16);
+            st128((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
+            if (p.stats) rq_stats_piece(u, gs_, gq_);
         }
         if (p.stats) {                              // uniform; same reduction as conv3x3_halo_kernel
             const int gsz = p.Cout / 32;
             float a0, q0, a1, q1;
             if (gsz == 4) {
-                a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]); q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
-                a1 = (gs_[4] + gs_[5]) + (gs_[6] + gs_[7]); q1 = (gq_[4] + gq_[5]) + (gq_[6] + gq_[7]);
+                a0 = gs_[0] + gs_[1]; q0 = gq_[0] + gq_[1];
+                a1 = gs_[2] + gs_[3]; q1 = gq_[2] + gq_[3];
             } else {
-                a0 = ((gs_[0] + gs_[1]) + (gs_[2] + gs_[3])) + ((gs_[4] + gs_[5]) + (gs_[6] + gs_[7]));
-                q0 = ((gq_[0] + gq_[1]) + (gq_[2] + gq_[3])) + ((gq_[4] + gq_[5]) + (gq_[6] + gq_[7]));
+                a0 = (gs_[0] + gs_[1]) + (gs_[2] + gs_[3]);
+                q0 = (gq_[0] + gq_[1]) + (gq_[2] + gq_[3]);
                 a1 = 0.f; q1 = 0.f;
             }
             a0 += rq_shfl_xor(a0, 16); q0 += rq_shfl_xor(q0, 16); a1 += rq_shfl_xor(a1, 16); q1 += rq_shfl_xor(q1, 16);
@@ -1297,20 +1344,22 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     static_assert((size_t)TH * HT_W * (H_BN * 2 + 16) + 4096 <= H_SMEM_BYTES, "the epilogue tile overlays the operand buffers");
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (ups && halo_persistent(ups)) {      // (the persistent forms of the plain / fused convs measured 0 ... -3 % and spilled: not compiled)
+    if (ups && halo_persistent(ups)) {      // (the persistent forms of the plain / fused convs measured 0 ... -3 % and need > 256 registers: not compiled)
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
         static int cus_per_xcd[16];
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (pk_once.first()) {
-            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
             int cus = 0;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
             cus_per_xcd[dev & 15] = cus / 8;
@@ -1318,12 +1367,14 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
         const int slots = ((n_mt + 7) / 8) * NT;
         int wpx = g_conv_halo_dbg_wpx > 0 ? g_conv_halo_dbg_wpx : cus_per_xcd[dev & 15];
         if (wpx > slots) wpx = slots;
-        RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 1>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 1, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
         return rq_check_launch("conv3x3_halo_pk_kernel");
     }
-    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
-    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    if (ups) RQ_LAUNCH((conv3x3_halo_kernel<0, 1, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.gn && a.resid) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, 1>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.gn) RQ_LAUNCH((conv3x3_halo_kernel<1, 0, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else if (a.resid) RQ_LAUNCH((conv3x3_halo_kernel<0, 0, 1>), dim3(nblocks), dim3(NTHR), smem, s, a);
+    else RQ_LAUNCH((conv3x3_halo_kernel<0, 0, 0>), dim3(nblocks), dim3(NTHR), smem, s, a);
     return rq_check_launch("conv3x3_halo_kernel");
 }
 

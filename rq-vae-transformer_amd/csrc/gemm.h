@@ -1082,6 +1082,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         rq_glds16_s(dst + 1024, base, b_off[nb][1]);
     };
 
+    // K-tile 0 is requested HERE, ahead of the fragment addresses and the 128 accumulator moves below: the first DMA used to be
+    // instruction ~500 of the kernel, i.e. a tile's 24 K-tiles started ~2000 cycles after the workgroup did
+    if (nk >= 2) { stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1); }
+    rq_sched_barrier();
+
     // ---- fragment read offsets: row = (wave block) + (lane & 31), 16-byte chunk 2 ks + (lane >> 5), swizzled
     const int frow = lane & 31, fk = lane >> 5;
     unsigned rd_a[4], rd_b[4];
@@ -1135,13 +1140,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     rq_sched_barrier();
 
     if (PH == 2 && nk >= 2) {
+        // (Measured and not kept, profiles/r03_gemm_p8_bh1_in_burst.txt: the DMA of BH1(t+1) issued from inside phase I's MFMA burst
+        // instead of in its load half, which carries 16 ds_reads + 6 DMA instructions against 8 + 2 in phase II -- bit-identical,
+        // qkv / proj / fc1 -0.3 ... -0.6 %, fc2 +7 %, classifier +2 %.)
         auto mma16 = [&](int ih, bool n1_first) {      // 16 MFMAs: m-blocks 2 ih, 2 ih + 1 x both n-blocks x 4 k-steps
             rq_sched_barrier();
             rq_wait_lgkmcnt<0>();
             rq_sched_barrier();
             if (!(p.dbg & 32)) rq_setprio(1);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = n1_first ? 1 - jj : jj;
@@ -1152,13 +1160,13 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
                                                  : rq_mfma_32x32x16_bf16(fa[ii][ks], b, acc[2 * ih + ii][j]);
                     }
                 }
+            }
             rq_setprio(0);
             rq_sched_barrier();
             rq_barrier_raw();
             rq_sched_barrier();
         };
-        // prologue: tile 0 whole; AH0, BH0, BH1 must have landed before phase I reads them (AH1 may still be in flight)
-        stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1);
+        // prologue: tile 0 whole (requested above); AH0, BH0, BH1 must have landed before phase I reads them (AH1 may still be in flight)
         RQ_P8_LOAD_END(2)
         if (wm == 1) rq_barrier_raw();           // wave row 1 runs half a phase behind
         rq_sched_barrier();
@@ -1184,8 +1192,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         rq_sched_barrier();
     } else
     if (nk >= 2) {
-        // prologue: tile 0 whole, AH0 / BH0 of tile 1; the first two units must have landed before phase 1 reads them
-        stage_a(kt0, U_AH0, 0); stage_b(kt0, U_BH0, 0); stage_b(kt0, U_BH1, 1); stage_a(kt0, U_AH1, 1);
+        // prologue: tile 0 whole (requested above), AH0 / BH0 of tile 1; the first two units must have landed before phase 1 reads them
         stage_a(kt0 + 1, U_AH0, 0); stage_b(kt0 + 1, U_BH0, 0);
         RQ_P8_LOAD_END(8)
         if (wm == 1) rq_barrier_raw();           // wave row 1 runs half a phase behind (uniform per wave: wm is scalar)

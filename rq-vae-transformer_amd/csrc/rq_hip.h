@@ -128,9 +128,18 @@ static __device__ __forceinline__ int rq_readlane_i(int v, int lane) { return __
 // makes `x` opaque to the optimiser at this point (keeps loop-invariant address arithmetic from being hoisted out of a
 // persistent tile loop, where it would hold dozens of registers across the whole main loop)
 static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v"(x)); }
+// the same for a 32-bit word of data: no producer of `x` is scheduled below this point and no consumer above it (an asm
+// statement is ordered against sched_barriers and other asm statements, register arithmetic is ordered only through operands)
+static __device__ __forceinline__ void rq_opaque_u(uint32_t& x) { asm volatile("" : "+v"(x)); }
+static __device__ __forceinline__ void rq_opaque_acc(f32x16& x) { asm volatile("" : "+v"(x)); }
 // "these values are needed now": makes the compiler place its wait for the loads that produce them here
 static __device__ __forceinline__ void rq_use(unsigned a, unsigned b, unsigned c, unsigned d) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); }
 static __device__ __forceinline__ void rq_use(float a, float b) { asm volatile("" :: "v"(a), "v"(b)); }
+// acc + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
+static __device__ __forceinline__ float rq_dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    typedef __bf16 rq_bf16x2_v __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rq_bf16x2_v, a), __builtin_bit_cast(rq_bf16x2_v, b), acc, false);
+}
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }   // median: clamp in one op

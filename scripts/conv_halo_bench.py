@@ -6,11 +6,13 @@ sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch
 import torch.nn.functional as F
 from rqvae import _native
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (scripts/build_variant.py; diagnostics only)
+    _native.LIB_PATH = os.environ['RQ_LIB']
 
 dev = 'cuda'
 
 
-def bench(fn, reps=10):
+def bench(fn, reps=20):
     fn(); fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -152,6 +152,13 @@ static inline unsigned long long rq_ballot(bool pred) {
 static inline int rq_popc64(unsigned long long m) { return __builtin_popcountll(m); }
 static inline void rq_threadfence_block() {}
 static inline void rq_opaque(int&) {}
+static inline void rq_opaque_u(uint32_t&) {}
+static inline float rq_dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    union { uint32_t u; float f; } al, ah, bl, bh;
+    al.u = a << 16; ah.u = a & 0xffff0000u; bl.u = b << 16; bh.u = b & 0xffff0000u;
+    return acc + (al.f * bl.f + ah.f * bh.f);
+}
+static inline void rq_opaque_acc(f32x16_emu&) {}
 static inline void rq_use(unsigned, unsigned, unsigned, unsigned) {}
 static inline void rq_use(float, float) {}
 static inline void rq_trap() { abort(); }
