@@ -1072,14 +1072,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     auto stage_a = [&](int kt, int uo, int mh) {
         const char* base = gA + (size_t)kt * (BK * 2);
         const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
-        rq_glds16_s(dst, base, a_off[mh][0]);
-        rq_glds16_s(dst + 1024, base, a_off[mh][1]);
+        rq_glds16_s2(dst, base, a_off[mh][0], a_off[mh][1]);
     };
     auto stage_b = [&](int kt, int uo, int nb) {
         const char* base = gW + (size_t)kt * (BK * 2);
         const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
-        rq_glds16_s(dst, base, b_off[nb][0]);
-        rq_glds16_s(dst + 1024, base, b_off[nb][1]);
+        rq_glds16_s2(dst, base, b_off[nb][0], b_off[nb][1]);
     };
 
     // K-tile 0 is requested HERE, ahead of the fragment addresses and the 128 accumulator moves below: the first DMA used to be
@@ -1120,7 +1118,8 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         rq_sched_barrier();
         rq_wait_lgkmcnt<0>();
         rq_sched_barrier();            // keeps the register-only MFMAs below the wait (hipcc hoists them past inline-asm waits)
-        if (!(p.dbg & 32)) rq_setprio(1);      // (dbg bit 5: A/B without the priority raise)
+        rq_setprio(1);                         // (measured null against no priority raise, profiles/r02_gemm_p8_prio.txt; the run-time
+                                               // A/B switch that used to sit here cost a VALU compare + branch per MFMA burst)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -1147,7 +1146,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
             rq_sched_barrier();
             rq_wait_lgkmcnt<0>();
             rq_sched_barrier();
-            if (!(p.dbg & 32)) rq_setprio(1);
+            rq_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll

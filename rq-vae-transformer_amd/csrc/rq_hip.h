@@ -90,6 +90,14 @@ static __device__ __forceinline__ void rq_glds16_s(unsigned lds_base, const void
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
+// Two of them, to lds_base and lds_base + 1024 (the two 8-row groups a wavefront owns in a 16-KB unit), in one statement: M0 is
+// saved and restored once.
+static __device__ __forceinline__ void rq_glds16_s2(unsigned lds_base, const void* sbase, unsigned voff0, unsigned voff1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_base) : "memory", "scc");
+}
 template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 template <int N> static __device__ __forceinline__ void rq_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
 static __device__ __forceinline__ void rq_barrier_raw() { __builtin_amdgcn_s_barrier(); }
