@@ -144,7 +144,15 @@ static __device__ __forceinline__ f32x4 rq_bias4(const float* bias, int n, int N
     return b;
 }
 
-template <int BM, int BN, int TR, int WGM, int WGN, int SMEM_BYTES>
+// FULL (256 x 256 kernel): the tile lies inside the problem and every vector-store condition holds (checked once per workgroup by
+// the caller), so no row / column test stands between the stores -- behind one, every 16-byte store of the bf16 stream-out waited
+// for its own LDS read (16 serialised round trips per thread, ~4500 cycles of an 80 000-cycle tile) and every in-place residual
+// vector sat in an exec-mask diamond of its own.
+// EK (256 x 256 kernel): the epilogue family as a compile-time constant -- a GemmEpi value, or 5 = EPI_F32_PARTIAL with the in-place
+// residual update (GemmArgs::accum), 6 = EPI_BF16_GELU with the sigmoid form (GemmArgs::gelu_v2); -1 = read p.epi / p.accum at run time (the other kernels).  With the family a run-time value
+// every vector of the in-place path carried a v_cndmask per element, a 64-bit slab-offset multiply and two scalar branches
+// (~45 instructions per 16-byte store).
+template <int BM, int BN, int TR, int WGM, int WGN, int SMEM_BYTES, bool FULL = false, int EK = -1>
 static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                         unsigned char* smem, int m0, int n0) {
     constexpr int NTH = 64 * WGM * WGN;
@@ -166,7 +174,14 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
     }
     const float* bias = p.bias;
     if (bias && p.bias_step) bias += (long)(*p.bias_step) * p.bias_stride;
-    const int epi = p.epi;
+    const int epi = EK < 0 ? p.epi : EK == 5 ? (int)EPI_F32_PARTIAL : EK == 6 ? (int)EPI_BF16_GELU : EK;       // (6: GELU v2)
+    const int gelu_v2 = EK == 1 ? 0 : EK == 6 ? 1 : p.gelu_v2;
+    // a lane's bias vector for columns n .. n + 3: inside a FULL tile one 16-byte load (rq_bias4's column tests cost an exec-mask
+    // diamond per vector)
+    auto bias4 = [&](const float* b, int n) -> f32x4 {
+        if (FULL) return b ? *(const f32x4*)(b + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        return rq_bias4(b, n, p.N);
+    };
     if (TR && epi <= EPI_BF16_RESID) {
         // bf16 outputs: each lane packs its 4 consecutive columns to 8 bytes and writes them into a padded
         // [BM][BN] bf16 tile in LDS (over the operand buffers); the tile is then streamed out as 16-byte,
@@ -179,7 +194,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bvec[j][q] = rq_bias4(bias, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
+            for (int q = 0; q < 4; ++q) bvec[j][q] = bias4(bias, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
         // likewise the lane's residual values (8 bytes per 4 columns), fetched up front with clamped addresses (rows / columns
         // outside the problem are computed but never stored): inside the loop below they were one global round trip each
         const bool res_vec = epi == EPI_BF16_RESID && (p.ldr & 3) == 0 && (p.N & 3) == 0;
@@ -192,8 +207,10 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         int m = m0 + wm * WM + i * 32 + (lane & 31), n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
-                        m = m < p.M ? m : p.M - 1;
-                        n = n < p.N ? n : p.N - 4;
+                        if (!FULL) {
+                            m = m < p.M ? m : p.M - 1;
+                            n = n < p.N ? n : p.N - 4;
+                        }
                         const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
                         rres[i][j][q][0] = rp[0];
                         rres[i][j][q][1] = rp[1];
@@ -215,7 +232,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] + bvec[j][q][e];
                     if (epi == EPI_BF16_GELU) {
-                        rq_gelu4(v, p.gelu_v2);
+                        rq_gelu4(v, gelu_v2);
                     }
                     if (res_vec) {
                         // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
@@ -247,6 +264,20 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         RQ_GT(4);
         constexpr int CPR = BN / 8;                // 16-byte chunks per row
         const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
+        if (FULL) {
+            // piece k of a thread = 16-byte chunk tid % CPR of tile row tid / CPR + (NTH / CPR) k: all reads, then all stores
+            static_assert(NTH % CPR == 0 && (BM * CPR) % NTH == 0, "whole rows per pass");
+            constexpr int IT = BM * CPR / NTH, RSTEP = NTH / CPR;
+            const char* src = sT + (tid / CPR) * LDR + (tid % CPR) * 16;
+            bf16_t* o = (bf16_t*)p.out + (long)(m0 + tid / CPR) * p.ldo + n0 + (tid % CPR) * 8;
+            rq_u128 u[IT];
+#pragma unroll
+            for (int k = 0; k < IT; ++k) u[k] = ld128(src + k * (RSTEP * LDR));
+#pragma unroll
+            for (int k = 0; k < IT; ++k) st128(o + (long)k * RSTEP * p.ldo, u[k]);
+            RQ_GT(5);
+            return;
+        }
 #pragma unroll 4
         for (int c = tid; c < BM * CPR; c += NTH) {
             const int ml = c / CPR, nl = (c - ml * CPR) * 8;
@@ -271,15 +302,20 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
     // FOUR CONSECUTIVE n -- one 8-byte (bf16) or 16-byte (fp32) vector store each, and the residual is
     // read the same way.  (The first version stored one scattered 2-byte element per register: +33..80 %
     // time on the decoder convs; an LDS-staged transpose was 19 %.)
-    const bool vec_ok = (p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0);
+    const bool vec_ok = FULL || ((p.ldo & 3) == 0 && (epi != EPI_BF16_RESID || (p.ldr & 3) == 0));
+    const bool accum = EK < 0 ? (epi == EPI_F32_PARTIAL && p.accum) : EK == 5;      // (launcher: splitk == 1, N % 4 == 0, ldo % 4 == 0)
     f32x4 bvec[NI][4];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            bvec[j][q] = rq_bias4((epi != EPI_F32_PARTIAL || p.accum) ? bias : nullptr, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5), p.N);
-    const bool accum = epi == EPI_F32_PARTIAL && p.accum;      // (launcher: splitk == 1, N % 4 == 0, ldo % 4 == 0)
+            bvec[j][q] = bias4((epi != EPI_F32_PARTIAL || accum) ? bias : nullptr, n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5));
     f32x4 xr2[2][NI][4];
+    // fp32 outputs: the lane's first vector of the tile (row m0 + wm WM + lane % 32, column n0 + wn WN + 4 (lane / 32), in the slab of
+    // this K split); vector (i, j, q) lies 32 i rows and 32 j + 8 q columns on
+    float* const o_lane = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) +
+                          (long)(m0 + wm * WM + (lane & 31)) * p.ldo + n0 + wn * WN + 4 * (lane >> 5);
+    const long o_istep = 32l * p.ldo;
     auto load_x = [&](int i, f32x4 (&dst)[NI][4]) {
         const int m = m0 + wm * WM + i * 32 + (lane & 31);
 #pragma unroll
@@ -287,7 +323,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
-                dst[j][q] = (m < p.M && n < p.N) ? *(const f32x4*)((const float*)p.out + (long)m * p.ldo + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                dst[j][q] = (FULL || (m < p.M && n < p.N)) ? *(const f32x4*)(o_lane + i * o_istep + j * 32 + 8 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
     };
 #pragma unroll
@@ -302,13 +338,13 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + wn * WN + j * 32 + 8 * q + 4 * (lane >> 5);
-                if (m >= p.M || n >= p.N) continue;
+                if (!FULL && (m >= p.M || n >= p.N)) continue;
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = accum ? (xr[j][q][e] + acc[i][j][4 * q + e]) + bvec[j][q][e] : acc[i][j][4 * q + e] + bvec[j][q][e];
-                const bool full4 = vec_ok && n + 3 < p.N;
+                const bool full4 = FULL || (vec_ok && n + 3 < p.N);
                 if (epi == EPI_BF16_GELU) {
-                    rq_gelu4(v, p.gelu_v2);
+                    rq_gelu4(v, gelu_v2);
                 }
                 if (epi <= EPI_BF16_RESID) {
                     bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
@@ -331,7 +367,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                         }
                     }
                 } else {
-                    float* o = (float*)p.out + (epi == EPI_F32_PARTIAL ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
+                    float* o = o_lane + i * o_istep + j * 32 + 8 * q;
                     if (full4) {
                         *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
                     } else {
@@ -377,7 +413,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                         for (int r = 0; r < 16; ++r) {
                             const int ml = wm * WM - hh * HB + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                             float v = acc[i][j][r] + bv;
-                            if (epi == EPI_BF16_GELU) v = rq_gelu(v, p.gelu_v2);
+                            if (epi == EPI_BF16_GELU) v = rq_gelu(v, gelu_v2);
                             sC[ml * BN + nl] = v;
                         }
                     }
@@ -430,7 +466,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= p.M || n >= p.N) continue;
+                if (!FULL && (m >= p.M || n >= p.N)) continue;
                 const float v = acc[i][j][r] + bv;
                 const long o = (long)m * p.ldo + n;
                 if (epi == EPI_F32) ((float*)p.out)[o] = v;
@@ -1026,7 +1062,7 @@ static __device__ __forceinline__ bool rq_gemm_tile_coords(const GemmArgs& p, in
 // PH = 2: phase I(t) refills [AH0, BH0, BH1] of the other buffer with tile t+1 (last read two phases ago, in I(t-1)), phase II(t)
 // refills its AH1; the wait that ends I(t) leaves three units in flight (vmcnt(6): AH1(t) has landed for II(t)), the wait that
 // ends II(t) one (vmcnt(2): [AH0, BH0, BH1](t+1) have landed for I(t+1)).
-template <int TR, int PH = 4>
+template <int TR, int PH = 4, int EK = -1>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4;
     constexpr int UNIT = 128 * BK * 2;                 // 16 KB
@@ -1233,7 +1269,11 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         rq_sched_barrier();
     }
 #undef RQ_P8_LOAD_END
-    rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES>(p, acc, smem, m0, n0);
+    // interior tile with every vector-store condition met (all tiles of the benchmark shapes): the check-free epilogue
+    const bool full = m0 + BM <= p.M && n0 + BN <= p.N && (p.N & 7) == 0 && (p.ldo & 7) == 0 &&
+                      (p.epi != EPI_BF16_RESID || (p.ldr & 3) == 0) && !(p.dbg & 1);
+    if (full) rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES, true, EK>(p, acc, smem, m0, n0);
+    else rq_gemm_epilogue<BM, BN, TR, WGM, WGN, SMEM_BYTES, false, EK>(p, acc, smem, m0, n0);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -73,13 +73,13 @@ static int launch_rb(const GemmArgs& a, hipStream_t stream) {
 }
 
 // 256 x 256 eight-phase kernel (gemm.h): dense operands, >= 2 K-tiles per split
-template <int TR, int PH = 4>
+template <int TR, int PH = 4, int EK = -1>
 static int launch_p8(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = 256, BN = 256;
     const size_t smem = (size_t)BM * (BN * 2 + 16);
     static RqDeviceOnce attr_once;
     if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<TR, PH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute((const void*)gemm_p8_kernel<TR, PH, EK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     }
     GemmArgs g = a;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
@@ -102,7 +102,7 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
         if (g.sched_gm > MT) g.sched_gm = MT;
         nblocks = 8 * ((MT * NT + 7) / 8);
     }
-    RQ_LAUNCH((gemm_p8_kernel<TR, PH>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
+    RQ_LAUNCH((gemm_p8_kernel<TR, PH, EK>), dim3(nblocks, 1, a.splitk), dim3(512), smem, stream, g);
     return rq_check_launch("gemm_p8_kernel");
 }
 
@@ -177,8 +177,18 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         // RQAMD_P8_PH=2|4 forces one schedule (A/B switch)
         static const int ph_env = getenv("RQAMD_P8_PH") ? atoi(getenv("RQAMD_P8_PH")) : 0;
         const bool ph2 = (a.dbg & 64) ? true : (a.dbg & 128) ? false : ph_env == 2 ? true : ph_env == 4 ? false : a.epi != EPI_F32;
-        if (ph2) return a.epi != EPI_F32 ? launch_p8<1, 2>(a, stream) : launch_p8<0, 2>(a, stream);
-        return a.epi != EPI_F32 ? launch_p8<1>(a, stream) : launch_p8<0>(a, stream);
+        // the shipped combinations carry their epilogue family as a compile-time constant (gemm.h: EK); the A/B schedules and
+        // EPI_BF16_RESID keep the run-time form
+        if (ph2 && a.epi != EPI_F32) {
+            switch (a.epi) {
+                case EPI_BF16: return launch_p8<1, 2, EPI_BF16>(a, stream);
+                case EPI_BF16_GELU: return a.gelu_v2 ? launch_p8<1, 2, 6>(a, stream) : launch_p8<1, 2, EPI_BF16_GELU>(a, stream);
+                case EPI_F32_PARTIAL: return a.accum ? launch_p8<1, 2, 5>(a, stream) : launch_p8<1, 2, EPI_F32_PARTIAL>(a, stream);
+                default: return launch_p8<1, 2>(a, stream);
+            }
+        }
+        if (ph2) return launch_p8<0, 2>(a, stream);
+        return a.epi != EPI_F32 ? launch_p8<1>(a, stream) : launch_p8<0, 4, EPI_F32>(a, stream);
     }
     {   // LDS-DMA staged variants (dense operands): RQAMD_GEMM_GL = number of LDS stages (experiment switch)
         static const int gl_env = getenv("RQAMD_GEMM_GL") ? atoi(getenv("RQAMD_GEMM_GL")) : 0;
