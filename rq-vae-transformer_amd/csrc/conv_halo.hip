@@ -613,15 +613,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     // offset (tile-independent), so the full derivation above is paid once per workgroup, not once per tile (it cost ~1800
     // cycles of VALU per tile when every tile recomputed it, profiles/r02_conv_halo_barrier_timeline.txt)
     auto restage = [&](const HaloTile& t) {
+        int tid_s = tid;                            // opaque, as in set_staging
+        rq_opaque(tid_s);
+        int hp = tid_s >> 3, hy = hp / PW, hx = hp - hy * PW;      // piece `it` = patch pixel (tid >> 3) + 64 it: one division, then steps
 #pragma unroll
         for (int it = 0; it < H_IT; ++it) {
             const unsigned in = (hd[it] >> 30) & 1u, lo = hd[it] & 0x1fff0000u;
-            const int hp = (int)(lo >> 19);
-            const int hy = hp / PW, hx = hp - hy * PW;
             const int gy = (UPS ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS ? t.tx0 >> 1 : t.tx0) + hx - 1;
             const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
             const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
             hd[it] = (unsigned)(cy * Ws + cx) | lo | (ok ? 1u << 29 : 0u) | (in << 30);
+            hy += (NTH / 8) / PW; hx += (NTH / 8) % PW;
+            if (hx >= PW) { hx -= PW; ++hy; }
         }
         x_img = (unsigned)((long)t.img * Hs * Ws * p.Cin * 2) + (unsigned)((tid & 7) * 16);
         if (FUSE_GN) gn = p.gn + (long)t.img * p.Cin * 2;
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     };
     // one tap: four k-steps on two fragment sets in ping-pong (the reads of k-step ks + 1 are issued ahead of the MFMAs of k-step
     // ks, held there by opaque accumulators as in conv3x3_halo_kernel; with one set every k-step waited out its own LDS round trip)
-    auto compute = [&](int hbuf, int wbuf, int ky, int kx) {
+    auto compute = [&](int hbuf, int wbuf, int ky, int kx, rq_u128* rhp, int pit) {      // pit >= 0: patch piece normalised under this tap
         const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * PK_PSTRIDE);
         const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
         bf16x8 af[2][RPW], bfr[2][2];
@@ -734,8 +737,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
             for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = rq_mfma_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j]);
+            if (FUSE_GN && pit >= 0) {          // one 32-bit word (two channels) of the piece per k-step region, as in conv3x3_halo_kernel
+                uint32_t& w = ks == 0 ? rhp[pit].x : ks == 1 ? rhp[pit].y : ks == 2 ? rhp[pit].z : rhp[pit].w;
+                rq_opaque_u(w);
+                const f32x4 ss = gs[ks];
+                const float ga = fmaf(__uint_as_float(w << 16), ss[0], ss[1]), gb = fmaf(__uint_as_float(w & 0xffff0000u), ss[2], ss[3]);
+                w = pack_bf16x2(rq_silu_l2(ga), rq_silu_l2(gb));
+                if (!h_ok(pit)) w = 0u;
+                rq_opaque_u(w);
+            }
             if (ks < 3) rq_sched_group(0x100, RPW + 2);
-            rq_sched_group(0x008, 2 * RPW);
+            if (FUSE_GN && pit >= 0) {
+#pragma unroll
+                for (int m = 0; m < 2 * RPW; ++m) { rq_sched_group(0x008, 1); rq_sched_group(0x002, 3); rq_sched_group(0x400, 1); }
+            } else {
+                rq_sched_group(0x008, 2 * RPW);
+            }
             rq_sched_barrier();
         }
     };
@@ -810,12 +827,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
             if (LAST && RES && tap >= 1) rr[tap - 1] = ld128((const char*)p.resid + (io_off0 + (unsigned)(tap - 1) * io_step));
             rq_sched_barrier();
             const bool ptap = tap >= FIRST;
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int it = (tap - FIRST) * PPT + k;
-                if (ptap && it < H_IT) rh[it < H_IT ? it : 0] = halo_piece_value(rh, it < H_IT ? it : 0);
+            static_assert(PPT == 1, "one patch piece per tap");
+            if (FUSE_GN) {
+                compute(hbuf, wbuf, ky, kx, rh, ptap && tap - FIRST < H_IT ? tap - FIRST : -1);
+            } else {
+                if (ptap && tap - FIRST < H_IT) rh[tap - FIRST] = halo_piece_value(rh, tap - FIRST);
+                compute(hbuf, wbuf, ky, kx, rh, -1);
             }
-            compute(hbuf, wbuf, ky, kx);
             store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) {
@@ -1352,7 +1370,10 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     }
     const int n_mt = a.B * (a.H / TH) * (a.W / HT_W), NT = a.Cout / H_BN;
     const int nblocks = 8 * ((n_mt + 7) / 8) * NT;
-    if (ups && halo_persistent(ups)) {      // (the persistent forms of the plain / fused convs measured 0 ... -3 % and need > 256 registers: not compiled)
+    // (the persistent forms of the plain / fused convs are not compiled: 0 ... -3 % in round 2; again in round 3 with the GroupNorm
+    // words dealt out under the MFMAs -- bit-identical, +2 % (GN) ... +9 % (GN + residual) slower, 256 registers with spills in
+    // its prologue / epilogue: profiles/r03_conv_halo_persist_fused_ab.txt)
+    if (ups && halo_persistent(ups)) {
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
         static int cus_per_xcd[16];
