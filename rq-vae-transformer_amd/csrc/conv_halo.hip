@@ -283,7 +283,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // (left to itself the compiler re-used ONE set -- read, wait, four MFMAs, read, wait ... -- and every k-step exposed the LDS
     // latency: a tap took ~1500 cycles per SIMD for 1024 cycles of MFMA work, profiles/r02_conv_halo_barrier_timeline.txt).
     // The tap's last k-step reads the NEXT tap's first fragments into set 0, before the barrier that ends the tap.
-    bf16x8 fa[2][RPW], fb[2][NJ];
+    // RQ_HALO_FDEPTH (A/B switch, default 1) = how many k-steps ahead the fragments are read: FD + 1 sets, k-step g = 4 tap + ks of a
+    // chunk (36 per chunk: the rotation is the same in every chunk) uses set g % (FD + 1).
+#ifndef RQ_HALO_FDEPTH
+#define RQ_HALO_FDEPTH 1
+#endif
+    constexpr int FD = RQ_HALO_FDEPTH, NSET = FD + 1;
+    static_assert(FD >= 1 && FD <= 3 && 36 % NSET == 0, "fragment read-ahead of 1..3 k-steps");
+    bf16x8 fa[NSET][RPW], fb[NSET][NJ];
     auto mfma_step = [&](int set) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
@@ -312,7 +319,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     }
     rq_syncthreads();
     RQ_CT(1);
-    load_frags(0, 0, 0, 0, 0, fa[0], fb[0]);
+#pragma unroll
+    for (int g = 0; g < FD; ++g) load_frags(0, 0, 0, 0, g, fa[g], fb[g]);           // k-steps 0 .. FD - 1 of tap 0
     // residual tile (epilogue operand): its 8 pieces per thread are fetched one per tap during the LAST chunk, where the
     // patch registers are idle, so the epilogue starts with the data in hand
     constexpr int CPR = H_BN / 8;
@@ -386,10 +394,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 for (int i = 0; i < RPW; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) rq_opaque_acc(acc[i][j]);
-                if (ks < 3) load_frags(hbuf, tap % W_SLOTS, ky, kx, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-                else if (tap < 8) load_frags(hbuf, (tap + 1) % W_SLOTS, (tap + 1) / 3, (tap + 1) % 3, 0, fa[0], fb[0]);
-                else if (!LAST) load_frags(hbuf ^ 1, 0, 0, 0, 0, fa[0], fb[0]);
-                mfma_step(ks & 1);
+                {
+                    // read k-step g + FD: this tap's, the next tap's (its weight slot and the patch were published one barrier ago), or
+                    // the next chunk's first (other patch buffer, complete since the barrier that ended tap 7)
+                    const int g = tap * 4 + ks + FD, t2 = g >> 2, k2 = g & 3, set2 = g % NSET;
+                    if (t2 < 9) load_frags(hbuf, t2 % W_SLOTS, t2 / 3, t2 % 3, k2, fa[set2], fb[set2]);
+                    else if (!LAST) load_frags(hbuf ^ 1, (t2 - 9) % W_SLOTS, (t2 - 9) / 3, (t2 - 9) % 3, k2, fa[set2], fb[set2]);
+                }
+                mfma_step((tap * 4 + ks) % NSET);
                 // The word's arithmetic is pinned INSIDE this region by making its input opaque here and its result opaque before
                 // the region closes: left alone, hipcc hoisted the whole tap's GroupNorm + SiLU (pure register arithmetic, which no
                 // sched_barrier holds back before instruction selection) to the top of the tap, or sank it below the last MFMA --
