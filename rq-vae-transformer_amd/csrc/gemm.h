@@ -1062,6 +1062,12 @@ static __device__ __forceinline__ bool rq_gemm_tile_coords(const GemmArgs& p, in
 // PH = 2: phase I(t) refills [AH0, BH0, BH1] of the other buffer with tile t+1 (last read two phases ago, in I(t-1)), phase II(t)
 // refills its AH1; the wait that ends I(t) leaves three units in flight (vmcnt(6): AH1(t) has landed for II(t)), the wait that
 // ends II(t) one (vmcnt(2): [AH0, BH0, BH1](t+1) have landed for I(t+1)).
+#ifndef RQ_P8_A_POL          // cache policy of the operand DMAs (A/B switches: ` nt` measured +7 ... +9 %, profiles/r03_gemm_p8_cache_policy.txt)
+#define RQ_P8_A_POL 0
+#endif
+#ifndef RQ_P8_W_POL
+#define RQ_P8_W_POL 0
+#endif
 template <int TR, int PH = 4, int EK = -1>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, BK = 64, WGM = 2, WGN = 4;
@@ -1108,12 +1114,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
     auto stage_a = [&](int kt, int uo, int mh) {
         const char* base = gA + (size_t)kt * (BK * 2);
         const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
-        rq_glds16_s2(dst, base, a_off[mh][0], a_off[mh][1]);
+        rq_glds16_s2<RQ_P8_A_POL>(dst, base, a_off[mh][0], a_off[mh][1]);
     };
     auto stage_b = [&](int kt, int uo, int nb) {
         const char* base = gW + (size_t)kt * (BK * 2);
         const rq_lds_t dst = lds0 + (rq_lds_t)(((kt - kt0) & 1) * BUF + uo) + my_grp;
-        rq_glds16_s2(dst, base, b_off[nb][0], b_off[nb][1]);
+        rq_glds16_s2<RQ_P8_W_POL>(dst, base, b_off[nb][0], b_off[nb][1]);
     };
 
     // K-tile 0 is requested HERE, ahead of the fragment addresses and the 128 accumulator moves below: the first DMA used to be

@@ -92,11 +92,18 @@ static __device__ __forceinline__ void rq_glds16_s(unsigned lds_base, const void
 }
 // Two of them, to lds_base and lds_base + 1024 (the two 8-row groups a wavefront owns in a 16-KB unit), in one statement: M0 is
 // saved and restored once.
+// POL: cache-policy suffix of the loads (A/B switch of gemm_p8_kernel: 0 default, 1 " nt", 2 " sc1", 3 " sc0 sc1")
+template <int POL = 0>
 static __device__ __forceinline__ void rq_glds16_s2(unsigned lds_base, const void* sbase, unsigned voff0, unsigned voff1) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_base) : "memory", "scc");
+#define RQ_GLDS2(P) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" P "\n\t" \
+                                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" P "\n\ts_mov_b32 m0, %0" \
+                                 : "=&s"(keep) : "v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_base) : "memory", "scc")
+    if (POL == 1) RQ_GLDS2(" nt");
+    else if (POL == 2) RQ_GLDS2(" sc1");
+    else if (POL == 3) RQ_GLDS2(" sc0 sc1");
+    else RQ_GLDS2("");
+#undef RQ_GLDS2
 }
 template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 template <int N> static __device__ __forceinline__ void rq_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
