@@ -21,6 +21,7 @@
 // with the loads of the next TWO K-tiles in flight behind the current tile's MFMAs; XCD-aware tile order; 16-byte-chunk XOR swizzle
 // (chunk ^ ((row>>1)&7)) makes both the b128 writes and the fragment reads bank-conflict free.
 #pragma once
+#include <type_traits>
 #include "rq_hip.h"
 
 #ifndef RQ_GEMM_VARIANT
@@ -1211,10 +1212,12 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
         RQ_P8_LOAD_END(2)
         if (wm == 1) rq_barrier_raw();           // wave row 1 runs half a phase behind
         rq_sched_barrier();
-        for (int t = 0; t < nk; ++t) {
+        // one K-tile; MORE (compile time): tile t + 1 exists and is staged -- the last tile runs from a copy of the body without the
+        // staging (as a run-time `if (t + 1 < nk)` inside one loop body every phase carried two scalar branches and their mask set-up)
+        auto k_tile = [&](int t, auto more_tag) {
+            constexpr bool more = decltype(more_tag)::value;
             const char* sb = (const char*)smem + (t & 1) * BUF;
             const int kt = kt0 + t;
-            const bool more = t + 1 < nk;
             // ---- phase I
             read_b(sb, U_BH0, fb0);
             read_b(sb, U_BH1, fb1);
@@ -1228,7 +1231,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(GemmArgs p) {
             if (more) { stage_a(kt + 1, U_AH1, 1); RQ_P8_LOAD_END(2) }
             else { RQ_P8_LOAD_END(0) }
             mma16(1, true);
-        }
+        };
+        for (int t = 0; t + 1 < nk; ++t) k_tile(t, std::true_type{});
+        k_tile(nk - 1, std::false_type{});
         if (wm == 0) rq_barrier_raw();           // wave row 0 catches up
         rq_sched_barrier();
     } else

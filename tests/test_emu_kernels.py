@@ -578,6 +578,13 @@ def test_emu_gemm_256x256_eight_phase(nat):
             bias_ = None if epi == 4 else bias
             assert torch.equal(nat.dbg_gemm(a, w, bias_, epi=epi + 512, bm=256, bn=256, splitk=1),
                                nat.dbg_gemm(a, w, bias_, epi=epi + 1024, bm=256, bn=256, splitk=1)), (M, N, K, epi)
+        # GELU family (compile-time EK = 1 / 6 in the 256 x 256 kernel; interior tiles take the check-free epilogue) against the
+        # 128 x 64 kernel's run-time form of the same epilogue
+        g256 = nat.dbg_gemm(a, w, bias, epi=1, bm=256, bn=256, splitk=1).float().numpy()
+        g128 = nat.dbg_gemm(a, w, bias, epi=1, bm=128, bn=64, splitk=1).float().numpy()
+        assert np.abs(g256 - g128).max() <= 2e-2 * np.abs(g128).max(), (M, N, K)
+        gref = 0.5 * ref * (1.0 + np.vectorize(__import__('math').erf)(ref / np.sqrt(2.0)))
+        assert np.abs(g256 - gref).max() < 1.5e-2 * np.abs(gref).max(), (M, N, K)
         # residual-stream epilogue (4 + 2048): out = (out + a w^T) + bias in place, the additions in the order of slab + resid_ln
         x0 = T(rng.standard_normal((M, N)).astype(np.float32))
         slab = nat.dbg_gemm(a, w, None, epi=4, bm=256, bn=256, splitk=1)[0]
