@@ -1,0 +1,97 @@
+"""Properties of the instruction streams hipcc emits for the two kernels that are two thirds of a step (CPU only: hipcc cross-compiles
+gfx950 here).  Round 3 found the fused halo conv's GroupNorm + SiLU arithmetic in one 70-150-instruction lump per tap with the matrix
+pipe idle, its fragment reads behind the MFMAs they were meant to precede, a conservative vmcnt behind a run-time branch, and the first
+global load of both kernels hundreds of instructions into the set-up code -- none of it visible in the source, all of it the compiler's
+placement of register-only code.  These checks fail when a source edit or a compiler update brings such a stream back."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'rq-vae-transformer_amd', 'csrc')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+import isa_summary  # noqa: E402
+
+
+def _asm(src, tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip('hipcc not available')
+    out = str(tmp_path_factory.mktemp('isa') / (src + '.s'))
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, '-S', '--cuda-device-only',
+                           os.path.join(CSRC, src), '-o', out], stderr=subprocess.DEVNULL)
+    return isa_summary.kernels(out)
+
+
+@pytest.fixture(scope='module')
+def conv_kernels(tmp_path_factory):
+    return _asm('conv_halo.hip', tmp_path_factory)
+
+
+@pytest.fixture(scope='module')
+def gemm_kernels(tmp_path_factory):
+    return _asm('gemm.hip', tmp_path_factory)
+
+
+def _taps(instrs):
+    """barrier intervals that are taps of the 3x3 stencil: exactly 16 MFMAs"""
+    return [iv for iv in isa_summary.intervals(instrs) if iv.count('M') == 16]
+
+
+@pytest.mark.parametrize('name', ['conv3x3_halo_kernel<1, 0, 0>', 'conv3x3_halo_kernel<1, 0, 1>'])
+def test_fused_halo_conv_schedule(conv_kernels, name):
+    ins = conv_kernels[name]
+    taps = _taps(ins)
+    assert len(taps) >= 14, len(taps)                      # 9 taps of the chunk loop + 9 of the last chunk (a few share an interval with loop glue)
+    lumps = []
+    for iv in taps:
+        # the longest run of VALU / transcendental / SALU instructions with no MFMA in it, counted from the tap's first MFMA to its last
+        body = iv[iv.index('M'):iv.rindex('M') + 1]
+        lumps.append(max(len(r) for r in re.split('M', body)))
+        # fragment reads precede the MFMAs of the previous k-step: never eight reads back to back followed by a wait
+        assert 'rrrrrrrr_' not in iv, iv
+    # a piece-carrying tap deals ~4 VALU + 1 transcendental out per MFMA (longest gap seen: 12); before the fix 70-150 sat in one gap
+    assert max(lumps) <= 24, lumps
+    # some taps do carry GroupNorm work (transcendentals between MFMAs): the fusion is still there
+    assert sum('t' in iv[iv.index('M'):iv.rindex('M')] for iv in taps) >= 5
+    # the first global load comes early (it was instruction ~310: the second half of the workgroup reached it ~6000 cycles late)
+    first = next(i for i, t in enumerate(ins) if t.startswith('global_load'))
+    assert first < 200, first
+
+
+def test_residual_prefetch_is_counted_exactly(conv_kernels):
+    """RES is a template parameter: the weight-tile wait at the head of a last-chunk tap leaves the residual loads in flight
+    (vmcnt(9) / (8)); behind a run-time `if (p.resid)` it was vmcnt(7) / (6) and also waited for the tile fetched two taps ago."""
+    ins = conv_kernels['conv3x3_halo_kernel<1, 0, 1>']
+    waits = [int(m.group(1)) for t in ins for m in [re.match(r's_waitcnt vmcnt\((\d+)\)', t)] if m]
+    assert 9 in waits and 8 in waits, sorted(set(waits))
+    assert 'conv3x3_halo_kernel<1, 0, 0>' in conv_kernels and 'conv3x3_halo_kernel<0, 0, 1>' in conv_kernels
+
+
+def test_gemm_p8_schedule(gemm_kernels):
+    ins = gemm_kernels['gemm_p8_kernel<1, 2, 0>']
+    # K-tile 0 is requested ahead of the fragment addresses and the accumulator init (it was instruction ~500)
+    first = next(i for i, t in enumerate(ins) if t.startswith('global_load_lds'))
+    assert first < 420, first
+    # the epilogue family is a compile-time constant: the bf16 kernel carries no GELU polynomial and is a fraction of the
+    # 22 000-line run-time form
+    assert len(ins) < 4000, len(ins)
+    # main loop body (between the loop header and its back edge): branch-free, 32 MFMAs, the staging of the next K-tile inside
+    text = '\n'.join(ins)
+    # find the densest 32-MFMA window without a branch: the peeled loop body
+    idx = [i for i, t in enumerate(ins) if t.startswith('v_mfma')]
+    ok = False
+    for a in range(0, len(idx) - 31):
+        lo, hi = idx[a], idx[a + 31]
+        window = ins[lo:hi + 1]
+        if not any(t.startswith('s_cbranch') or t.startswith('s_branch') for t in window) and sum(t.startswith('global_load_lds') for t in window) >= 2:
+            ok = True
+            break
+    assert ok, 'no branch-free K-tile body with its staging found'
+    # every shipped family exists as its own kernel
+    for ek in (0, 1, 4, 5, 6):
+        assert f'gemm_p8_kernel<1, 2, {ek}>' in gemm_kernels, ek
+    assert 'gemm_p8_kernel<0, 4, 3>' in gemm_kernels
