@@ -362,7 +362,7 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
     if (epi >= 2048) { accum = 1; epi -= 2048; }              // 4 + 2048: in-place residual accumulation (splitk 1)
     if (epi >= 1024) { flags |= 128; epi -= 1024; }           // epi + 1024: 256x256 kernel with four phases per K-tile (A/B)
     if (epi >= 512) { flags |= 64; epi -= 512; }              // epi + 512: 256x256 kernel with two phases per K-tile (A/B)
-    if (epi >= 256) { flags |= 32; epi -= 256; }              // epi + 256: eight-phase kernel without s_setprio (A/B)
+    if (epi >= 256) { flags |= 32; epi -= 256; }              // epi + 256: accepted and ignored (was: 256x256 kernel without s_setprio, measured null in round 2)
     if (epi >= 64) { glds = epi / 32; epi -= glds * 32; }      // epi + 32 * stages: LDS-DMA operand staging (2 or 3 stages)
     if (epi >= 16) { flags |= 1; epi -= 16; }      // epi + 16: skip the epilogue (ablation)
     GemmArgs a{};
