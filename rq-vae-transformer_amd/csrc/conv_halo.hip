@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
         if (FUSE_GN) {
             const float* gn = p.gn + ((long)d.img * p.Cin + cq * 8) * 2;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4);
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + e * 4) * RQ_LOG2E;      // rq_silu_l2 takes the argument pre-scaled
         }
 #pragma unroll
         for (int k = 0; k < PIT; ++k) {
@@ -1079,8 +1079,8 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
                 for (int e = 0; e < 8; e += 2) {
                     const f32x4 ss = gs[e >> 1];
                     const float a = fmaf(f[e], ss[0], ss[1]), b = fmaf(f[e + 1], ss[2], ss[3]);
-                    f[e] = a * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * a));
-                    f[e + 1] = b * rq_fast_rcp(1.0f + rq_fast_exp2(-1.4426950408889634f * b));
+                    f[e] = rq_silu_l2(a);
+                    f[e + 1] = rq_silu_l2(b);
                 }
                 v.x = pack_bf16x2(f[0], f[1]); v.y = pack_bf16x2(f[2], f[3]);
                 v.z = pack_bf16x2(f[4], f[5]); v.w = pack_bf16x2(f[6], f[7]);
@@ -1135,18 +1135,25 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        // The 36 (tap, k-step) MFMAs of a chunk run on ONE accumulator, each with both operands out of LDS: written as read, read,
+        // MFMA the stream was `rr_M` 72 times -- every MFMA waited out its own LDS round trip (~100 cycles for a 32-cycle
+        // instruction).  The fragments of step s + OD are read ahead of the MFMA of step s (OD + 1 register sets in rotation).
+        constexpr int OD = 4;
         for (int c = 0; c < NC; ++c) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap - ky * 3;
+            bf16x8 af[OD + 1], wf[OD + 1];
+            auto frag = [&](int s, bf16x8& a, bf16x8& w) {         // s = tap * 4 + ks
+                const int tap = s >> 2, ks = s & 3, ky = tap / 3, kx = tap - ky * 3;
                 const unsigned ha = (unsigned)(c * O_PLANE) + halo_lds_off(wave + ky, ftx + kx, fk);
-                const char* wt = wl + (tap * p.Cin + c * 64) * 2;
+                a = as_bf16x8(ld128(sH + (ha ^ (unsigned)(ks << 5))));
+                w = as_bf16x8(ld128(wl + (tap * p.Cin + c * 64) * 2 + ks * 32));
+            };
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 af = as_bf16x8(ld128(sH + (ha ^ (unsigned)(ks << 5))));
-                    const bf16x8 wf = as_bf16x8(ld128(wt + ks * 32));
-                    acc = rq_mfma_32x32x16_bf16(wf, af, acc);
-                }
+            for (int s = 0; s < OD; ++s) frag(s, af[s], wf[s]);
+#pragma unroll
+            for (int s = 0; s < 36; ++s) {
+                if (s + OD < 36) frag(s + OD, af[(s + OD) % (OD + 1)], wf[(s + OD) % (OD + 1)]);
+                acc = rq_mfma_32x32x16_bf16(wf[s % (OD + 1)], af[s % (OD + 1)], acc);
+                rq_sched_barrier();
             }
         }
         // C/D layout: lanes 0..31 hold rows (= cout) 0..3 of column (= pixel) lane in acc[0..3]

@@ -3,6 +3,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'rq-vae-transformer_amd'))
 from rqvae import _native as nat
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (scripts/build_variant.py; diagnostics only)
+    nat.LIB_PATH = os.environ['RQ_LIB']
 dev = 'cuda'
 B, H, Cin, Cout = int(os.environ.get('RQ_B', 64)), 256, 128, 3
 g = torch.Generator(device=dev).manual_seed(0)
