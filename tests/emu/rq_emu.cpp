@@ -10,6 +10,7 @@ dim3 g_blockIdx, g_blockDim, g_gridDim;
 std::function<void()> g_entry;
 
 static std::vector<char*> g_stacks;
+bool g_dma_late = false;
 
 unsigned char* dyn_smem() { return g_blk->dyn.data(); }
 size_t dyn_smem_size() { return g_blk->dyn.size(); }
@@ -17,6 +18,7 @@ size_t dyn_smem_size() { return g_blk->dyn.size(); }
 static void trampoline() {
     g_entry();
     Fiber& f = *g_cur;
+    dma_land_until(f, 0);          // a wavefront's outstanding DMAs complete before it retires
     f.done = true;
     Block& b = *g_blk;
     b.waves[f.wave].nalive--;
@@ -32,6 +34,10 @@ void run_grid(dim3 grid, dim3 block, size_t smem) {
     while ((int)g_stacks.size() < nthreads) g_stacks.push_back((char*)malloc(kStack));
     g_blockDim = block;
     g_gridDim = grid;
+    {
+        const char* e = getenv("RQ_EMU_DMA");
+        g_dma_late = e && strcmp(e, "late") == 0;
+    }
     for (unsigned bz = 0; bz < grid.z; ++bz)
         for (unsigned by = 0; by < grid.y; ++by)
             for (unsigned bx = 0; bx < grid.x; ++bx) {

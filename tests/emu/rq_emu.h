@@ -44,6 +44,12 @@ struct Wave {
     unsigned char mail[2][kWave][kMail];
 };
 
+// one lane's share (16 bytes) of an LDS-DMA instruction that has been issued and has not landed yet (RQ_EMU_DMA=late)
+struct PendingDma {
+    char* dst;
+    unsigned char data[16];
+};
+
 struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
@@ -51,7 +57,20 @@ struct Fiber {
     int lane = 0, wave = 0;
     unsigned gen = 0;   // per-fiber count of wave exchanges
     bool done = false;
+    std::vector<PendingDma> dma;   // issue order; front = oldest
 };
+
+// RQ_EMU_DMA=late (environment, read at every launch): an LDS-DMA lands when the issuing lane's counted s_waitcnt vmcnt(N) retires it
+// (or when its kernel ends) -- the LATEST moment the hardware allows -- so a ds_read that is not ordered behind the covering wait
+// (and, for other wavefronts' reads, a barrier after it) returns the OLD LDS bytes, as it may on the GPU: a RAW hazard turns into
+// wrong results.  Default (early): the DMA lands at issue, the EARLIEST moment, which is the worst case for WAR hazards (a unit
+// refilled while some wavefront still has to read it).  A kernel's LDS-DMA schedule should pass in both modes.
+extern bool g_dma_late;
+inline void dma_land_until(Fiber& f, size_t keep) {
+    size_t n = f.dma.size() > keep ? f.dma.size() - keep : 0;
+    for (size_t i = 0; i < n; ++i) memcpy(f.dma[i].dst, f.dma[i].data, 16);
+    if (n) f.dma.erase(f.dma.begin(), f.dma.begin() + (long)n);
+}
 
 struct Block {
     std::vector<Fiber> fibers;
@@ -127,7 +146,14 @@ static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
         fprintf(stderr, "rq_glds16: LDS destination %ld outside the %zu-byte dynamic segment\n", (long)(dst - (char*)rqemu::dyn_smem()), rqemu::dyn_smem_size());
         abort();
     }
-    memcpy(dst, gsrc, 16);
+    if (rqemu::g_dma_late) {
+        rqemu::PendingDma pd;
+        pd.dst = dst;
+        memcpy(pd.data, gsrc, 16);
+        rqemu::g_cur->dma.push_back(pd);
+    } else {
+        memcpy(dst, gsrc, 16);
+    }
 }
 static inline void rq_glds16_s(uintptr_t lds_base, const void* sbase, unsigned voff) { rq_glds16(lds_base, (const char*)sbase + voff); }
 template <int POL = 0>
@@ -135,7 +161,9 @@ static inline void rq_glds16_s2(uintptr_t lds_base, const void* sbase, unsigned 
     rq_glds16(lds_base, (const char*)sbase + voff0);
     rq_glds16(lds_base + 1024, (const char*)sbase + voff1);
 }
-template <int N> static inline void rq_wait_vmcnt() {}
+// counted wait: the issuing lane's DMAs land, oldest first, until at most N are outstanding (hardware also counts the lane's other
+// global loads there; the kernels that use counted waits issue none between their DMAs)
+template <int N> static inline void rq_wait_vmcnt() { if (rqemu::g_dma_late) rqemu::dma_land_until(*rqemu::g_cur, (size_t)N); }
 template <int N> static inline void rq_wait_lgkmcnt() {}
 // A wavefront executes in lockstep: past any point of the program every lane has issued everything before it.  The emulator runs
 // lanes as fibers, so kernels whose lanes hand data to each other through LDS WITHOUT a workgroup barrier (gemm_stream_kernel's

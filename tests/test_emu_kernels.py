@@ -603,6 +603,21 @@ def test_emu_gemm_256x256_eight_phase(nat):
             a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
 
 
+@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream'])
+def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
+    """The LDS-DMA GEMMs again with RQ_EMU_DMA=late: a DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it --
+    the latest moment the hardware allows -- so a fragment read that is not ordered behind the covering wait (+ a barrier for other
+    wavefronts' data) returns stale LDS bytes and the result is wrong.  The default mode lands a DMA at issue (the worst case for WAR);
+    a schedule has to pass in both."""
+    monkeypatch.setenv('RQ_EMU_DMA', 'late')
+    if which == 'tiles':
+        test_emu_gemm_tiles_and_lds_dma(nat)
+    elif which == 'eight_phase':
+        test_emu_gemm_256x256_eight_phase(nat)
+    else:
+        test_emu_gemm_stream(nat)
+
+
 def test_emu_gemm_skinny(nat):
     """M <= 64 skinny kernel: k-permuted operand fragments, in-workgroup split-K over eight wavefronts, LDS reduction, global
     split-K slabs, ragged M / N, every epilogue family."""
