@@ -373,6 +373,21 @@ def verify_codes(vae, ar, codes, cond, top_k, top_p, n_rows=8):
         _native.dbg_set_row_scale(1)
     logits = logits.cpu().numpy()
     sub = sub.cpu().numpy()
+    outside, outside_relaxed = count_outside_support(logits, sub, top_k, top_p)
+    n = sub.size
+    return {'verified': bool(in_range and outside_relaxed == 0 and outside <= max(2, n // 200)), 'codes_in_range': in_range,
+            'rows_teacher_forced': len(rows), 'codes_checked': n, 'codes_outside_filtered_support': outside,
+            'codes_outside_relaxed_support': outside_relaxed,
+            'what': 'post-timed-region: codes of the last timed step; filtered support via the oracle sampler on teacher-forced logits '
+                    '(relaxed = top-k + 2 %, top-p + 0.01: no code may lie outside it)'}
+
+
+def count_outside_support(logits, codes, top_k, top_p):
+    """(strict, relaxed) numbers of codes[r, h, w, d] that have zero probability under the filtered distribution of logits[r, h, w, d, :]
+    (numpy; the oracle's restatement of sample_from_logits).  See verify_codes for the two filters."""
+    import oracle
+    sub = codes
+    rows = range(sub.shape[0])
     H, W, D = sub.shape[1:]
     # strict: the filter of the run; relaxed: top-k + 2 %, top-p + 0.01 -- the margin a code at the very edge of the support needs when
     # the teacher-forced logits come through other kernel variants than the sampled ones (text-conditioned models: the 8 checked rows
@@ -390,12 +405,7 @@ def verify_codes(vae, ar, codes, cond, top_k, top_p, n_rows=8):
                 if miss.any():
                     pr2 = oracle.filtered_probs(logits[:, h, w, d], 1.0, k_rel, p_rel)
                     outside_relaxed += int((pr2[np.arange(len(rows)), sub[:, h, w, d]] <= 0).sum())
-    n = len(rows) * H * W * D
-    return {'verified': bool(in_range and outside_relaxed == 0 and outside <= max(2, n // 200)), 'codes_in_range': in_range,
-            'rows_teacher_forced': len(rows), 'codes_checked': n, 'codes_outside_filtered_support': outside,
-            'codes_outside_relaxed_support': outside_relaxed,
-            'what': 'post-timed-region: codes of the last timed step; filtered support via the oracle sampler on teacher-forced logits '
-                    '(relaxed = top-k + 2 %, top-p + 0.01: no code may lie outside it)'}
+    return outside, outside_relaxed
 
 
 def timed_batch(vae, ar, B, device, top_k, top_p, steps, warmup):

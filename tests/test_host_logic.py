@@ -120,3 +120,30 @@ def test_sample_argument_normalisation(monkeypatch):
                 return [torch.zeros((100, 64))] * 4
     with pytest.raises(ValueError):
         ar.sample(z, BadAux)
+
+
+def test_bench_support_count_strict_and_relaxed():
+    """bench.py's post-run check: a sampled code must lie in the filtered support (top-k, top-p) of its teacher-forced logits; a code one
+    token outside the strict top-p edge (bf16 logits through another kernel variant move the edge) is counted but tolerated by the
+    relaxed filter (top-k + 2 %, top-p + 0.01); a code far outside fails both."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('rq_bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    V = 200
+    # descending probabilities: token i has logit -0.05 i  ->  the top-p = 0.5 support is a prefix [0, n0)
+    logits = np.tile((-0.05 * np.arange(V, dtype=np.float32))[None, None, None, None, :], (3, 1, 1, 1, 1))
+    pr = oracle.filtered_probs(logits[:, 0, 0, 0], 1.0, 100, 0.5)
+    n0 = int((pr[0] > 0).sum())
+    pr2 = oracle.filtered_probs(logits[:, 0, 0, 0], 1.0, 102, 0.51)
+    n1 = int((pr2[0] > 0).sum())
+    assert 0 < n0 < n1 < 100
+    codes = np.array([n0 - 1, n0, 150], dtype=np.int64).reshape(3, 1, 1, 1)       # inside / first token past the strict edge / far outside
+    assert bench.count_outside_support(logits, codes, 100, 0.5) == (2, 1)
+    assert bench.count_outside_support(logits[:2], codes[:2], 100, 0.5) == (1, 0)
+    assert bench.count_outside_support(logits[:1], codes[:1], 100, 0.5) == (0, 0)
+    # top-k edge: rank k is outside the strict filter, inside the relaxed one (k + 2 %)
+    codes_k = np.array([99, 100, 101, 102], dtype=np.int64).reshape(4, 1, 1, 1)
+    lg4 = np.tile(logits[:1], (4, 1, 1, 1, 1))
+    assert bench.count_outside_support(lg4, codes_k, 100, None) == (3, 1)
