@@ -18,13 +18,17 @@ import sys
 REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, '_ref')
-# the modules the sampling path imports (rqvae.models -> rqvae.utils.utils, rqvae.optimizer.loss); nothing of the trainers,
-# datasets or metrics
+# the modules the sampling path imports (rqvae.models -> rqvae.utils.utils, rqvae.optimizer.loss); nothing of the trainers
 WANT = ['rqvae/__init__.py', 'rqvae/models/**/*.py', 'rqvae/utils/__init__.py', 'rqvae/utils/utils.py',
         'rqvae/optimizer/*.py',
         # the reference's throughput DRIVER, unchanged: tests/test_gpu_reference_driver.py runs its bytecode on the MI355X on top
         # of this repo's rqvae package (rqamd_run.py -m measure_throughput with RQVAE_REFERENCE_ROOT=oracle/_ref)
-        'measure_throughput/__main__.py']
+        'measure_throughput/__main__.py',
+        # ... and its FID-sampling DRIVER with the import closure of its module level (compute_metrics -> rqvae.metrics ->
+        # rqvae.txtimg_datasets): the same test file runs main_sampling_fid's sampling loop -- sample(), one decode_code call per
+        # image, all_gather_cat, the sample pickles -- on synthetic checkpoints; the metric networks themselves are never built
+        'main_sampling_fid.py', 'compute_metrics.py', 'rqvae/metrics/*.py', 'rqvae/txtimg_datasets/*.py',
+        'rqvae/txtimg_datasets/tokenizers/*.py']
 # data files the compiled modules open next to themselves: parsed here and re-emitted (JSON is YAML), not copied
 DATA = ['measure_throughput/rq_defaults.yaml']
 
