@@ -95,3 +95,14 @@ def test_gemm_p8_schedule(gemm_kernels):
     for ek in (0, 1, 4, 5, 6):
         assert f'gemm_p8_kernel<1, 2, {ek}>' in gemm_kernels, ek
     assert 'gemm_p8_kernel<0, 4, 3>' in gemm_kernels
+
+
+def test_conv_out_reads_run_ahead_of_their_mfma(conv_kernels):
+    """Decoder.conv_out: 36 MFMAs per chunk on one accumulator, both operands out of LDS.  Written as read, read, MFMA every MFMA waited for
+    its own reads (`s_waitcnt lgkmcnt(0)` 72 times per tile); with the fragments of step s + 4 read ahead of the MFMA of step s the waits
+    are counted ones that leave the younger reads in flight."""
+    ins = conv_kernels['conv_out_halo_kernel<1>']
+    idx = [i for i, t in enumerate(ins) if t.startswith('v_mfma')]
+    assert len(idx) == 36, len(idx)                        # the chunk loop is not unrolled: 9 taps x 4 k-steps
+    waits = [int(m.group(1)) for t in ins[idx[0]:idx[-1] + 1] for m in [re.match(r's_waitcnt lgkmcnt\((\d+)\)', t)] if m]
+    assert len(waits) >= 30 and sorted(waits)[len(waits) // 2] >= 4, waits
