@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 3
+#define RQAMD_ABI_VERSION 4
 
 typedef enum {
     RQAMD_OK = 0,
@@ -67,13 +67,14 @@ int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norm
  *   (deterministic; no (n_embed x n_vec) one-hot matrix).  The caller all-reduces both over the ranks (:101-103) before
  * rqamd_rq_ema_update <- :105-118: cluster_size_ema = decay * cluster_size_ema + (1 - decay) * count, embed_ema likewise with sum;
  *   restart_vectors (n_embed, dim) fp32 or NULL: the dead-code restart with the caller's random vectors (usage = cluster_size_ema
- *   >= 1; unused codes take the random vector and cluster size 1).  In place.
+ *   >= 1; unused codes take the random vector and cluster size 1).  In place.  decay is a double (ABI v4): torch computes the step
+ *   as mul_(decay) then add_(x, alpha = 1 - decay) with alpha taken in double, and so does the kernel.
  * rqamd_rq_ema_normalize <- :120-129: weight_out[k][:] = embed_ema[k][:] / (n (cluster_size_ema[k] + eps) / (n + n_embed eps)),
  *   n = *n_total, a device scalar holding sum(cluster_size_ema) (computed by the caller). */
 int rqamd_rq_ema_accumulate(const float* x, const int64_t* idx, int64_t n_vec, int dim, int n_embed, float* count_out,
                             float* sum_out, void* stream);
 int rqamd_rq_ema_update(float* cluster_size_ema, float* embed_ema, const float* count, const float* sum,
-                        const float* restart_vectors, int n_embed, int dim, float decay, void* stream);
+                        const float* restart_vectors, int n_embed, int dim, double decay, void* stream);
 int rqamd_rq_ema_normalize(const float* cluster_size_ema, const float* embed_ema, const float* n_total, int n_embed, int dim,
                            float eps, float* weight_out, void* stream);
 
@@ -209,6 +210,14 @@ int rqamd_rqt_get_profile_attn(rqamd_rqt* h, double* attn_ms_total, int64_t* att
  * Used by the kernel-level parity test and scripts/gemm_bench.py; not part of the reference-facing surface. */
 int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                         void* out, int bm, int bn, int splitk, void* stream);
+/* The two halves of a LayerNorm folded into the GEMMs on either side of it -- how the decode step at <= 128 rows runs
+ * ln2 + mlp.0 of AttentionBlock.forward (attentions.py:135) without a launch for the LayerNorm (csrc/gemm.h, GemmArgs::xb /
+ * ln_part_in).  mode 0, producer: x[M][N] fp32 is updated in place, x = (x + A.W^T) + bias; xb[M][N] receives bf16(x) and
+ * part[N / 32][M][2] the (sum, sum of squared deviations) of every 32-column group of every row.  mode 1, consumer:
+ * out[M][N] bf16 = epi(rstd_m (A.W^T - mean_m c1[n]) + bias[n]) with A the raw rows, W the gain-folded weight, c1[n] = sum_k W[n][k],
+ * mean_m / rstd_m merged from part[K / 32][M][2] (eps 1e-5); epi 0 (none) or 1 (GELU).  bm: 66 (64-row form) or 130 (128 rows). */
+int rqamd_dbg_gemm_ln(const void* A, const void* W, int M, int N, int K, const float* bias, int mode, int epi, float* x,
+                      void* xb, float* part, const float* c1, void* out, int bm, void* stream);
 /* One raw implicit-GEMM convolution launch (the conv form of the same kernel): x NHWC bf16
  * [B][H>>ups][W>>ups][Cin] (H, W = virtual input size after the folded nearest-2x upsample), w bf16
  * [Cout][k][k][Cin], out NHWC bf16 (+bias, +resid if not NULL); stride 2 = Downsample (layers.py:50-54). */

@@ -59,6 +59,9 @@ RQT_XWIDE = rqt(2560, 40, 2, 1, 16384)
 # 3 body + 2 head layers each (configs/cc3m/stage2/*.yaml; BASELINE configs[4])
 RQT_TXT32 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=32)
 RQT_TXT64 = rqt(1280, 20, 3, 2, 16384, vocab_cond=16384, block_cond=64)
+# BASELINE configs[4] at FULL depth: the 3.9B text-to-image model = the 3.8B dims (E 2560 / 40 heads / 42 + 6 layers) with 64 BPE
+# tokens of a 16384-word vocabulary (README.md:60, notebooks/notebook_utils.py:32; same shape as rqvae/presets.py 'txt3900m')
+RQT_TXT_3900M = rqt(2560, 40, 42, 6, 16384, vocab_cond=16384, block_cond=64)
 
 # Variants of the stage-2 flags that no released config uses (primitives.py: TupleEmbedding / BatchLinear / LogitMask):
 def _variant(base, **kw):

@@ -479,7 +479,9 @@ extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float
         if (g != 1) return g;
     }
     RQ_TRY(vae_prepare(h, chunk));
-    RQ_TRY(vae_prepare_slab(h, batch % chunk ? batch % chunk : chunk));      // a tail chunk of <= SPLIT_MAX_B images divides K
+    // chunks of <= SPLIT_MAX_B images divide K over workgroups and need the slab: the FULL chunks when RQAMD_VAE_CHUNK is that small
+    // (they are the larger ones), otherwise only a tail chunk
+    RQ_TRY(vae_prepare_slab(h, chunk <= rqamd_vae::SPLIT_MAX_B ? chunk : (batch % chunk ? batch % chunk : chunk)));
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(decode_chunk(h, z_q + (size_t)b0 * lowres * lowres * c.embed_dim, n,
@@ -500,7 +502,7 @@ extern "C" int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* 
         if (g != 1) return g;
     }
     RQ_TRY(vae_prepare(h, chunk));
-    RQ_TRY(vae_prepare_slab(h, batch % chunk ? batch % chunk : chunk));
+    RQ_TRY(vae_prepare_slab(h, chunk <= rqamd_vae::SPLIT_MAX_B ? chunk : (batch % chunk ? batch % chunk : chunk)));
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(encode_chunk(h, x + (size_t)b0 * c.in_channels * c.resolution * c.resolution, n,

@@ -64,6 +64,20 @@ struct GemmArgs {
     int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
     int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
     int glds;                // 0 = register-staged operands; 2..3 = LDS-DMA ring with that many stages (dense only)
+    // ---- LayerNorm folded into the GEMMs on either side of it (gemm_stream_kernel only; the small-batch decode step, engine_rqt.hip)
+    // Producer side (accum != 0): besides updating the fp32 residual stream in place, the epilogue writes a bf16 copy of the
+    // updated rows (xb, row stride N: the next GEMM's A operand) and, per workgroup, the (sum, sum of squared deviations from the
+    // workgroup's own mean) of its 32 columns of every row (ln_part_out[blockIdx.x][M][2]).
+    bf16_t* xb;
+    float* ln_part_out;
+    // Consumer side (ln_part_in != nullptr; bf16 epilogues): A is the RAW residual row (bf16), W is the weight with the LayerNorm
+    // gain folded in (W[n][k] * gamma[k], rounded once), and the normalisation is applied to the accumulator:
+    //     out[m][n] = rstd_m * (acc[m][n] - mean_m * ln_c1[n]) + bias[n],   ln_c1[n] = sum_k Wg[n][k],  bias[n] = b[n] + sum_k W[n][k] beta[k]
+    // = Linear(LayerNorm(x)) (attentions.py:128,135 of the reference) with mean_m / rstd_m merged from the producer's ln_n_part partials.
+    const float* ln_part_in;
+    const float* ln_c1;
+    int ln_n_part;
+    float ln_eps;
 };
 
 // GELU of the transformer MLP (attentions.py:17-22 of the reference): v1 = x * Phi(x), v2 = x * sigmoid(1.702 x).
@@ -1420,8 +1434,18 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
 // pieces.  blockIdx.z = split-K slice (fp32 partial slabs, residual-producing GEMMs).  The arithmetic of an output element
 // (K-tiles of a slice dealt round-robin to four accumulators, MFMA order inside a tile, reduction order) does not depend on
 // BM, so the 64- and 128-row forms agree bit for bit.
+#ifdef RQ_STREAM_TRACE
+// Diagnostics build only (scripts/stream_trace.py): constant-clock (100 MHz) stamps of every workgroup's phases
+static __device__ unsigned long long g_stream_trace[1024 * 2 * 8];
+#define RQ_ST(slot) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3) && blockIdx.y == 0) { \
+        const int wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                                                          \
+        if (wg_ < 1024) g_stream_trace[(wg_ * 2 + ((threadIdx.x >> 6) == 3)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define RQ_ST(slot) do { } while (0)
+#endif
 template <int BM>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
+    RQ_ST(0);
     constexpr int BN = 32, BK = 64, NW = 4;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, SLOT = A_BYTES + W_BYTES;
     constexpr int NS = BM == 64 ? 3 : 2;               // slots per wavefront
@@ -1484,6 +1508,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
         if (s0 < n_mine) issue(s0, s0);
+    RQ_ST(1);
     // what the epilogue needs from global memory (bias, and the fp32 residual rows of the in-place update) is requested now, under the
     // streaming loop: fetched after it, each was a dependent L2 / HBM round trip (~1.5 us) at the very end of a ~7-us kernel
     const float* bias = p.bias;
@@ -1504,6 +1529,50 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
             for (int e = 0; e < 8; ++e) xr[rr][e] = (accum && m < p.M && n + e < p.N) ? ((const float*)p.out)[(long)m * p.ldo + n + e] : 0.f;
         }
     }
+    // LayerNorm applied in the epilogue (GemmArgs::ln_part_in): the row's mean / rstd are merged here, while the first K-tiles are in
+    // flight, from the producer's per-workgroup partials (sum, M2 about the partial's own mean, 32 columns each).  The four threads
+    // of a row take every fourth partial, two passes over registers (mean first, then M2 += 32 (mean_j - mean)^2: Chan's update with
+    // equal counts), quad butterflies by DPP -- a fixed order, so a row's statistics depend on nothing but the row.
+    constexpr int LN_PS = 32;                        // partials per thread: ln_n_part <= 128, i.e. K <= 4096
+    float c1v[8], ln_mu[BM / 64], ln_rs[BM / 64];
+#pragma unroll
+    for (int rr = 0; rr < BM / 64; ++rr) { ln_mu[rr] = 0.f; ln_rs[rr] = 1.f; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c1v[e] = 0.f;
+    if (p.ln_part_in) {                              // uniform
+        const int n = n0 + c0, sub = tid & 3;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c1v[e] = (n + e < p.N) ? p.ln_c1[n + e] : 0.f;
+        const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+        for (int rr = 0; rr < BM / 64; ++rr) {
+            int m = m0 + (tid >> 2) + 64 * rr;
+            m = m < p.M ? m : p.M - 1;
+            f32x2 ps[LN_PS];
+#pragma unroll
+            for (int i = 0; i < LN_PS; ++i) {
+                const int j = 4 * i + sub;
+                ps[i] = (f32x2){0.f, 0.f};
+                if (j < p.ln_n_part) ps[i] = *(const f32x2*)(p.ln_part_in + ((long)j * p.M + m) * 2);
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_PS; ++i) s += ps[i].x;
+            s += rq_dpp_xor1(s);
+            s += rq_dpp_xor2(s);
+            const float mean = s * inv_k;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_PS; ++i) {
+                const float d = ps[i].x * (1.0f / 32.0f) - mean;
+                if (4 * i + sub < p.ln_n_part) q += fmaf(32.0f * d, d, ps[i].y);
+            }
+            q += rq_dpp_xor1(q);
+            q += rq_dpp_xor2(q);
+            ln_mu[rr] = mean;
+            ln_rs[rr] = 1.0f / sqrtf(q * inv_k + p.ln_eps);
+        }
+    }
     int slot = 0;
     for (int i = 0; i < n_mine; ++i) {
         const int newer = n_mine - 1 - i;            // tiles issued after tile i that may still be in flight (at most NS - 1)
@@ -1511,6 +1580,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         else if (newer >= 1) rq_wait_vmcnt<PER>();
         else rq_wait_vmcnt<0>();
         rq_wave_sync();                              // every lane's share of the tile has landed
+        if (i == 0) RQ_ST(2);
         const char* sb = (const char*)smem + (wave * NS + slot) * SLOT;
         bf16x8 af[MI][4], bfr[4];
 #pragma unroll
@@ -1531,7 +1601,9 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
     }
 
     // ---- cross-wavefront reduction (wavefront order) + epilogue
+    RQ_ST(3);
     rq_syncthreads();                                // every wavefront is done with its ring
+    RQ_ST(4);
     float* sRed = (float*)smem;                      // [NW][BM][RS]
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -1541,11 +1613,14 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
             sRed[(wave * BM + row) * RS + frow] = acc[mi][r];
         }
     rq_syncthreads();
+    RQ_ST(5);
 #pragma unroll
     for (int rr = 0; rr < BM / 64; ++rr) {
         const int row = (tid >> 2) + 64 * rr;
         const int m = m0 + row, n = n0 + c0;
-        if (m >= p.M || n >= p.N) continue;
+        const bool ln_out = accum && p.xb;           // uniform: every lane stays for the quad reductions of the LayerNorm partials
+        const bool valid = m < p.M && n < p.N;
+        if (!valid && !ln_out) continue;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1556,8 +1631,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         }
         const bool full = n + 7 < p.N;
         if (epi <= EPI_BF16_RESID) {
+            if (p.ln_part_in) {                      // uniform: Linear(LayerNorm(x)) from the raw row, see GemmArgs::ln_part_in
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                for (int e = 0; e < 8; ++e) v[e] = fmaf(ln_rs[rr], fmaf(-ln_mu[rr], c1v[e], v[e]), bv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            }
             if (epi == EPI_BF16_GELU) {
                 float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
                 rq_gelu4(lo, p.gelu_v2);
@@ -1577,19 +1657,41 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
             }
         } else {
             float* o = (float*)p.out + ((epi == EPI_F32_PARTIAL && !accum) ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
-            if (full && (p.ldo & 3) == 0) {
+            if (ln_out || (full && (p.ldo & 3) == 0)) {      // (ln_out: the launcher checked N % 32 == 0 and ldo % 4 == 0)
                 f32x4 lo, hi;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     lo[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
                     hi[e] = accum ? (xr[rr][4 + e] + v[4 + e]) + bv[4 + e] : v[4 + e] + bv[4 + e];
                 }
-                *(f32x4*)o = lo;
-                *(f32x4*)(o + 4) = hi;
+                if (valid) {
+                    *(f32x4*)o = lo;
+                    *(f32x4*)(o + 4) = hi;
+                }
+                if (ln_out) {                        // the LayerNorm hand-off, GemmArgs::xb / ln_part_out
+                    rq_u128 u;
+                    u.x = pack_bf16x2(lo[0], lo[1]); u.y = pack_bf16x2(lo[2], lo[3]); u.z = pack_bf16x2(hi[0], hi[1]); u.w = pack_bf16x2(hi[2], hi[3]);
+                    if (valid) st128(p.xb + (long)m * p.N + n, u);
+                    float sm = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((hi[0] + hi[1]) + (hi[2] + hi[3]));
+                    sm += rq_dpp_xor1(sm);           // the four threads of a row: its 32 columns in this workgroup
+                    sm += rq_dpp_xor2(sm);
+                    const float mu = sm * (1.0f / 32.0f);
+                    float q = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float dl = lo[e] - mu, dh = hi[e] - mu; q = fmaf(dl, dl, q); q = fmaf(dh, dh, q); }
+                    q += rq_dpp_xor1(q);
+                    q += rq_dpp_xor2(q);
+                    if (valid && (tid & 3) == 0) *(f32x2*)(p.ln_part_out + ((long)blockIdx.x * p.M + m) * 2) = (f32x2){sm, q};
+                }
             } else {
                 for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
             }
         }
     }
+    RQ_ST(6);
+#ifdef RQ_STREAM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have been acknowledged
+    RQ_ST(7);
+#endif
 }
 

@@ -154,6 +154,14 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         return rq_fail(RQAMD_ERR_INVALID, "gemm: virtual split-K needs a conv with a bf16 epilogue, one real split and an even number of K-tiles per chunk");
     if (a.accum && (a.epi != EPI_F32_PARTIAL || a.splitk != 1 || (a.N & 3) || (a.ldo & 3) || (bm == 64 && bn == 32)))
         return rq_fail(RQAMD_ERR_INVALID, "gemm: in-place accumulation needs the slab epilogue, one K split and N, ldo multiples of 4");
+    if (a.xb || a.ln_part_out || a.ln_part_in) {      // LayerNorm folded into the GEMMs around it: gemm_stream_kernel only
+        if (!((bm == 66 || bm == 130) && bn == 32) || a.conv)
+            return rq_fail(RQAMD_ERR_INVALID, "gemm: the folded-LayerNorm epilogues exist in the weight-streaming kernel only");
+        if ((a.xb || a.ln_part_out) && (!a.xb || !a.ln_part_out || !a.accum || (a.N & 31) || (a.ldo & 3)))
+            return rq_fail(RQAMD_ERR_INVALID, "gemm: LayerNorm partials need the in-place residual epilogue, xb and ln_part_out, N %% 32 == 0");
+        if (a.ln_part_in && (a.epi > EPI_BF16_GELU || !a.ln_c1 || a.ln_n_part < 1 || a.ln_n_part > 128 || a.ln_n_part * 32 != a.K))
+            return rq_fail(RQAMD_ERR_INVALID, "gemm: the folded LayerNorm needs a bf16 epilogue, ln_c1 and K / 32 <= 128 partials");
+    }
     if ((bm == 66 || bm == 130) && bn == 32) {      // tile codes 66x32 / 130x32: the weight-streaming kernel on 64 / 128 activation rows
         if (a.conv) return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm stream: dense operands only");
         return bm == 66 ? launch_stream<64>(a, stream) : launch_stream<128>(a, stream);
@@ -379,6 +387,24 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
 }
 
+// diagnostics: the two halves of a LayerNorm folded into the GEMMs around it (gemm_stream_kernel; GemmArgs::xb / ln_part_in).
+//  mode 0 (producer): x[M][N] fp32 is updated in place, x = (x + A W^T) + bias; xb[M][N] bf16 and part[N / 32][M][2] are written.
+//  mode 1 (consumer): out[M][N] bf16 = epi(rstd_m (A W^T - mean_m c1) + bias), statistics merged from part[K / 32][M][2]; epi 0 / 1.
+extern "C" int rqamd_dbg_gemm_ln(const void* A, const void* W, int M, int N, int K, const float* bias, int mode, int epi, float* x,
+                                 void* xb, float* part, const float* c1, void* out, int bm, void* stream) {
+    if (!A || !W || !part) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.bias = bias; a.splitk = 1;
+    if (mode == 0) {
+        if (!x || !xb) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
+        a.epi = EPI_F32_PARTIAL; a.accum = 1; a.out = x; a.ldo = N; a.xb = (bf16_t*)xb; a.ln_part_out = part;
+    } else {
+        if (!out || !c1) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
+        a.epi = epi; a.out = out; a.ldo = N; a.ln_part_in = part; a.ln_c1 = c1; a.ln_n_part = K / 32; a.ln_eps = 1e-5f;
+    }
+    return rq_gemm_launch(a, bm == 130 ? 130 : 66, 32, (hipStream_t)stream);
+}
+
 // diagnostics: one implicit-GEMM convolution launch.  x NHWC bf16 [B][H>>ups][W>>ups][Cin], w [Cout][k][k][Cin] bf16,
 // out NHWC bf16 [B][Ho][Wo][Cout] (+bias, +resid when given).  flags bit0: skip the epilogue (ablation).
 extern "C" int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bias, const void* resid, int B, int H, int W,
@@ -397,6 +423,18 @@ extern "C" int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bi
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
 }
 
+#ifdef RQ_STREAM_TRACE
+// diagnostics build only (scripts/stream_trace.py)
+extern "C" int rqamd_dbg_stream_trace(unsigned long long* out_host, int clear) {
+    if (clear) {
+        static unsigned long long zeros[1024 * 2 * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stream_trace), zeros, sizeof(zeros)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "stream_trace: clear failed");
+        return RQAMD_OK;
+    }
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stream_trace), sizeof(g_stream_trace)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "stream_trace: copy failed");
+    return RQAMD_OK;
+}
+#endif
 #ifdef RQ_GEMM_TRACE
 // diagnostics build only (scripts/gemm_trace.sh)
 extern "C" int rqamd_dbg_gemm_trace(unsigned long long* out_host) {

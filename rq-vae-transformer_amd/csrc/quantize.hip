@@ -535,13 +535,16 @@ __global__ __launch_bounds__(256) void rq_ema_accumulate_kernel(const float* x, 
 // cluster_size_ema.mul_(decay).add_(count, alpha = 1 - decay); embed_ema likewise; then (restart != null) the dead-code restart:
 // usage = cluster_size_ema >= 1; embed_ema = embed_ema * usage + restart * (1 - usage); cluster_size_ema = cluster_size_ema *
 // usage + (1 - usage)   (quantizations.py:103-118).  One thread per (code, dim).
+// The arithmetic mirrors torch's two steps: mul_(decay) rounds the product, add_(x, alpha) is one fused multiply-add with alpha =
+// float(1 - decay) taken in DOUBLE (1 - 0.99 -> 0.01f, not 1.0f - 0.99f = 0.00999999), so that values next to the restart
+// threshold cs >= 1 fall on the reference's side of it.
 __global__ void rq_ema_update_kernel(float* cs_ema, float* embed_ema, const float* count, const float* sum, const float* restart,
-                                     int K, int D, float decay) {
+                                     int K, int D, float decay, float alpha) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long)K * D) return;
     const int k = (int)(gid / D);
-    float cs = cs_ema[k] * decay + (1.0f - decay) * count[k];
-    float e = embed_ema[gid] * decay + (1.0f - decay) * sum[gid];
+    float cs = fmaf(alpha, count[k], cs_ema[k] * decay);
+    float e = fmaf(alpha, sum[gid], embed_ema[gid] * decay);
     if (restart) {
         const float usage = cs >= 1.0f ? 1.0f : 0.0f;
         e = e * usage + restart[gid] * (1.0f - usage);
@@ -549,10 +552,10 @@ __global__ void rq_ema_update_kernel(float* cs_ema, float* embed_ema, const floa
     }
     embed_ema[gid] = e;      // cluster_size_ema[k] is read by every thread of the row: it is updated by rq_ema_cs_kernel, after this launch
 }
-__global__ void rq_ema_cs_kernel(float* cs_ema, const float* count, int K, float decay, int restart) {
+__global__ void rq_ema_cs_kernel(float* cs_ema, const float* count, int K, float decay, float alpha, int restart) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    float cs = cs_ema[k] * decay + (1.0f - decay) * count[k];
+    float cs = fmaf(alpha, count[k], cs_ema[k] * decay);
     if (restart) {
         const float usage = cs >= 1.0f ? 1.0f : 0.0f;
         cs = cs * usage + (1.0f - usage);
@@ -581,15 +584,16 @@ extern "C" int rqamd_rq_ema_accumulate(const float* x, const int64_t* idx, int64
 }
 
 extern "C" int rqamd_rq_ema_update(float* cluster_size_ema, float* embed_ema, const float* count, const float* sum, const float* restart_vectors,
-                                   int n_embed, int dim, float decay, void* stream) {
+                                   int n_embed, int dim, double decay, void* stream) {
     if (!cluster_size_ema || !embed_ema || !count || !sum) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_update: null argument");
     if (n_embed < 1 || dim < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_ema_update: bad shape");
     const long n = (long)n_embed * dim;
     // embed_ema first (it reads the OLD cluster_size_ema for the restart decision), then cluster_size_ema itself
     RQ_LAUNCH(rq_ema_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, embed_ema, count, sum,
-              restart_vectors, n_embed, dim, decay);
+              restart_vectors, n_embed, dim, (float)decay, (float)(1.0 - decay));
     RQ_TRY(rq_check_launch("rq_ema_update_kernel"));
-    RQ_LAUNCH(rq_ema_cs_kernel, dim3((n_embed + 255) / 256), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, count, n_embed, decay, restart_vectors ? 1 : 0);
+    RQ_LAUNCH(rq_ema_cs_kernel, dim3((n_embed + 255) / 256), dim3(256), 0, (hipStream_t)stream, cluster_size_ema, count, n_embed, (float)decay,
+              (float)(1.0 - decay), restart_vectors ? 1 : 0);
     return rq_check_launch("rq_ema_cs_kernel");
 }
 

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RqamdError(RuntimeError):
@@ -49,7 +49,7 @@ _SIGS = {
                                       C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p]),
     'rqamd_rq_ema_accumulate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'rqamd_rq_ema_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'rqamd_rq_ema_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     'rqamd_rq_ema_normalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     'rqamd_rq_embed': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
@@ -78,6 +78,8 @@ _SIGS = {
     'rqamd_rqt_get_profile_attn': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'rqamd_dbg_gemm_ln': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -301,6 +303,30 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
             out = torch.empty((M, N), dtype=torch.float32 if kind == 3 else torch.bfloat16, device=a_bf16.device)
     check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
                                     ptr(out), bm, bn, splitk, stream_of(a_bf16)))
+    return out
+
+
+def dbg_gemm_ln_producer(a_bf16, w_bf16, bias, x, bm=66):
+    """diagnostics: the residual-producing half of a folded LayerNorm: x (M,N) fp32 is updated in place, x = (x + a @ w^T) + bias;
+    returns (xb, part): bf16(x) and the per-32-column LayerNorm partials (N / 32, M, 2)."""
+    M, K = a_bf16.shape
+    N = w_bf16.shape[0]
+    xb = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    part = torch.empty((N // 32, M, 2), dtype=torch.float32, device=x.device)
+    check(lib().rqamd_dbg_gemm_ln(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias, torch.float32), 0, 0,
+                                  ptr(x, torch.float32), ptr(xb), ptr(part), None, None, bm, stream_of(x)))
+    return xb, part
+
+
+def dbg_gemm_ln_consumer(xb, wg_bf16, c1, c2, part, gelu=False, bm=66):
+    """diagnostics: Linear(LayerNorm(x)) from the raw bf16 rows xb (M,K), the gain-folded weight wg (N,K), c1 = wg.sum(1),
+    c2 = bias + W @ beta and the producer's partials; returns (M,N) bf16."""
+    M, K = xb.shape
+    N = wg_bf16.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=xb.device)
+    check(lib().rqamd_dbg_gemm_ln(ptr(xb, torch.bfloat16), ptr(wg_bf16, torch.bfloat16), M, N, K, ptr(c2, torch.float32), 1,
+                                  1 if gelu else 0, None, None, ptr(part, torch.float32), ptr(c1, torch.float32), ptr(out), bm,
+                                  stream_of(xb)))
     return out
 
 

@@ -243,7 +243,9 @@ class RQTransformer(Stage2Model):
         logits of the whole code map from the codes drawn so far (one teacher-forced pass of the engine per step, 256 per
         batch, as slow as the reference's own uncached loop) and samples position (h, w, d) from them with the draw the
         cached path would make at that step (same Philox key: seed, offset + step).  It exists, as in the reference, as the
-        cross-check of the cache: the codes equal ``cached=True`` bit for bit (tests/test_gpu_parity.py)."""
+        cross-check of the cache: the codes equal ``cached=True`` bit for bit (tests/test_gpu_parity.py).  (Both paths step the
+        engine with B rows per launch -- the teacher-forced pass is the cached stepping over given codes, not one (B*H*W*D)-row
+        pass -- so both pick the same kernels for a given B)"""
         from ... import _native
         (H, W, D) = self.block_size
         start = max(int(start_loc[0]) * W + int(start_loc[1]), 0)

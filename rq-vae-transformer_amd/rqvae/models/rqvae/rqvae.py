@@ -49,7 +49,12 @@ class _ReadAhead:
     and summation order is a function of the layer, not of the batch), and a window is served only while the base tensor
     object, its storage, its version counter, the weights involved and the window's own version counters are what they were
     when it was computed (tests/test_gpu_parity.py::test_vae_decode_code_read_ahead, ::test_vae_forward_read_ahead).
-    RQAMD_DECODE_AHEAD=<max rows per window> (0 = off)."""
+    RQAMD_DECODE_AHEAD=<max rows per window> (0 = off).
+
+    Two things differ from the reference's fresh tensor per call and are the price of the batched rate: the rows handed out are
+    VIEWS of one window buffer (up to 512 images = 400 MB at 256x256 per model; keeping one row alive keeps its window alive
+    until the next miss), and an in-place edit of a served row ends read-ahead for that run (see serve).  Calls under
+    torch.inference_mode() take the plain path."""
     RAMP = 8
 
     def __init__(self):
@@ -64,6 +69,7 @@ class _ReadAhead:
         self.versions = None
         self.next_row = -1            # the row a sequential caller asks for next
         self.window = 0               # rows computed by the last engine call of this run
+        self.ramp_ok = True           # False once a served row of this base was edited in place: no read-ahead for this base
         self.event = None
         self.stream = None
         self.hits = self.engine_calls = 0
@@ -90,10 +96,15 @@ class _ReadAhead:
         if rows is None:
             return None
         base, i0, n = rows
+        # Inference tensors carry no version counter (`t._version` raises): neither a batch created under torch.inference_mode()
+        # nor the results this would compute inside it can be watched for in-place edits, so such calls take the plain path.
+        if torch.is_inference_mode_enabled() or base.is_inference() or arg.is_inference():
+            return None
         key = (base.data_ptr(), base._version, tuple(base.shape), base.dtype, weights_signature())
         same = self.base_ref is not None and self.base_ref() is base and self.key == key
-        if same and self.results is not None and self.lo <= i0 and i0 + n <= self.hi and \
-                all(t._version == v for t, v in zip(self.results, self.versions)):
+        covered = same and self.results is not None and self.lo <= i0 and i0 + n <= self.hi
+        edited = covered and not all(t._version == v for t, v in zip(self.results, self.versions))
+        if covered and not edited:
             if arg.is_cuda:
                 cur = torch.cuda.current_stream(arg.device)
                 if cur != self.stream:
@@ -102,7 +113,15 @@ class _ReadAhead:
             self.hits += 1
             return tuple(t[i0 - self.lo:i0 - self.lo + n] for t in self.results)
         window = n
-        if same and i0 == self.next_row:               # a sequential run: read ahead, RAMP x what the last engine call computed
+        # A caller that edits the rows it is handed in place (decode_code(c[i:i+1]).clamp_()) bumps the version counter the whole
+        # window shares: every later call would miss and recompute a ramped-up window -- read-ahead is dropped for this base
+        # instead (one row per call, what the caller would get without it).
+        if not same:
+            self.ramp_ok = True
+        elif edited:
+            self.ramp_ok = False
+        if same and i0 == self.next_row and self.ramp_ok:
+            # a sequential run: read ahead, RAMP x what the last engine call computed
             window = max(n, min(self.window * self.RAMP, self.max_rows, base.shape[0] - i0))
         results = tuple(compute(base[i0:i0 + window]))
         self.base_ref, self.key = weakref.ref(base), key
@@ -154,7 +173,9 @@ class RQVAE(Stage1Model):
 
     # ------------------------------------------------------------------ engine plumbing
     def _eng(self):
-        sig = signature(self)
+        # what the engine holds: encoder, decoder and the two 1x1 convs -- not the quantizer (push_all skips it), whose EMA
+        # buffers change at every train-mode forward and would otherwise trigger a re-push of all ~398 tensors per step
+        sig = signature(self.encoder, self.decoder, self.quant_conv, self.post_quant_conv)
         dev = self.quant_conv.weight.device
         if self._engine is not None and self._engine.device != dev:
             self._engine.close()                        # the module moved (model.to(other device)): rebuild there

@@ -179,6 +179,23 @@ def gen_vae():
              z_e=z_e, enc_codes=ecodes.astype(np.int32), dec_absmax=np.float32(np.abs(dec).max()))
 
 
+def gen_vae_batch():
+    """Round 4: the released ImageNet RQ-VAE shape on a BATCH -- decode_code of 4 code maps (stored fp16: the
+    tests report PSNR and the post-clamp uint8 difference, main_sampling_fid.py:223-225) and encode / get_codes of 8 images."""
+    hps, dd = C.VAE_IMAGENET
+    m, params = ref_rqvae(hps, dd, seed=33)
+    rng = np.random.default_rng(35)
+    codes = rng.integers(0, hps['n_embed'], (4, 8, 8, 4))
+    dec = m.decode_code(torch.from_numpy(codes)).numpy()
+    x = np.clip(rng.standard_normal((8, 3, 256, 256), dtype=np.float32), -1, 1)
+    xt = torch.from_numpy(x)
+    z_e = torch.cat([m.encode(xt[i:i + 2]) for i in range(0, 8, 2)]).numpy()
+    ecodes = torch.cat([m.get_codes(xt[i:i + 2]) for i in range(0, 8, 2)]).numpy()
+    print(f'  vae[imagenet batch] |dec| max {np.abs(dec).max():.3f} std {dec.std():.3f}; |z_e| max {np.abs(z_e).max():.3f}')
+    save('vae_imagenet_batch.npz', seed=33, data_seed=35, codes=codes.astype(np.int32), decode_code=dec.astype(np.float16),
+         z_e=z_e.astype(np.float32), enc_codes=ecodes.astype(np.int32))
+
+
 # ------------------------------------------------------------------ 4. tiny RQ-Transformer
 def gen_rqt():
     hps, dd = C.VAE_TINY
@@ -242,7 +259,10 @@ def gen_rqt_big(only=None):
     (2+1 layers), and the text-to-image width E=1280/20 heads with 32 and 64 conditioning tokens (3+2 layers; also
     the cond_classifier logits).  Stored: fp16 logits at BIG_POS x all depths; inputs/weights regenerate from seeds."""
     cases = [('in1400m', C.RQT_IN_1400M, 2, 61), ('ffhq355m', C.RQT_FFHQ_355M, 2, 62), ('xwide', C.RQT_XWIDE, 2, 63),
-             ('txt32', C.RQT_TXT32, 2, 64), ('txt64', C.RQT_TXT64, 2, 65)]
+             ('txt32', C.RQT_TXT32, 2, 64), ('txt64', C.RQT_TXT64, 2, 65),
+             # round 4 (VERDICT r03 item 2): BASELINE configs[3] / configs[4] at FULL depth (42 + 6 layers, E 2560); 15 GB of fp32
+             # weights each on the CPU -- generate one at a time: `make_golden.py rqt_big:in3800m` / `rqt_big:txt3900m`
+             ('in3800m', C.RQT_IN_3800M, 2, 66), ('txt3900m', C.RQT_TXT_3900M, 2, 67)]
     for tag, cfg, B, seed in cases:
         if only and tag not in only:
             continue
@@ -374,11 +394,11 @@ def gen_param_counts():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'rqt', 'rqt_big', 'rqt_var', 'ema', 'counts']
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'vae_batch', 'rqt', 'rqt_big', 'rqt_var', 'ema', 'counts']
     for w in which:
         print(f'[{w}]')
         if w.startswith('rqt_big:'):                      # e.g. rqt_big:txt32,txt64
             gen_rqt_big(w.split(':', 1)[1].split(','))
             continue
-        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
+        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'vae_batch': gen_vae_batch, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
          'ema': gen_ema, 'counts': gen_param_counts}[w]()

@@ -535,6 +535,43 @@ def test_emu_vae_decode_code_read_ahead(nat, golden):
         assert torch.equal(o, o0) and torch.equal(c, c0) and torch.equal(l, l0) and l.shape == l0.shape
 
 
+def test_emu_vae_read_ahead_inference_mode_and_in_place_edits(nat, golden):
+    """(1) the per-row driver loop under torch.inference_mode() -- inference tensors have no version counter, so the
+    read-ahead must step aside instead of raising; (2) a caller that edits every row it is handed in place
+    (decode_code(c[i:i+1]).clamp_()) gets correct rows and, once the first edit of a served window has been seen, one engine
+    call per row for the rest of that batch -- not a ramped-up window recomputed at every call."""
+    from rqvae.models.rqvae import RQVAE
+    g = golden('vae_tiny.npz')
+    hps, dd = C.VAE_TINY
+    params = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed']))
+    vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
+    vae.load_state_dict({k: T(v) for k, v in params.items()})
+    vae.eval()
+    rng = np.random.default_rng(22)
+    codes = T(rng.integers(0, hps['n_embed'], (6, 8, 8, 4)))
+    cold = [vae.decode_code(codes[i:i + 1].clone()) for i in range(6)]
+    st = vae._ahead
+    with torch.inference_mode():
+        rows = [vae.decode_code(codes[i:i + 1]) for i in range(6)]                   # base created outside, results inside
+        inner = codes.clone()                                                      # an inference tensor as the batch
+        rows2 = [vae.decode_code(inner[i:i + 1]) for i in range(3)]
+    assert st.hits == 0
+    for i in range(6):
+        assert torch.equal(rows[i], cold[i])
+    for i in range(3):
+        assert torch.equal(rows2[i], cold[i])
+    calls = st.engine_calls
+    out = []
+    for i in range(6):
+        r = vae.decode_code(codes[i:i + 1])
+        assert torch.equal(r, cold[i]), i
+        out.append(r.clamp_(0, 1))                                                   # in-place edit of the served row
+    # row 0 cold, rows 1.. one window of 5 (read ahead), row 2 sees the edited window: from there on one call per row
+    assert st.engine_calls - calls == 2 + 4, st.engine_calls - calls
+    for i in range(6):
+        assert torch.equal(out[i], cold[i].clamp(0, 1))
+
+
 def test_emu_gemm_tiles_and_lds_dma(nat):
     """Decode-step GEMM through the diagnostics entry: register-staged and LDS-DMA staged (2 / 3 stages) operand paths,
     ragged M / N (clamped rows), odd and even K-tile counts, bf16 / fp32 / split-K epilogues, vs fp32 matmul."""
@@ -672,6 +709,75 @@ def test_emu_gemm_stream(nat):
     ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
     out = nat.dbg_gemm(a, w, bias, epi=1, bm=66, bn=32, splitk=1).float().numpy()
     assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
+
+
+def test_emu_gemm_folded_layernorm(nat):
+    """LayerNorm folded into the GEMMs on either side of it (gemm_stream_kernel, GemmArgs::xb / ln_part_in -- the <= 128-row decode
+    step's ln2 + mlp.0, attentions.py:135): the producer updates the fp32 stream in place exactly like the plain in-place epilogue
+    and hands over bf16(x) plus per-32-column (sum, M2) partials; the consumer multiplies the RAW rows by the gain-folded weight and
+    normalises in the epilogue.  Checked against numpy LayerNorm + Linear on the fp32 rows; 64- and 128-row forms bit-identical;
+    ragged M, several m-tiles, partial counts that leave some of a row's four threads without work."""
+    rng = np.random.default_rng(29)
+    for (M, E, N2, K0) in ((64, 128, 96, 256), (37, 192, 64, 128), (128, 64, 160, 64), (200, 320, 64, 192)):
+        a = torch.from_numpy(rng.standard_normal((M, K0)).astype(np.float32)).to(torch.bfloat16)
+        wp = torch.from_numpy((0.1 * rng.standard_normal((E, K0))).astype(np.float32)).to(torch.bfloat16)
+        bp = T(rng.standard_normal(E).astype(np.float32))
+        x0 = torch.from_numpy((rng.standard_normal((M, E)) * 1.5 + 0.3).astype(np.float32))
+        gamma = (1.0 + 0.2 * rng.standard_normal(E)).astype(np.float32)
+        beta = (0.1 * rng.standard_normal(E)).astype(np.float32)
+        w1 = (0.1 * rng.standard_normal((N2, E))).astype(np.float32)
+        b1 = rng.standard_normal(N2).astype(np.float32)
+        wg = torch.from_numpy(w1 * gamma[None, :]).to(torch.bfloat16)
+        c1 = wg.float().sum(1).contiguous()
+        c2 = T(b1 + w1 @ beta)
+        outs = {}
+        for bm in (66, 130):
+            x = x0.clone()
+            xb, part = nat.dbg_gemm_ln_producer(a, wp, bp, x, bm=bm)
+            slab = nat.dbg_gemm(a, wp, None, epi=4, bm=bm, bn=32, splitk=1)[0]
+            assert torch.equal(x, (x0 + slab) + bp), (M, E, bm)                   # the plain in-place epilogue's additions
+            assert torch.equal(xb, x.to(torch.bfloat16)), (M, E, bm)
+            xg = x.numpy().reshape(M, E // 32, 32).astype(np.float64)
+            want = np.stack([xg.sum(-1), ((xg - xg.mean(-1, keepdims=True)) ** 2).sum(-1)], -1).transpose(1, 0, 2)
+            assert np.allclose(part.numpy(), want, rtol=2e-5, atol=2e-5), (M, E, bm)
+            for gelu in (False, True):
+                out = nat.dbg_gemm_ln_consumer(xb, wg, c1, c2, part, gelu=gelu, bm=bm).float().numpy()
+                xn = x.numpy().astype(np.float64)
+                ln = (xn - xn.mean(-1, keepdims=True)) / np.sqrt(xn.var(-1, keepdims=True) + 1e-5) * gamma + beta
+                ref = ln @ w1.T.astype(np.float64) + b1
+                if gelu:
+                    ref = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
+                assert np.abs(out - ref).max() < 1.5e-2 * max(np.abs(ref).max(), 1.0), (M, E, bm, gelu, np.abs(out - ref).max())
+                outs[(bm, gelu)] = out
+        for gelu in (False, True):
+            assert np.array_equal(outs[(66, gelu)], outs[(130, gelu)]), (M, E, gelu)
+
+
+def test_emu_rqt_folded_layernorm_late_parameters(nat, golden):
+    """The fold of ln2 into mlp.0 is made from the fp32 weight when the LayerNorm parameters are already there (state_dict order);
+    a LayerNorm that arrives AFTER the weight (a caller editing ln2 in place) is folded into the bf16 copy when the tables are
+    finalised.  Both orders give the fixture's logits (the late order within the extra bf16 rounding of the weight), and
+    RQAMD_NO_LNFOLD-free engines agree with the un-folded large-batch path within bf16 noise (test_emu_rqt_tiny_logits)."""
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
+    eng = _rqt_engine(nat, cfg, params)
+    first = eng.logits(codes, cond, [T(cb)] * 4).numpy()
+    late = dict((k, v) for k, v in params.items() if '.ln2.' not in k)
+    late.update((k, v) for k, v in params.items() if '.ln2.' in k)             # ln2 last
+    eng2 = _rqt_engine(nat, cfg, late)
+    second = eng2.logits(codes, cond, [T(cb)] * 4).numpy()
+    for out in (first, second):
+        err = np.abs(out - g['logits'])
+        assert err.max() < 0.06 and err.mean() < 0.01
+    assert np.abs(first - second).max() < 0.02
+    # re-pushing in state_dict order over the late-order engine restores the single-rounding fold bit for bit
+    for k, v in params.items():
+        eng2.set_param(k, T(v))
+    assert np.array_equal(eng2.logits(codes, cond, [T(cb)] * 4).numpy(), first)
 
 
 def test_emu_conv_halo(nat):

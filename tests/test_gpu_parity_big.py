@@ -4,8 +4,9 @@ CPU, seeded weights) for
 
   * the full ImageNet 1.4B model (E 1536 / 24 heads / 42 + 6 layers / V 16384) -- the headline configuration,
   * the full FFHQ 355M model (E 1024 / 16 heads / 24 + 4 layers / V 2048, unconditional) -- BASELINE configs[1],
-  * E 2560 / 40 heads (3.8B layer shapes, 2 + 1 layers) -- BASELINE configs[3],
-  * E 1280 / 20 heads with 32 and 64 text tokens (body contexts 95 / 127: the DYN attention kernels) -- configs[4].
+  * E 2560 / 40 heads (3.8B layer shapes, 2 + 1 layers) and, round 4, the FULL 3.8B model (42 + 6 layers) -- BASELINE configs[3],
+  * E 1280 / 20 heads with 32 and 64 text tokens (body contexts 95 / 127: the DYN attention kernels) and, round 4, the FULL 3.9B
+    text-to-image shape (E 2560, 42 + 6 layers, 64 text tokens, cond_classifier logits) -- configs[4].
 
 Tolerance: bf16 weights and GEMM activations, fp32 accumulation / residual stream / LayerNorm / softmax; logits have
 |max| ~ 3, std 0.58.  Bound: max |err| < 0.08, mean |err| < 0.012 (measured values are printed and recorded in
@@ -51,8 +52,10 @@ def _load(cfg, seed):
     return ar.to(DEV).eval()
 
 
+# round 4: + BASELINE configs[3] / configs[4] at FULL depth (42 + 6 layers at E 2560; the 3.9B text model with its 64 text tokens,
+# body context 127, cond_classifier included) -- the two models bench.py --model xhuge / txt3900m time
 CASES = [('in1400m', C.RQT_IN_1400M), ('ffhq355m', C.RQT_FFHQ_355M), ('xwide', C.RQT_XWIDE),
-         ('txt32', C.RQT_TXT32), ('txt64', C.RQT_TXT64)]
+         ('txt32', C.RQT_TXT32), ('txt64', C.RQT_TXT64), ('in3800m', C.RQT_IN_3800M), ('txt3900m', C.RQT_TXT_3900M)]
 
 
 @pytest.mark.parametrize('tag,cfg', CASES)
@@ -90,6 +93,23 @@ def test_rqt_logits_vs_reference(golden, tag, cfg):
         print(f'rqt {tag}: cond_logits max err {cerr.max():.4f} mean {cerr.mean():.5f}')
         assert cerr.max() < 0.08 and cerr.mean() < 0.012
     # the sampler runs at these shapes too: graph == eager, codes in range
+    if tag == 'in3800m':
+        # ... and through the kernels bench.py's batch selects for this model (256 x 256 eight-phase GEMMs, large-batch attention /
+        # LayerNorm variants): the two fixture images tiled to 514 rows, kernel selection seeing 20x as many (the row-scale hook)
+        reps = 257
+        _native.dbg_set_row_scale(20)
+        try:
+            big = ar(codes.repeat(reps, 1, 1, 1), aux, cond=cond.repeat(reps, 1))
+        finally:
+            _native.dbg_set_row_scale(1)
+        worst = 0.0
+        for r0 in (0, 256, 512):
+            gb = torch.stack([big[r0:r0 + 2, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+            worst = max(worst, float(np.abs(gb - ref).max()))
+            assert np.abs(gb - ref).mean() < 0.012
+        print(f'rqt {tag} through the large-batch kernels (514 rows, selection sees 10280): logits max err {worst:.4f}')
+        assert worst < 0.08
+        del big
     if tag in ('ffhq355m', 'txt64', 'xwide'):
         part = torch.zeros_like(codes)
         res = []
