@@ -53,6 +53,10 @@ A100_FIG4_IMG_S = 52.6          # reference Fig. 4, 1.4B 8x8x4,
 # for the N = 1536 / 4608 / 6144 GEMMs of the 1.4B model (98 % of 1 / 3 / 4 rounds); 16384 = 64 m-tiles for E = 1024,
 # 6400 = 25 m-tiles for E = 2560.
 DEFAULT_BATCH = {'huge': 10752, 'large': 10752, 'small': 10752, 'medium': 16384, 'xhuge': 6400, 'txt3900m': 2048, 'cc3m': 4096, 'tiny': 64}
+# N > 1 ranks: the two models BASELINE.json quotes on 8 GPUs are quoted at a GLOBAL batch (configs[3]: 512 = 64 per GPU; configs[4]
+# batch-sharded the same way), so their multi-GPU default is that per-GPU share; the 1.4B headline model keeps its N = 1 batch on
+# every rank (weak scaling: per-GPU work fixed, so the driver's per-N values are comparable with the N = 1 line).
+DEFAULT_BATCH_MULTI = {'xhuge': 64, 'txt3900m': 64}
 WORKLOADS = {'huge': 'BASELINE configs[2]', 'medium': 'BASELINE configs[1]', 'xhuge': 'BASELINE configs[3] dims',
              'txt3900m': 'BASELINE configs[4] dims', 'cc3m': 'CC-3M 654M'}
 
@@ -98,6 +102,14 @@ def self_launch(args, argv):
 GATHER_BUDGET_BYTES = 16 << 30
 
 
+def gather_plan(world, batch, per_img_bytes):
+    """(rows per all-gather call, number of calls) of gather_pixels for a local batch -- also what config.parallelism reports."""
+    if world * batch * per_img_bytes <= GATHER_BUDGET_BYTES:
+        return batch, 1
+    step = max(1, GATHER_BUDGET_BYTES // (world * per_img_bytes))
+    return step, (batch + step - 1) // step
+
+
 def gather_pixels(distenv, pixels):
     """main_sampling_fid.py:226: every rank receives all ranks' pixels, rank-major (rqvae.utils.dist.all_gather_cat = one
     RCCL all_gather_into_tensor).  At the bench batch the gathered fp32 tensor is world x 8.4 GB -- next to a 180 GB KV cache
@@ -105,13 +117,25 @@ def gather_pixels(distenv, pixels):
     (same bytes over xGMI, same rank-major order per slice) and each gathered slice is released before the next."""
     from rqvae.utils.dist import all_gather_cat
     per_img = pixels[0].numel() * pixels.element_size()
-    if distenv.world_size * pixels.shape[0] * per_img <= GATHER_BUDGET_BYTES:
+    step, calls = gather_plan(distenv.world_size, pixels.shape[0], per_img)
+    if calls == 1:
         return all_gather_cat(distenv, pixels)
-    step = max(1, GATHER_BUDGET_BYTES // (distenv.world_size * per_img))
     last = None
     for s0 in range(0, pixels.shape[0], step):
         last = all_gather_cat(distenv, pixels[s0:s0 + step])
     return last
+
+
+def parallelism_note(world, batch, per_img_bytes=3 * 256 * 256 * 4):
+    """config.parallelism, truthfully: how many all-gather calls a step makes and what survives them."""
+    if world <= 1:
+        return 'single GPU'
+    step, calls = gather_plan(world, batch, per_img_bytes)
+    if calls == 1:
+        return f'replica x{world}, image batches sharded, one pixel all-gather (RCCL all_gather_into_tensor) per step'
+    return (f'replica x{world}, image batches sharded; the gathered fp32 pixels ({world} x {batch} images) exceed the {GATHER_BUDGET_BYTES >> 30} GiB '
+            f'gather budget, so every step runs {calls} all-gathers over slices of {step} local images (same bytes over xGMI, rank-major per '
+            f'slice) and keeps only the last gathered slice')
 
 
 def one_step(vae, ar, empty_sample, empty_cond, distenv, top_k, top_p):
@@ -154,7 +178,9 @@ def cpu_baseline_reference(model, top_k, top_p, batch=32, positions=16, n_dec=8,
             'sample': f"the reference's own modules (oracle/_ref), fp32 on torch CPU kernels, {d['threads']} threads: RQTransformer.sample over the "
                       f"last {d['positions']} of {d['of_positions']} spatial positions of a batch of {d['batch']} (prefix prefilled by its first "
                       f"cached step; top-k {top_k} / top-p {top_p}) = {d['ar_s']:.1f} s, scaled x{d['of_positions'] / d['positions']:.0f} -> "
-                      f"{d['ar_s_per_image']:.2f} s/img; per-image RQVAE.decode_code + clamp of {d['decoded']} images = {d['decode_s_per_image']:.2f} s/img"}
+                      f"{d['ar_s_per_image']:.2f} s/img (an UPPER bound on s/img, i.e. biased against the CPU: the late positions carry the "
+                      f"longest prefix re-embedding, transformers.py:218-225); per-image RQVAE.decode_code + clamp of {d['decoded']} images = "
+                      f"{d['decode_s_per_image']:.2f} s/img"}
 
 
 def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):
@@ -606,6 +632,8 @@ def main(argv=None):
     vcfg = presets.RQVAE[presets.RQTRANSFORMER[args.model][1]]
     set_seed(0 + rank)                                   # main_sampling_fid.py:166-169
     B = args.batch if args.batch > 0 else DEFAULT_BATCH.get(args.model, 1024)
+    if args.batch <= 0 and world > 1 and args.model in DEFAULT_BATCH_MULTI:
+        B = DEFAULT_BATCH_MULTI[args.model]
     # safety net (normally a no-op): the default batch is sized for an empty 288-GB device (KV caches ~17 MB per image at the
     # 1.4B shape).  If this device has less free memory, shrink the batch to what fits -- in whole 256-row GEMM tiles, the same on
     # every rank -- instead of dying in hipMalloc; the line then reports the batch actually used (config.batch_per_gpu).
@@ -782,7 +810,7 @@ def main(argv=None):
                        'batch_per_gpu': B, 'global_batch': B * world, 'batch_note': batch_note, 'top_k': args.top_k, 'top_p': args.top_p,
                        'overlap_decode_with_next_sampling': bool(args.overlap), 'world_size': world, 'requested_gpus': args.gpus,
                        'per_rank_seconds': rank_times,
-                       'parallelism': f'replica x{world}, image batches sharded, one pixel all-gather (RCCL) per step' if world > 1 else 'single GPU',
+                       'parallelism': parallelism_note(world, B),
                        'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU; '
                                           'different batch / precision / hardware -- context, not a like-for-like ratio'},
             'ar_ms_per_image': t_ar / (args.steps * B) if not args.overlap else None,

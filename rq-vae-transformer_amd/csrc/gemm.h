@@ -1436,10 +1436,10 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
 // BM, so the 64- and 128-row forms agree bit for bit.
 #ifdef RQ_STREAM_TRACE
 // Diagnostics build only (scripts/stream_trace.py): constant-clock (100 MHz) stamps of every workgroup's phases
-static __device__ unsigned long long g_stream_trace[1024 * 2 * 8];
+static __device__ unsigned long long g_stream_trace[1024 * 2 * 24];
 #define RQ_ST(slot) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3) && blockIdx.y == 0) { \
         const int wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                                                          \
-        if (wg_ < 1024) g_stream_trace[(wg_ * 2 + ((threadIdx.x >> 6) == 3)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+        if (wg_ < 1024) g_stream_trace[(wg_ * 2 + ((threadIdx.x >> 6) == 3)) * 24 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define RQ_ST(slot) do { } while (0)
 #endif
@@ -1448,7 +1448,11 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
     RQ_ST(0);
     constexpr int BN = 32, BK = 64, NW = 4;
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, SLOT = A_BYTES + W_BYTES;
+#ifdef RQ_STREAM_NS
+    constexpr int NS = RQ_STREAM_NS;                   // (diagnostics: ring-depth sensitivity)
+#else
     constexpr int NS = BM == 64 ? 3 : 2;               // slots per wavefront
+#endif
     constexpr int A_G = BM / 8, W_G = BN / 8, PER = A_G + W_G;      // 1-KB (8-row) DMA groups per K-tile
     constexpr int MI = BM / 32;
     constexpr int RS = BN + 1;                         // row stride (floats) of a partial tile in LDS
@@ -1581,6 +1585,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         else rq_wait_vmcnt<0>();
         rq_wave_sync();                              // every lane's share of the tile has landed
         if (i == 0) RQ_ST(2);
+        if (i < 8) RQ_ST(8 + 2 * i);
         const char* sb = (const char*)smem + (wave * NS + slot) * SLOT;
         bf16x8 af[MI][4], bfr[4];
 #pragma unroll
@@ -1597,6 +1602,9 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi] = rq_mfma_32x32x16_bf16(af[mi][ks], bfr[ks], acc[mi]);
+#ifdef RQ_STREAM_TRACE
+        if (i < 8) { rq_opaque_acc(acc[0]); RQ_ST(9 + 2 * i); }
+#endif
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
 

@@ -109,7 +109,11 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
 // weight-streaming kernel for small batches (gemm.h): dense operands, 32 weight rows x BM activation rows per workgroup
 template <int BM>
 static int launch_stream(const GemmArgs& a, hipStream_t stream) {
+#ifdef RQ_STREAM_NS
+    constexpr size_t smem = (size_t)4 * RQ_STREAM_NS * ((BM + 32) * 64 * 2);
+#else
     constexpr size_t smem = (size_t)4 * (BM == 64 ? 3 : 2) * ((BM + 32) * 64 * 2);
+#endif
     static RqDeviceOnce attr_once;
     if (attr_once.first())
         (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -427,7 +431,7 @@ extern "C" int rqamd_dbg_conv_bf16(const void* x, const void* w, const float* bi
 // diagnostics build only (scripts/stream_trace.py)
 extern "C" int rqamd_dbg_stream_trace(unsigned long long* out_host, int clear) {
     if (clear) {
-        static unsigned long long zeros[1024 * 2 * 8];
+        static unsigned long long zeros[1024 * 2 * 24];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stream_trace), zeros, sizeof(zeros)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "stream_trace: clear failed");
         return RQAMD_OK;
     }

@@ -50,6 +50,52 @@ __global__ __launch_bounds__(256) void k_rows(const char* a, int a_bytes, const 
     for (int i = tid; i < out_words; i += 256) out[(long)blockIdx.x * out_words + i] = acc + i;
 }
 
+// the same traffic with EVERY load of the thread in flight before the first use (NA + NW 16-byte loads per thread, in registers):
+// what one memory round trip + the CU's intake rate allow
+template <int NA, int NWL>
+__global__ __launch_bounds__(256) void k_rows_deep(const char* a, const char* w, long w_stride, unsigned* out, int out_words) {
+    const int tid = threadIdx.x;
+    u32x4 ra[NA > 0 ? NA : 1], rw[NWL > 0 ? NWL : 1];
+    const char* src = w + (long)blockIdx.x * w_stride;
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) rw[i] = *(const u32x4*)(src + tid * 16 + i * 4096);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = *(const u32x4*)(a + tid * 16 + i * 4096);
+    __builtin_amdgcn_sched_barrier(0);               // (the compiler otherwise sinks the loads between their uses)
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) acc += rw[i].x ^ rw[i].y ^ rw[i].z ^ rw[i].w;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc += ra[i].x ^ ra[i].y ^ ra[i].z ^ ra[i].w;
+    for (int i = tid; i < out_words; i += 256) out[(long)blockIdx.x * out_words + i] = acc + i;
+}
+
+// the same again through LDS-DMA (global_load_lds_dwordx4, what gemm_stream_kernel stages its operands with): NA + NWL 1-KB
+// bursts per wavefront... per thread 16 bytes each, all issued before one s_waitcnt vmcnt(0); NA + NWL <= 36 (144 KB of LDS)
+template <int NA, int NWL>
+__global__ __launch_bounds__(256) void k_rows_dma(const char* a, const char* w, long w_stride, unsigned* out, int out_words) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem + (unsigned)wave * 1024u);
+    const char* src = w + (long)blockIdx.x * w_stride;
+    auto dma = [&](unsigned lds_base, const void* g) {
+        unsigned keep;
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_base);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(lb) : "memory");
+    };
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) dma(lds0 + i * 4096, src + tid * 16 + i * 4096);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma(lds0 + (NWL + i) * 4096, a + tid * 16 + i * 4096);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned acc = 0;
+    for (int i = 0; i < NA + NWL; ++i) acc += ((const unsigned*)smem)[i * 1024 + tid];
+    (void)lane;
+    for (int i = tid; i < out_words; i += 256) out[(long)blockIdx.x * out_words + i] = acc + i;
+}
+
 template <typename F> static double time_graph(F enqueue, int n_launch, int reps) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -89,9 +135,9 @@ int main() {
     const int A_BYTES = 64 * 1536 * 2, W_BYTES = 3 * 1536 * 1536 * 2 / 256, NW = 12, OUT_WORDS = 2048;
     char* w;
     unsigned *o0, *o1;
-    CK(hipMalloc(&w, (size_t)NW * 256 * W_BYTES));
+    CK(hipMalloc(&w, (size_t)NW * 256 * W_BYTES + (1 << 20)));
     CK(hipMemset(w, 1, (size_t)NW * 256 * W_BYTES));
-    CK(hipMalloc(&o0, 256 * OUT_WORDS * 4)); CK(hipMalloc(&o1, 256 * OUT_WORDS * 4));
+    CK(hipMalloc(&o0, 256 * OUT_WORDS * 4 + (1 << 20))); CK(hipMalloc(&o1, 256 * OUT_WORDS * 4 + (1 << 20)));
     CK(hipMemset(o0, 0, 256 * OUT_WORDS * 4)); CK(hipMemset(o1, 0, 256 * OUT_WORDS * 4));
     for (int wgs : {48, 144, 256}) {
         for (int mode : {1, 2, 3}) {
@@ -103,6 +149,37 @@ int main() {
             printf("  %-10s %3d wgs  %.2f   (%s)\n", mode == 1 ? "bcast_rows" : mode == 2 ? "stream_w" : "both", wgs, t,
                    mode == 1 ? "196 KB shared rows per workgroup" : mode == 2 ? "55 KB own weights per workgroup" : "196 KB shared + 55 KB own");
         }
+    }
+    // every load in flight at once: 48 x 4 KB = 196 KB shared rows, 12 x 4 KB = 49 KB (a quarter of the rows: what a 4-way K split
+    // or an activation-stationary workgroup reads), 14 x 4 KB = 56 KB own weights
+    auto deep = [&](const char* label, auto kern, int wgs) {
+        const double t = time_graph([&](hipStream_t s, int i) {
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, s, (const char*)((i & 1) ? o0 : o1), (const char*)(w + (size_t)(i % NW) * 256 * W_BYTES), (long)W_BYTES,
+                               (i & 1) ? o1 : o0, OUT_WORDS);
+        }, NL, REPS);
+        printf("  %-34s %3d wgs  %.2f\n", label, wgs, t);
+    };
+    for (int wgs : {144, 256}) {
+        deep("deep: 196 KB shared", k_rows_deep<48, 0>, wgs);
+        deep("deep: 56 KB own", k_rows_deep<0, 14>, wgs);
+        deep("deep: 196 KB shared + 56 KB own", k_rows_deep<48, 14>, wgs);
+        deep("deep: 49 KB shared + 56 KB own", k_rows_deep<12, 14>, wgs);
+        deep("deep: 49 KB shared + 16 KB own", k_rows_deep<12, 4>, wgs);
+    }
+    // plain loads vs LDS-DMA at equal traffic: 128 KB shared rows + 16 KB own weights per workgroup, everything in flight
+    auto dma = [&](const char* label, auto kern, int wgs, int smem) {
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        const double t = time_graph([&](hipStream_t s, int i) {
+            hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), smem, s, (const char*)((i & 1) ? o0 : o1), (const char*)(w + (size_t)(i % NW) * 256 * W_BYTES), (long)W_BYTES,
+                               (i & 1) ? o1 : o0, OUT_WORDS);
+        }, NL, REPS);
+        printf("  %-34s %3d wgs  %.2f\n", label, wgs, t);
+    };
+    for (int wgs : {144, 256}) {
+        deep("plain: 128 KB shared + 16 KB own", k_rows_deep<32, 4>, wgs);
+        dma("lds-dma: 128 KB shared + 16 KB own", k_rows_dma<32, 4>, wgs, 36 * 4096);
+        deep("plain: 16 KB own", k_rows_deep<0, 4>, wgs);
+        dma("lds-dma: 16 KB own", k_rows_dma<0, 4>, wgs, 4 * 4096);
     }
     return 0;
 }

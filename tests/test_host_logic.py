@@ -147,3 +147,19 @@ def test_bench_support_count_strict_and_relaxed():
     codes_k = np.array([99, 100, 101, 102], dtype=np.int64).reshape(4, 1, 1, 1)
     lg4 = np.tile(logits[:1], (4, 1, 1, 1, 1))
     assert bench.count_outside_support(lg4, codes_k, 100, None) == (3, 1)
+
+
+def test_bench_gather_plan_and_multi_gpu_defaults():
+    """bench.py: the pixel all-gather runs as ONE call while world x batch fits the gather budget and as
+    slices above it -- and config.parallelism says which; the two models BASELINE.json quotes at a global batch on 8 GPUs default
+    to its per-GPU share (64) when launched with more than one rank."""
+    import bench
+    per_img = 3 * 256 * 256 * 4
+    assert bench.gather_plan(8, 64, per_img) == (64, 1)
+    step, calls = bench.gather_plan(8, 10752, per_img)
+    assert calls > 1 and step * 8 * per_img <= bench.GATHER_BUDGET_BYTES < (step + 1) * 8 * per_img and step * calls >= 10752
+    assert bench.parallelism_note(1, 10752) == 'single GPU'
+    assert 'one pixel all-gather' in bench.parallelism_note(8, 64)
+    note = bench.parallelism_note(8, 10752)
+    assert f'{calls} all-gathers' in note and 'keeps only the last gathered slice' in note
+    assert bench.DEFAULT_BATCH_MULTI == {'xhuge': 64, 'txt3900m': 64} and 'huge' not in bench.DEFAULT_BATCH_MULTI
