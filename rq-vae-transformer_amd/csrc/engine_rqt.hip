@@ -34,6 +34,8 @@ struct FoldLin {
 
 struct RqtLayer {
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
+    bf16_t *pqkv, *pproj, *pfc1, *pfc2;      // fragment-packed copies for the K-split kernel (gemm_ks.h: decode steps of <= 512 rows)
+    bool packed_dirty = true;
     float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
     bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
     FoldLin f1;        // mlp.0 with ln2 folded in (the small-batch decode step)
@@ -85,6 +87,7 @@ struct rqamd_rqt {
     bf16_t *y, *qkv, *ya, *hbuf, *ain;
     bf16_t* xb;         // [rows][E] bf16 copy of the residual stream after the attention branch (A operand of the folded fc1)
     float* lnp;         // [E / 32][rows][2] LayerNorm partials written by the proj GEMM (GemmArgs::ln_part_out)
+    bool use_ks = true; // decode steps of <= 512 rows on the K-split kernel (RQAMD_NO_KS=1 at create: the round-3 kernels; A/B switch)
     bool fold = true;   // small-batch decode step: ln2 folded into the GEMMs around it (RQAMD_NO_LNFOLD=1 turns it off: A/B switch)
     int64_t *xs, *cond;
     int* st;            // [0] = spatial position
@@ -176,7 +179,8 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     const size_t E = h->E, V = h->V, Din = h->Din;
     const int vc = c->vocab_size_cond < 1 ? 1 : c->vocab_size_cond;
     const size_t per_layer = al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2) + al(3 * E * 4) + al(4 * E * 4) + 6 * al(E * 4)
-                             + al(4 * E * E * 2) + 3 * al(4 * E * 4);      // + mlp.0 with ln2 folded in (FoldLin)
+                             + al(4 * E * E * 2) + 3 * al(4 * E * 4)       // + mlp.0 with ln2 folded in (FoldLin)
+                             + al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2);      // + the fragment-packed copies
     size_t total = per_layer * (c->n_layer_body + c->n_layer_head) + 2 * al(E * Din * 2) + al(V * E * 2) + 4 * al(E * 4) + al(V * 4)
                    + al(vc * E * 4) + al(h->cond_len * E * 4) + 2 * al(h->HW * E * 4) + 2 * al(h->D * E * 4);
     if (h->cond_len > 1) total += al((size_t)vc * E * 2) + al((size_t)vc * 4) + 2 * al(E * 4);
@@ -215,6 +219,8 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
             L.bqkv = (float*)take(3 * E * 4); L.bfc1 = (float*)take(4 * E * 4);
             L.bproj = (float*)take(E * 4); L.bfc2 = (float*)take(E * 4);
             L.ln1w = (float*)take(E * 4); L.ln1b = (float*)take(E * 4); L.ln2w = (float*)take(E * 4); L.ln2b = (float*)take(E * 4);
+            L.pqkv = (bf16_t*)take(3 * E * E * 2); L.pproj = (bf16_t*)take(E * E * 2);
+            L.pfc1 = (bf16_t*)take(4 * E * E * 2); L.pfc2 = (bf16_t*)take(4 * E * E * 2);
             L.f1.wg = (bf16_t*)take(4 * E * E * 2);
             L.f1.c1 = (float*)take(4 * E * 4); L.f1.wb = (float*)take(4 * E * 4); L.f1.c2 = (float*)take(4 * E * 4);
             L.kc = L.vc = nullptr;
@@ -235,7 +241,10 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
         h->ccls_lnw = (float*)take(E * 4); h->ccls_lnb = (float*)take(E * 4);
     }
     // (the folded step runs on gemm_stream_kernel: N = 4 E must stay below the classifier-sized N that the picker sends elsewhere)
-    h->fold = getenv("RQAMD_NO_LNFOLD") == nullptr && getenv("RQAMD_NO_STREAM") == nullptr && getenv("RQAMD_NO_FUSE_RESID") == nullptr &&
+    h->use_ks = getenv("RQAMD_NO_KS") == nullptr;
+    // Measured (profiles/r04_lnfold_ab.txt, MI355X, 1.4B): 224.7 -> 235.9 ms per 64-image batch, i.e. SLOWER -- the un-split proj GEMM
+    // it needs (48 workgroups, 24 K-tiles each) costs more than the resid_ln launch it saves.  Kept behind RQAMD_LNFOLD=1.
+    h->fold = getenv("RQAMD_LNFOLD") != nullptr && getenv("RQAMD_NO_STREAM") == nullptr && getenv("RQAMD_NO_FUSE_RESID") == nullptr &&
               E % 64 == 0 && 4 * E < 16384;
     h->n_required = 4 + 4 + 4 + 12 * 2 * 0;   // filled below
     h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + (h->in_vq ? 2 : 0) + (h->head_vq ? 2 : 0) + (h->tok_rows ? 1 : 0) + 4 /*classifier*/
@@ -337,15 +346,16 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
             else if (leaf == "ln1.bias") rc = f32copy(L.ln1b, E);
             else if (leaf == "ln2.weight") { rc = f32copy(L.ln2w, E); L.ln2_ver++; L.ln2_seen |= 1; }
             else if (leaf == "ln2.bias") { rc = f32copy(L.ln2b, E); L.ln2_ver++; L.ln2_seen |= 2; }
-            else if (leaf == "attn.query.weight") rc = bf16copy(L.wqkv, E * E);
-            else if (leaf == "attn.key.weight") rc = bf16copy(L.wqkv + E * E, E * E);
-            else if (leaf == "attn.value.weight") rc = bf16copy(L.wqkv + 2 * E * E, E * E);
+            else if (leaf == "attn.query.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv, E * E);
+            else if (leaf == "attn.key.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv + E * E, E * E);
+            else if (leaf == "attn.value.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv + 2 * E * E, E * E);
             else if (leaf == "attn.query.bias") rc = f32copy(L.bqkv, E);
             else if (leaf == "attn.key.bias") rc = f32copy(L.bqkv + E, E);
             else if (leaf == "attn.value.bias") rc = f32copy(L.bqkv + 2 * E, E);
-            else if (leaf == "attn.proj.weight") rc = bf16copy(L.wproj, E * E);
+            else if (leaf == "attn.proj.weight") L.packed_dirty = true, rc = bf16copy(L.wproj, E * E);
             else if (leaf == "attn.proj.bias") rc = f32copy(L.bproj, E);
             else if (leaf == "mlp.0.weight") {
+                L.packed_dirty = true;
                 rc = bf16copy(L.wfc1, 4 * E * E);
                 // ln2 precedes mlp.0 in the state_dict: fold its gain into the fp32 parameter while it is at hand (one rounding);
                 // a LayerNorm that arrives later is folded into the bf16 copy by finalize_tables
@@ -356,7 +366,7 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
                 }
             }
             else if (leaf == "mlp.0.bias") { rc = f32copy(L.bfc1, 4 * E); L.f1.c2_dirty = true; }
-            else if (leaf == "mlp.2.weight") rc = bf16copy(L.wfc2, 4 * E * E);
+            else if (leaf == "mlp.2.weight") L.packed_dirty = true, rc = bf16copy(L.wfc2, 4 * E * E);
             else if (leaf == "mlp.2.bias") rc = f32copy(L.bfc2, E);
             else known = false;
         }
@@ -423,6 +433,16 @@ static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
     if (h->seen.size() - h->n_ccls_seen < h->n_required)
         return rq_fail(RQAMD_ERR_STATE, "rqt: only %zu of %zu parameters set", h->seen.size() - h->n_ccls_seen, h->n_required);
     if (!h->tables_dirty) return RQAMD_OK;
+    for (auto* stack : {&h->body, &h->head})
+        for (auto& L : *stack)
+            if (L.packed_dirty) {
+                const int E = h->E;
+                RQ_TRY(rq_pack_w(L.wqkv, L.pqkv, 3 * E, E, st));
+                RQ_TRY(rq_pack_w(L.wproj, L.pproj, E, E, st));
+                RQ_TRY(rq_pack_w(L.wfc1, L.pfc1, 4 * E, E, st));
+                RQ_TRY(rq_pack_w(L.wfc2, L.pfc2, E, 4 * E, st));
+                L.packed_dirty = false;
+            }
     if (h->fold) {
         for (auto* stack : {&h->body, &h->head})
             for (auto& L : *stack) {
@@ -458,17 +478,20 @@ static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
 struct LnIn { const float* c1; };
 static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, int epi,
                      const float* bias, const int* bias_step, int bias_stride, void* out, int ldo, int* n_slabs, hipStream_t st,
-                     float* resid = nullptr, const float* resid_bias = nullptr, bool ln_out = false, const LnIn* ln_in = nullptr) {
+                     float* resid = nullptr, const float* resid_bias = nullptr, bool ln_out = false, const LnIn* ln_in = nullptr,
+                     const bf16_t* Wp = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cfg.gelu_v2;
     a.bias = bias; a.bias_step = bias_step; a.bias_stride = bias_stride; a.out = out; a.ldo = ldo;
-    int bm, bn, sk, gl = 0;
-    rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL && !ln_out, &bm, &bn, &sk, &gl);
+    int bm, bn, sk, gl = 0, nwave = 0;
+    // decode steps of <= 512 rows: the K-split kernel on the fragment-packed copy of the weight (gemm_ks.h)
+    const bool ks = Wp && h->use_ks && !ln_out && !ln_in && rq_gemm_pick_ks(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &nwave, &sk);
+    if (!ks) rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL && !ln_out, &bm, &bn, &sk, &gl);
     if (sk > h->max_slabs) sk = h->max_slabs;
     if (ln_out) { a.xb = h->xb; a.ln_part_out = h->lnp; }
     if (ln_in) { a.ln_part_in = h->lnp; a.ln_c1 = ln_in->c1; a.ln_n_part = K / 32; a.ln_eps = 1e-5f; }
     static const bool no_fuse = getenv("RQAMD_NO_FUSE_RESID") != nullptr;      // A/B switch
-    if (resid && epi == EPI_F32_PARTIAL && sk == 1 && !no_fuse && (N & 3) == 0 && !(bm == 64 && bn == 32)) {
+    if (resid && epi == EPI_F32_PARTIAL && sk == 1 && !no_fuse && (N & 3) == 0 && (ks || !(bm == 64 && bn == 32))) {
         a.accum = 1; a.bias = resid_bias; a.out = resid; a.ldo = N;
         sk = 0;                                                              // reported slab count
     }
@@ -483,7 +506,8 @@ static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, in
         }
         RQ_HIP(hipEventRecord(pf.ev[pf.used], st));
     }
-    RQ_TRY(rq_gemm_launch(a, bm, bn, st));
+    if (ks) { a.W = Wp; RQ_TRY(rq_gemm_launch_ks(a, bm, bn, nwave, st)); }
+    else RQ_TRY(rq_gemm_launch(a, bm, bn, st));
     if (pf.on) {
         RQ_HIP(hipEventRecord(pf.ev[pf.used + 1], st));
         pf.used += 2;
@@ -507,7 +531,8 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     r.x_out = (x_in != x || pend.slabs || pend.bias || addvec) ? x : nullptr;      // nothing to add in place: the stream is not rewritten
     r.gamma = L.ln1w; r.beta = L.ln1b; r.y = h->y; r.rows = rows; r.E = E; r.eps = 1e-5f;
     RQ_TRY(rq_launch_resid_ln(r, st));
-    RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
+    RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st, nullptr, nullptr, false, nullptr,
+                     L.pqkv));
     if (pf) {
         AttnPrefillArgs ap{};
         const long img_stride = (long)h->cfg.n_head * Tcap * 64;
@@ -542,13 +567,14 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
         else pend = Pending{nullptr, 0, nullptr};
         return RQAMD_OK;
     }
-    RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj));
+    RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj, false, nullptr, L.pproj));
     ResidLnArgs r2{};
     r2.x_in = x; r2.x_out = ns ? x : nullptr; r2.slabs = ns ? h->slabs : nullptr; r2.n_slabs = ns; r2.bias = ns ? L.bproj : nullptr;
     r2.gamma = L.ln2w; r2.beta = L.ln2b; r2.y = h->y; r2.rows = rows; r2.E = E; r2.eps = 1e-5f;
     RQ_TRY(rq_launch_resid_ln(r2, st));
-    RQ_TRY(step_gemm(h, h->y, E, L.wfc1, rows, 4 * E, E, EPI_BF16_GELU, L.bfc1, nullptr, 0, h->hbuf, 4 * E, nullptr, st));
-    RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bfc2));
+    RQ_TRY(step_gemm(h, h->y, E, L.wfc1, rows, 4 * E, E, EPI_BF16_GELU, L.bfc1, nullptr, 0, h->hbuf, 4 * E, nullptr, st, nullptr, nullptr, false, nullptr,
+                     L.pfc1));
+    RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bfc2, false, nullptr, L.pfc2));
     if (ns) { pend.slabs = h->slabs; pend.n = ns; pend.bias = L.bfc2; }
     else pend = Pending{nullptr, 0, nullptr};      // the stream already holds this block's output
     return RQAMD_OK;

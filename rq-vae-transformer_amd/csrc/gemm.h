@@ -1416,6 +1416,17 @@ int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds);
 
 
+// ---- K-split kernel for 1 .. 512 rows (gemm_ks.h; kernels instantiated in gemm.hip)
+#define RQ_WP_BLOCK_BYTES 4096
+// Packs W[N][K] (row-major bf16) into the fragment layout of gemm_ks.h; Wp must hold rq_packed_w_elems(N, K) bf16.
+static inline long rq_packed_w_elems(int N, int K) { return (long)((N + 31) / 32) * (K / 64) * (RQ_WP_BLOCK_BYTES / 2); }
+int rq_pack_w(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t stream);
+// Tile choice of the K-split kernel for a decode-step GEMM of M rows: false when another kernel should run (M > 512, the
+// classifier's N, ...).  bm = 64 / 128, bn = 32 / 64 / 96, nwave = 8 / 4; splitk > 1 only with allow_splitk.
+bool rq_gemm_pick_ks(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* nwave, int* splitk);
+// a.W = the packed copy
+int rq_gemm_launch_ks(const GemmArgs& a, int bm, int bn, int nwave, hipStream_t stream);
+
 // -------------------------------------------------------------------------------------------------
 // Weight-streaming GEMM for the small-batch decode steps (M <= 128 rows per m-tile: the per-GPU batches of 64 / 100 that
 // SURVEY 8d names).  At these sizes a GEMM is one pass over W with almost no arithmetic, and what decides its time is how

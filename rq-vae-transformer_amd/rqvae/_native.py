@@ -78,6 +78,8 @@ _SIGS = {
     'rqamd_rqt_get_profile_attn': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'rqamd_dbg_pack_w': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_dbg_pick_ks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     'rqamd_dbg_gemm_ln': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -304,6 +306,37 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
     check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
                                     ptr(out), bm, bn, splitk, stream_of(a_bf16)))
     return out
+
+
+def dbg_pack_w(w_bf16):
+    """diagnostics: w (N,K) bf16 -> the fragment-packed copy the K-split decode GEMM reads (csrc/gemm_ks.h)."""
+    N, K = w_bf16.shape
+    wp = torch.empty((((N + 31) // 32) * (K // 64) * 2048,), dtype=torch.bfloat16, device=w_bf16.device)
+    check(lib().rqamd_dbg_pack_w(ptr(w_bf16, torch.bfloat16), N, K, ptr(wp), stream_of(w_bf16)))
+    return wp
+
+
+def dbg_gemm_ks(a_bf16, wp_bf16, N, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
+    """diagnostics: dbg_gemm through the K-split kernel; wp = dbg_pack_w(w), N = w.shape[0]."""
+    M, K = a_bf16.shape
+    if out is None:
+        kind = epi % 16
+        if kind == 4:
+            out = torch.empty((splitk if splitk > 0 else 8, M, N), dtype=torch.float32, device=a_bf16.device)
+        else:
+            out = torch.empty((M, N), dtype=torch.float32 if kind == 3 else torch.bfloat16, device=a_bf16.device)
+    check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(wp_bf16, torch.bfloat16), M, N, K, ptr(bias), epi + 4096,
+                                    ptr(out), bm, bn, splitk, stream_of(a_bf16)))
+    return out
+
+
+def dbg_pick_ks(M, N, K, allow_splitk=False):
+    """diagnostics: (bm, bn, wavefronts, splitk) of the K-split kernel for this shape, or None when another kernel runs."""
+    out = (C.c_int * 4)()
+    r = lib().rqamd_dbg_pick_ks(int(M), int(N), int(K), int(bool(allow_splitk)), out)
+    if r < 0:
+        check(r)
+    return tuple(out) if r == 1 else None
 
 
 def dbg_gemm_ln_producer(a_bf16, w_bf16, bias, x, bm=66):

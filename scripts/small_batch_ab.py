@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Small-batch sampling A/B (round 4): RQTransformer.sample of the 1.4B model (or RQ_MODEL) at the per-GPU batches SURVEY 8d names,
-with and without the LayerNorm fold of the <= 128-row decode step (RQAMD_NO_LNFOLD=1 is read when an engine is created, so both
-engines live in one process and are timed interleaved).  Prints AR ms per batch and images/s (AR only)."""
+"""Small-batch sampling A/B (round 4): RQTransformer.sample of the 1.4B model (or RQ_MODEL) at the per-GPU batches SURVEY 8d names, on
+engine variants that live in one process and are timed interleaved (the switches are read when an engine is created):
+  base  the round-3 kernels (RQAMD_NO_KS=1)      ks  the K-split decode GEMM (default)      fold  base + LayerNorm fold (RQAMD_LNFOLD=1)
+RQ_VARIANTS=base,ks  RQ_BS=64,100,200,500  RQ_MODEL=huge.  Prints AR ms per batch and images/s (AR only).  The codes of two variants
+differ wherever rounding differs (other summation orders): the parity of each is what the GPU tests check."""
 import os
 import sys
 import time
@@ -17,19 +19,20 @@ torch.set_grad_enabled(False)
 dev = torch.device('cuda', 0)
 model = os.environ.get('RQ_MODEL', 'huge')
 batches = [int(b) for b in os.environ.get('RQ_BS', '64,100,128').split(',')]
-variants = os.environ.get('RQ_VARIANTS', 'base,fold').split(',')
+variants = os.environ.get('RQ_VARIANTS', 'base,ks').split(',')
 engines = {}
 vae = None
+ENV = {'base': {'RQAMD_NO_KS': '1'}, 'ks': {}, 'fold': {'RQAMD_NO_KS': '1', 'RQAMD_LNFOLD': '1'}}
 for v in variants:
-    if v == 'base':
-        os.environ['RQAMD_NO_LNFOLD'] = '1'
-    else:
-        os.environ.pop('RQAMD_NO_LNFOLD', None)
+    for k in ('RQAMD_NO_KS', 'RQAMD_LNFOLD'):
+        os.environ.pop(k, None)
+    os.environ.update(ENV[v])
     vae, ar, cfg = presets.build(model, device=dev, seed=0)
     part = torch.zeros((2,) + tuple(ar.block_size), device=dev, dtype=torch.long)
     ar.sample(part, model_aux=vae, cond=torch.zeros((2, ar.block_size_cond), device=dev, dtype=torch.long), top_k=1024, top_p=0.95)
     engines[v] = ar
-os.environ.pop('RQAMD_NO_LNFOLD', None)
+for k in ('RQAMD_NO_KS', 'RQAMD_LNFOLD'):
+    os.environ.pop(k, None)
 for B in batches:
     part = torch.zeros((B,) + tuple(engines[variants[0]].block_size), device=dev, dtype=torch.long)
     cond = torch.zeros((B, engines[variants[0]].block_size_cond), device=dev, dtype=torch.long)

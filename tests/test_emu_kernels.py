@@ -640,7 +640,7 @@ def test_emu_gemm_256x256_eight_phase(nat):
             a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
 
 
-@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream'])
+@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream', 'ksplit'])
 def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
     """The LDS-DMA GEMMs again with RQ_EMU_DMA=late: a DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it --
     the latest moment the hardware allows -- so a fragment read that is not ordered behind the covering wait (+ a barrier for other
@@ -651,6 +651,8 @@ def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
         test_emu_gemm_tiles_and_lds_dma(nat)
     elif which == 'eight_phase':
         test_emu_gemm_256x256_eight_phase(nat)
+    elif which == 'ksplit':
+        test_emu_gemm_ksplit(nat)          # (its W loads are plain global loads between the DMAs: they take their place in the count)
     else:
         test_emu_gemm_stream(nat)
 
@@ -709,6 +711,72 @@ def test_emu_gemm_stream(nat):
     ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
     out = nat.dbg_gemm(a, w, bias, epi=1, bm=66, bn=32, splitk=1).float().numpy()
     assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
+
+
+def _pack_w_numpy(w):
+    """Wp[ceil(N / 32)][K / 64][4][64][8] of csrc/gemm_ks.h: lane l of k-step ks holds W[32 nb + (l & 31)][64 kt + 16 ks + 8 (l >> 5) + 0..7]"""
+    N, K = w.shape
+    nbt, kt = (N + 31) // 32, K // 64
+    wz = np.zeros((nbt * 32, K), w.dtype)
+    wz[:N] = w
+    v = wz.reshape(nbt, 32, kt, 4, 2, 8)                   # nb, row, kt, ks, half, e
+    return np.ascontiguousarray(v.transpose(0, 2, 3, 4, 1, 5)).reshape(-1)   # nb, kt, ks, half, row, e -> lane = row + 32 half
+
+
+def _check_gemm_ks(nat, rng, M, N, K, bm, bn):
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+    wp = nat.dbg_pack_w(w)
+    assert np.array_equal(wp.view(torch.int16).numpy(), _pack_w_numpy(w.view(torch.int16).numpy())), (N, K)
+    bias = T(rng.standard_normal(N).astype(np.float32))
+    ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+    scale = np.abs(ref).max()
+    out = nat.dbg_gemm_ks(a, wp, N, bias, epi=3, bm=bm, bn=bn, splitk=1).numpy()
+    assert np.abs(out - ref).max() < 2e-3 * scale, (M, N, K, bm, bn)
+    out16 = nat.dbg_gemm_ks(a, wp, N, bias, epi=0, bm=bm, bn=bn, splitk=1).float().numpy()
+    assert np.abs(out16 - ref).max() < 1e-2 * scale, (M, N, K, bm, bn)
+    if (K // 64) % 2 == 0:
+        slabs = nat.dbg_gemm_ks(a, wp, N, None, epi=4, bm=bm, bn=bn, splitk=2).numpy()
+        assert np.abs(slabs.sum(0) - (ref - bias.numpy())).max() < 2e-3 * scale, (M, N, K, bm, bn)
+    x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
+    xs = x0.clone()
+    nat.dbg_gemm_ks(a, wp, N, bias, epi=4 + 2048, bm=bm, bn=bn, splitk=1, out=xs)
+    slab = nat.dbg_gemm_ks(a, wp, N, None, epi=4, bm=bm, bn=bn, splitk=1)[0]
+    assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm, bn)           # the additions of slab + resid_ln, in their order
+    return out
+
+
+def test_emu_gemm_ksplit(nat):
+    """K-split decode GEMM (csrc/gemm_ks.h: wavefronts take every NWAVE-th K-tile, A through private two-slot LDS-DMA rings, W through
+    registers from the fragment-packed copy, pairwise tree reduction through LDS): the packed layout against its definition; every
+    tile (64 x 32 with eight wavefronts, 128 x 32 / 64 / 96 with four) on ragged M / N, several m-tiles, K-tile counts that leave
+    wavefronts with one, several or no tiles; fp32 / bf16 / GELU / split-K slab / in-place residual epilogues vs numpy; a row's
+    result does not depend on the rows around it."""
+    rng = np.random.default_rng(31)
+    for (M, N, K) in ((64, 96, 512), (37, 70, 1536), (1, 64, 128), (64, 160, 1024)):
+        _check_gemm_ks(nat, rng, M, N, K, 64, 32)
+    for bn in (32, 64, 96):
+        for (M, N, K) in ((128, 192, 384), (100, 200, 640), (300, 96, 256)):
+            _check_gemm_ks(nat, rng, M, N, K, 128, bn)
+    # GELU epilogue vs torch; batch independence of a row (same tile: rows 0..4 alone == inside 50 rows)
+    a = torch.from_numpy(rng.standard_normal((50, 256)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
+    wp = nat.dbg_pack_w(w)
+    bias = T(rng.standard_normal(64).astype(np.float32))
+    ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
+    for bm, bn in ((64, 32), (128, 64)):
+        out = nat.dbg_gemm_ks(a, wp, 64, bias, epi=1, bm=bm, bn=bn, splitk=1).float().numpy()
+        assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
+        few = nat.dbg_gemm_ks(a[:5].contiguous(), wp, 64, bias, epi=1, bm=bm, bn=bn, splitk=1).float().numpy()
+        assert np.array_equal(few, out[:5])
+    # the picker: <= 64 rows -> 64 x 32 / eight wavefronts; 65 .. 512 rows -> 128-row tiles in one round of 256 workgroups
+    assert nat.dbg_pick_ks(64, 4608, 1536)[:3] == (64, 32, 8)
+    assert nat.dbg_pick_ks(64, 1536, 6144, True) == (64, 32, 8, 4)
+    for M in (100, 200, 500):
+        for N, K, sk in ((4608, 1536, False), (1536, 1536, True), (6144, 1536, False), (1536, 6144, True)):
+            bm, bn, nw, s = nat.dbg_pick_ks(M, N, K, sk)
+            assert (bm, nw) == (128, 4) and ((M + 127) // 128) * ((N + bn - 1) // bn) * s <= 256, (M, N, K, bn, s)
+    assert nat.dbg_pick_ks(1000, 4608, 1536) is None and nat.dbg_pick_ks(64, 16384, 1536) is None
 
 
 def test_emu_gemm_folded_layernorm(nat):
