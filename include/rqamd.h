@@ -210,20 +210,6 @@ int rqamd_rqt_get_profile_attn(rqamd_rqt* h, double* attn_ms_total, int64_t* att
  * Used by the kernel-level parity test and scripts/gemm_bench.py; not part of the reference-facing surface. */
 int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                         void* out, int bm, int bn, int splitk, void* stream);
-/* The decode-step GEMM for 1 .. 512 rows (csrc/gemm_ks.h) reads its weights from a fragment-packed copy: rqamd_dbg_pack_w makes it
- * (Wp: ceil(N / 32) * (K / 64) * 2048 bf16), rqamd_dbg_gemm_bf16 with epi + 4096 runs the kernel on it (bm 64 / bn 32, or bm 128 /
- * bn 32, 64, 96; bm <= 0: the engine's choice), rqamd_dbg_pick_ks reports that choice: out[4] = {bm, bn, wavefronts, splitk},
- * return value 1 when the kernel applies to (M, N, K), 0 when another kernel runs. */
-int rqamd_dbg_pack_w(const void* W, int N, int K, void* Wp, void* stream);
-int rqamd_dbg_pick_ks(int M, int N, int K, int allow_splitk, int* out);
-/* The two halves of a LayerNorm folded into the GEMMs on either side of it -- how the decode step at <= 128 rows runs
- * ln2 + mlp.0 of AttentionBlock.forward (attentions.py:135) without a launch for the LayerNorm (csrc/gemm.h, GemmArgs::xb /
- * ln_part_in).  mode 0, producer: x[M][N] fp32 is updated in place, x = (x + A.W^T) + bias; xb[M][N] receives bf16(x) and
- * part[N / 32][M][2] the (sum, sum of squared deviations) of every 32-column group of every row.  mode 1, consumer:
- * out[M][N] bf16 = epi(rstd_m (A.W^T - mean_m c1[n]) + bias[n]) with A the raw rows, W the gain-folded weight, c1[n] = sum_k W[n][k],
- * mean_m / rstd_m merged from part[K / 32][M][2] (eps 1e-5); epi 0 (none) or 1 (GELU).  bm: 66 (64-row form) or 130 (128 rows). */
-int rqamd_dbg_gemm_ln(const void* A, const void* W, int M, int N, int K, const float* bias, int mode, int epi, float* x,
-                      void* xb, float* part, const float* c1, void* out, int bm, void* stream);
 /* One raw implicit-GEMM convolution launch (the conv form of the same kernel): x NHWC bf16
  * [B][H>>ups][W>>ups][Cin] (H, W = virtual input size after the folded nearest-2x upsample), w bf16
  * [Cout][k][k][Cin], out NHWC bf16 (+bias, +resid if not NULL); stride 2 = Downsample (layers.py:50-54). */

@@ -22,24 +22,10 @@
 #include "rq_common.h"
 #include "rqt_kernels.h"
 
-// A Linear with the LayerNorm in front of it folded in (GemmArgs::ln_part_in, gemm.h): the weight carries the LayerNorm gain,
-// wg[n][k] = bf16(W[n][k] * gamma[k]) (one rounding, from the fp32 parameter, when the gain is known at the time the weight arrives --
-// the state_dict order; refolded from the bf16 copy otherwise), c1[n] = sum_k wg[n][k], wb[n] = sum_k W[n][k] beta[k], c2 = wb + bias.
-struct FoldLin {
-    bf16_t* wg = nullptr;
-    float *c1 = nullptr, *wb = nullptr, *c2 = nullptr;
-    int ln_ver_used = -1;    // version of the LayerNorm parameters the fold was made with
-    bool c2_dirty = true;
-};
-
 struct RqtLayer {
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
-    bf16_t *pqkv, *pproj, *pfc1, *pfc2;      // fragment-packed copies for the K-split kernel (gemm_ks.h: decode steps of <= 512 rows)
-    bool packed_dirty = true;
     float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
     bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
-    FoldLin f1;        // mlp.0 with ln2 folded in (the small-batch decode step)
-    int ln2_ver = 0, ln2_seen = 0;
 };
 
 struct GemmProfile {
@@ -85,10 +71,6 @@ struct rqamd_rqt {
     DevBuf ws, kv;
     float *x, *xh, *slabs, *logits;
     bf16_t *y, *qkv, *ya, *hbuf, *ain;
-    bf16_t* xb;         // [rows][E] bf16 copy of the residual stream after the attention branch (A operand of the folded fc1)
-    float* lnp;         // [E / 32][rows][2] LayerNorm partials written by the proj GEMM (GemmArgs::ln_part_out)
-    bool use_ks = true; // decode steps of <= 512 rows on the K-split kernel (RQAMD_NO_KS=1 at create: the round-3 kernels; A/B switch)
-    bool fold = true;   // small-batch decode step: ln2 folded into the GEMMs around it (RQAMD_NO_LNFOLD=1 turns it off: A/B switch)
     int64_t *xs, *cond;
     int* st;            // [0] = spatial position
     uint64_t* rng;      // {seed, offset}
@@ -124,41 +106,6 @@ __global__ void set_rng_kernel(uint64_t* rng, uint64_t seed, uint64_t offset) {
     if (threadIdx.x == 0) { rng[0] = seed; rng[1] = offset; }
 }
 
-// One workgroup per weight row n: wg[n][:] = bf16(W[n][:] * gamma), c1[n] = sum_k wg[n][k] (of the ROUNDED values: a constant row
-// then cancels exactly in acc - mean * c1), wb[n] = sum_k W[n][k] beta[k].  SRC_F32: W is the fp32 parameter, else its bf16 copy.
-template <bool SRC_F32>
-__global__ __launch_bounds__(256) void fold_ln_kernel(const void* W, const float* gamma, const float* beta, bf16_t* wg, float* c1,
-                                                      float* wb, int K) {
-    __shared__ float red[8];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = tid; k < K; k += 256) {
-        const float w = SRC_F32 ? ((const float*)W)[(long)n * K + k] : bf16_to_f32(((const bf16_t*)W)[(long)n * K + k]);
-        const bf16_t g = f32_to_bf16(w * gamma[k]);
-        wg[(long)n * K + k] = g;
-        s1 += bf16_to_f32(g);
-        s2 = fmaf(w, beta[k], s2);
-    }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
-    rq_syncthreads();
-    if (tid == 0) {
-        c1[n] = (red[0] + red[1]) + (red[2] + red[3]);
-        wb[n] = (red[4] + red[5]) + (red[6] + red[7]);
-    }
-}
-__global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
-}
-static int fold_ln(const void* W, bool src_f32, const float* gamma, const float* beta, FoldLin& f, int N, int K, hipStream_t st) {
-    if (src_f32) RQ_LAUNCH(fold_ln_kernel<true>, dim3(N), dim3(256), 0, st, W, gamma, beta, f.wg, f.c1, f.wb, K);
-    else RQ_LAUNCH(fold_ln_kernel<false>, dim3(N), dim3(256), 0, st, W, gamma, beta, f.wg, f.c1, f.wb, K);
-    f.c2_dirty = true;
-    return rq_check_launch("fold_ln_kernel");
-}
-
 static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 
 extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
@@ -178,9 +125,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     if (h->Tbody > 256) { delete h; return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: context %d > 256", h->Tbody); }
     const size_t E = h->E, V = h->V, Din = h->Din;
     const int vc = c->vocab_size_cond < 1 ? 1 : c->vocab_size_cond;
-    const size_t per_layer = al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2) + al(3 * E * 4) + al(4 * E * 4) + 6 * al(E * 4)
-                             + al(4 * E * E * 2) + 3 * al(4 * E * 4)       // + mlp.0 with ln2 folded in (FoldLin)
-                             + al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2);      // + the fragment-packed copies
+    const size_t per_layer = al(3 * E * E * 2) + al(E * E * 2) + 2 * al(4 * E * E * 2) + al(3 * E * 4) + al(4 * E * 4) + 6 * al(E * 4);
     size_t total = per_layer * (c->n_layer_body + c->n_layer_head) + 2 * al(E * Din * 2) + al(V * E * 2) + 4 * al(E * 4) + al(V * 4)
                    + al(vc * E * 4) + al(h->cond_len * E * 4) + 2 * al(h->HW * E * 4) + 2 * al(h->D * E * 4);
     if (h->cond_len > 1) total += al((size_t)vc * E * 2) + al((size_t)vc * 4) + 2 * al(E * 4);
@@ -219,10 +164,6 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
             L.bqkv = (float*)take(3 * E * 4); L.bfc1 = (float*)take(4 * E * 4);
             L.bproj = (float*)take(E * 4); L.bfc2 = (float*)take(E * 4);
             L.ln1w = (float*)take(E * 4); L.ln1b = (float*)take(E * 4); L.ln2w = (float*)take(E * 4); L.ln2b = (float*)take(E * 4);
-            L.pqkv = (bf16_t*)take(3 * E * E * 2); L.pproj = (bf16_t*)take(E * E * 2);
-            L.pfc1 = (bf16_t*)take(4 * E * E * 2); L.pfc2 = (bf16_t*)take(4 * E * E * 2);
-            L.f1.wg = (bf16_t*)take(4 * E * E * 2);
-            L.f1.c1 = (float*)take(4 * E * 4); L.f1.wb = (float*)take(4 * E * 4); L.f1.c2 = (float*)take(4 * E * 4);
             L.kc = L.vc = nullptr;
         }
     };
@@ -240,12 +181,6 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
         h->w_ccls = (bf16_t*)take((size_t)vc * E * 2); h->b_ccls = (float*)take((size_t)vc * 4);
         h->ccls_lnw = (float*)take(E * 4); h->ccls_lnb = (float*)take(E * 4);
     }
-    // (the folded step runs on gemm_stream_kernel: N = 4 E must stay below the classifier-sized N that the picker sends elsewhere)
-    h->use_ks = getenv("RQAMD_NO_KS") == nullptr;
-    // Measured (profiles/r04_lnfold_ab.txt, MI355X, 1.4B): 224.7 -> 235.9 ms per 64-image batch, i.e. SLOWER -- the un-split proj GEMM
-    // it needs (48 workgroups, 24 K-tiles each) costs more than the resid_ln launch it saves.  Kept behind RQAMD_LNFOLD=1.
-    h->fold = getenv("RQAMD_LNFOLD") != nullptr && getenv("RQAMD_NO_STREAM") == nullptr && getenv("RQAMD_NO_FUSE_RESID") == nullptr &&
-              E % 64 == 0 && 4 * E < 16384;
     h->n_required = 4 + 4 + 4 + 12 * 2 * 0;   // filled below
     h->n_required = 3 /*pos*/ + 1 /*cond_emb*/ + (h->in_vq ? 2 : 0) + (h->head_vq ? 2 : 0) + (h->tok_rows ? 1 : 0) + 4 /*classifier*/
                     + (size_t)16 * (c->n_layer_body + c->n_layer_head);
@@ -344,29 +279,19 @@ extern "C" int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* 
             std::string leaf = s.substr(dot + 1);
             if (leaf == "ln1.weight") rc = f32copy(L.ln1w, E);
             else if (leaf == "ln1.bias") rc = f32copy(L.ln1b, E);
-            else if (leaf == "ln2.weight") { rc = f32copy(L.ln2w, E); L.ln2_ver++; L.ln2_seen |= 1; }
-            else if (leaf == "ln2.bias") { rc = f32copy(L.ln2b, E); L.ln2_ver++; L.ln2_seen |= 2; }
-            else if (leaf == "attn.query.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv, E * E);
-            else if (leaf == "attn.key.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv + E * E, E * E);
-            else if (leaf == "attn.value.weight") L.packed_dirty = true, rc = bf16copy(L.wqkv + 2 * E * E, E * E);
+            else if (leaf == "ln2.weight") rc = f32copy(L.ln2w, E);
+            else if (leaf == "ln2.bias") rc = f32copy(L.ln2b, E);
+            else if (leaf == "attn.query.weight") rc = bf16copy(L.wqkv, E * E);
+            else if (leaf == "attn.key.weight") rc = bf16copy(L.wqkv + E * E, E * E);
+            else if (leaf == "attn.value.weight") rc = bf16copy(L.wqkv + 2 * E * E, E * E);
             else if (leaf == "attn.query.bias") rc = f32copy(L.bqkv, E);
             else if (leaf == "attn.key.bias") rc = f32copy(L.bqkv + E, E);
             else if (leaf == "attn.value.bias") rc = f32copy(L.bqkv + 2 * E, E);
-            else if (leaf == "attn.proj.weight") L.packed_dirty = true, rc = bf16copy(L.wproj, E * E);
+            else if (leaf == "attn.proj.weight") rc = bf16copy(L.wproj, E * E);
             else if (leaf == "attn.proj.bias") rc = f32copy(L.bproj, E);
-            else if (leaf == "mlp.0.weight") {
-                L.packed_dirty = true;
-                rc = bf16copy(L.wfc1, 4 * E * E);
-                // ln2 precedes mlp.0 in the state_dict: fold its gain into the fp32 parameter while it is at hand (one rounding);
-                // a LayerNorm that arrives later is folded into the bf16 copy by finalize_tables
-                L.f1.ln_ver_used = -1;
-                if (rc == RQAMD_OK && h->fold && L.ln2_seen == 3) {
-                    rc = fold_ln(src, true, L.ln2w, L.ln2b, L.f1, (int)(4 * E), (int)E, st);
-                    L.f1.ln_ver_used = L.ln2_ver;
-                }
-            }
-            else if (leaf == "mlp.0.bias") { rc = f32copy(L.bfc1, 4 * E); L.f1.c2_dirty = true; }
-            else if (leaf == "mlp.2.weight") L.packed_dirty = true, rc = bf16copy(L.wfc2, 4 * E * E);
+            else if (leaf == "mlp.0.weight") rc = bf16copy(L.wfc1, 4 * E * E);
+            else if (leaf == "mlp.0.bias") rc = f32copy(L.bfc1, 4 * E);
+            else if (leaf == "mlp.2.weight") rc = bf16copy(L.wfc2, 4 * E * E);
             else if (leaf == "mlp.2.bias") rc = f32copy(L.bfc2, E);
             else known = false;
         }
@@ -405,8 +330,7 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     const size_t prow = (size_t)prefill_chunk(h, B) * (h->cond_len - 1);
     const size_t rows = brows > prow ? brows : prow;              // activation rows (decode step or prefill chunk)
     size_t total = 2 * al(rows * E * 4) + al((size_t)h->max_slabs * rows * E * 4) + al(brows * V * 4) + 2 * al(rows * E * 2) + al(rows * 3 * E * 2)
-                   + al(rows * 4 * E * 2) + al(brows * h->Din * 2) + al(brows * h->HW * h->D * 8) + al(brows * h->cond_len * 8) + al(64) + al(64) + al(brows * 4)
-                   + al(rows * E * 2) + al((E / 32 + 1) * rows * 8);
+                   + al(rows * 4 * E * 2) + al(brows * h->Din * 2) + al(brows * h->HW * h->D * 8) + al(brows * h->cond_len * 8) + al(64) + al(64) + al(brows * 4);
     RQ_TRY(h->ws.reserve(total));
     char* p = (char*)h->ws.p;
     auto take = [&](size_t bytes) { char* r = p; p += al(bytes); return (void*)r; };
@@ -416,7 +340,6 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     h->y = (bf16_t*)take(rows * E * 2); h->ya = (bf16_t*)take(rows * E * 2);
     h->qkv = (bf16_t*)take(rows * 3 * E * 2); h->hbuf = (bf16_t*)take(rows * 4 * E * 2);
     h->ain = (bf16_t*)take(brows * h->Din * 2);
-    h->xb = (bf16_t*)take(rows * E * 2); h->lnp = (float*)take((E / 32 + 1) * rows * 8);
     h->xs = (int64_t*)take(brows * h->HW * h->D * 8); h->cond = (int64_t*)take(brows * h->cond_len * 8);
     h->st = (int*)take(64); h->rng = (uint64_t*)take(64); h->smp_redo = (int*)take(brows * 4);
     // KV caches: body [rows][nh][Tbody][64] x2 per layer, head Tcap = D
@@ -433,30 +356,6 @@ static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
     if (h->seen.size() - h->n_ccls_seen < h->n_required)
         return rq_fail(RQAMD_ERR_STATE, "rqt: only %zu of %zu parameters set", h->seen.size() - h->n_ccls_seen, h->n_required);
     if (!h->tables_dirty) return RQAMD_OK;
-    for (auto* stack : {&h->body, &h->head})
-        for (auto& L : *stack)
-            if (L.packed_dirty) {
-                const int E = h->E;
-                RQ_TRY(rq_pack_w(L.wqkv, L.pqkv, 3 * E, E, st));
-                RQ_TRY(rq_pack_w(L.wproj, L.pproj, E, E, st));
-                RQ_TRY(rq_pack_w(L.wfc1, L.pfc1, 4 * E, E, st));
-                RQ_TRY(rq_pack_w(L.wfc2, L.pfc2, E, 4 * E, st));
-                L.packed_dirty = false;
-            }
-    if (h->fold) {
-        for (auto* stack : {&h->body, &h->head})
-            for (auto& L : *stack) {
-                if (L.f1.ln_ver_used != L.ln2_ver) {      // ln2 changed after mlp.0.weight arrived: refold from the bf16 copy
-                    RQ_TRY(fold_ln(L.wfc1, false, L.ln2w, L.ln2b, L.f1, 4 * h->E, h->E, st));
-                    L.f1.ln_ver_used = L.ln2_ver;
-                }
-                if (L.f1.c2_dirty) {
-                    RQ_LAUNCH(vec_add_kernel, dim3((unsigned)((4 * h->E + 255) / 256)), dim3(256), 0, st, L.f1.wb, L.bfc1, L.f1.c2, 4 * h->E);
-                    L.f1.c2_dirty = false;
-                }
-            }
-        RQ_TRY(rq_check_launch("vec_add_kernel"));
-    }
     long n = (long)h->HW * h->E;
     RQ_LAUNCH(bias_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, h->b_in, (float)h->D, h->pos_hw, h->body_in_bias, h->HW, h->E);
     n = (long)h->D * h->E;
@@ -473,25 +372,17 @@ static int finalize_tables(rqamd_rqt* h, hipStream_t st) {
 // the LayerNorm that follows reads the stream only (one fp32 read + the bf16 write instead of stream + slab in, stream + bf16
 // out: 41 -> 18 us per call at 10752 rows; the slab round trip through HBM goes away too).  With a K split the partial slabs and
 // their reduction in resid_ln stay as they are.  The additions happen in the same order either way: bit-identical results.
-// ln_out (producer of a folded LayerNorm, fold path of run_block): no K split, the residual stream updated in place, h->xb and
-// h->lnp written by the epilogue.  ln_in (consumer): A is h->xb, W the folded weight, bias = c2.
-struct LnIn { const float* c1; };
 static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, int epi,
                      const float* bias, const int* bias_step, int bias_stride, void* out, int ldo, int* n_slabs, hipStream_t st,
-                     float* resid = nullptr, const float* resid_bias = nullptr, bool ln_out = false, const LnIn* ln_in = nullptr,
-                     const bf16_t* Wp = nullptr) {
+                     float* resid = nullptr, const float* resid_bias = nullptr) {
     GemmArgs a{};
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cfg.gelu_v2;
     a.bias = bias; a.bias_step = bias_step; a.bias_stride = bias_stride; a.out = out; a.ldo = ldo;
-    int bm, bn, sk, gl = 0, nwave = 0;
-    // decode steps of <= 512 rows: the K-split kernel on the fragment-packed copy of the weight (gemm_ks.h)
-    const bool ks = Wp && h->use_ks && !ln_out && !ln_in && rq_gemm_pick_ks(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &nwave, &sk);
-    if (!ks) rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL && !ln_out, &bm, &bn, &sk, &gl);
+    int bm, bn, sk, gl = 0;
+    rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);
     if (sk > h->max_slabs) sk = h->max_slabs;
-    if (ln_out) { a.xb = h->xb; a.ln_part_out = h->lnp; }
-    if (ln_in) { a.ln_part_in = h->lnp; a.ln_c1 = ln_in->c1; a.ln_n_part = K / 32; a.ln_eps = 1e-5f; }
     static const bool no_fuse = getenv("RQAMD_NO_FUSE_RESID") != nullptr;      // A/B switch
-    if (resid && epi == EPI_F32_PARTIAL && sk == 1 && !no_fuse && (N & 3) == 0 && (ks || !(bm == 64 && bn == 32))) {
+    if (resid && epi == EPI_F32_PARTIAL && sk == 1 && !no_fuse && (N & 3) == 0 && !(bm == 64 && bn == 32)) {
         a.accum = 1; a.bias = resid_bias; a.out = resid; a.ldo = N;
         sk = 0;                                                              // reported slab count
     }
@@ -506,8 +397,7 @@ static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, in
         }
         RQ_HIP(hipEventRecord(pf.ev[pf.used], st));
     }
-    if (ks) { a.W = Wp; RQ_TRY(rq_gemm_launch_ks(a, bm, bn, nwave, st)); }
-    else RQ_TRY(rq_gemm_launch(a, bm, bn, st));
+    RQ_TRY(rq_gemm_launch(a, bm, bn, st));
     if (pf.on) {
         RQ_HIP(hipEventRecord(pf.ev[pf.used + 1], st));
         pf.used += 2;
@@ -531,8 +421,7 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     r.x_out = (x_in != x || pend.slabs || pend.bias || addvec) ? x : nullptr;      // nothing to add in place: the stream is not rewritten
     r.gamma = L.ln1w; r.beta = L.ln1b; r.y = h->y; r.rows = rows; r.E = E; r.eps = 1e-5f;
     RQ_TRY(rq_launch_resid_ln(r, st));
-    RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st, nullptr, nullptr, false, nullptr,
-                     L.pqkv));
+    RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
     if (pf) {
         AttnPrefillArgs ap{};
         const long img_stride = (long)h->cfg.n_head * Tcap * 64;
@@ -553,28 +442,13 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
         if (pfl.on) { RQ_HIP(hipEventRecord(pfl.ev_attn[pfl.used_attn + 1], st)); pfl.used_attn += 2; }
     }
     int ns = 1;
-    if (h->fold && !pf && (long)rows * g_rq_row_scale <= 128) {
-        // Small-batch decode step (<= 128 rows: every launch is a few microseconds of latency): ln2 costs no
-        // launch of its own.  The proj GEMM adds its branch into the residual stream in place and hands the next GEMM a bf16 copy
-        // of the updated rows plus their LayerNorm partials; mlp.0 multiplies the RAW rows by the gain-folded weight and
-        // normalises in its epilogue (GemmArgs::ln_part_in).  Six launches per block instead of seven.
-        RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj, true));
-        if (ns != 0) return rq_fail(RQAMD_ERR_STATE, "rqt: the folded-LayerNorm step needs the in-place residual epilogue");
-        const LnIn li{L.f1.c1};
-        RQ_TRY(step_gemm(h, h->xb, E, L.f1.wg, rows, 4 * E, E, EPI_BF16_GELU, L.f1.c2, nullptr, 0, h->hbuf, 4 * E, nullptr, st, nullptr, nullptr, false, &li));
-        RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bfc2));
-        if (ns) { pend.slabs = h->slabs; pend.n = ns; pend.bias = L.bfc2; }
-        else pend = Pending{nullptr, 0, nullptr};
-        return RQAMD_OK;
-    }
-    RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj, false, nullptr, L.pproj));
+    RQ_TRY(step_gemm(h, h->ya, E, L.wproj, rows, E, E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bproj));
     ResidLnArgs r2{};
     r2.x_in = x; r2.x_out = ns ? x : nullptr; r2.slabs = ns ? h->slabs : nullptr; r2.n_slabs = ns; r2.bias = ns ? L.bproj : nullptr;
     r2.gamma = L.ln2w; r2.beta = L.ln2b; r2.y = h->y; r2.rows = rows; r2.E = E; r2.eps = 1e-5f;
     RQ_TRY(rq_launch_resid_ln(r2, st));
-    RQ_TRY(step_gemm(h, h->y, E, L.wfc1, rows, 4 * E, E, EPI_BF16_GELU, L.bfc1, nullptr, 0, h->hbuf, 4 * E, nullptr, st, nullptr, nullptr, false, nullptr,
-                     L.pfc1));
-    RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bfc2, false, nullptr, L.pfc2));
+    RQ_TRY(step_gemm(h, h->y, E, L.wfc1, rows, 4 * E, E, EPI_BF16_GELU, L.bfc1, nullptr, 0, h->hbuf, 4 * E, nullptr, st));
+    RQ_TRY(step_gemm(h, h->hbuf, 4 * E, L.wfc2, rows, E, 4 * E, EPI_F32_PARTIAL, nullptr, nullptr, 0, h->slabs, E, &ns, st, x, L.bfc2));
     if (ns) { pend.slabs = h->slabs; pend.n = ns; pend.bias = L.bfc2; }
     else pend = Pending{nullptr, 0, nullptr};      // the stream already holds this block's output
     return RQAMD_OK;

@@ -64,20 +64,6 @@ struct GemmArgs {
     int sched, sched_gm;     // tile schedule (filled by rq_gemm_launch): 0 linear, 1 n-ranges per XCD, 2 m-bands per XCD
     int dbg;                 // diagnostics only: bit0 = skip the epilogue (ablation in scripts/gemm_bench.py)
     int glds;                // 0 = register-staged operands; 2..3 = LDS-DMA ring with that many stages (dense only)
-    // ---- LayerNorm folded into the GEMMs on either side of it (gemm_stream_kernel only; the small-batch decode step, engine_rqt.hip)
-    // Producer side (accum != 0): besides updating the fp32 residual stream in place, the epilogue writes a bf16 copy of the
-    // updated rows (xb, row stride N: the next GEMM's A operand) and, per workgroup, the (sum, sum of squared deviations from the
-    // workgroup's own mean) of its 32 columns of every row (ln_part_out[blockIdx.x][M][2]).
-    bf16_t* xb;
-    float* ln_part_out;
-    // Consumer side (ln_part_in != nullptr; bf16 epilogues): A is the RAW residual row (bf16), W is the weight with the LayerNorm
-    // gain folded in (W[n][k] * gamma[k], rounded once), and the normalisation is applied to the accumulator:
-    //     out[m][n] = rstd_m * (acc[m][n] - mean_m * ln_c1[n]) + bias[n],   ln_c1[n] = sum_k Wg[n][k],  bias[n] = b[n] + sum_k W[n][k] beta[k]
-    // = Linear(LayerNorm(x)) (attentions.py:128,135 of the reference) with mean_m / rstd_m merged from the producer's ln_n_part partials.
-    const float* ln_part_in;
-    const float* ln_c1;
-    int ln_n_part;
-    float ln_eps;
 };
 
 // GELU of the transformer MLP (attentions.py:17-22 of the reference): v1 = x * Phi(x), v2 = x * sigmoid(1.702 x).
@@ -1416,17 +1402,6 @@ int rq_gemm_launch(const GemmArgs& a, int bm, int bn, hipStream_t stream);
 void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* splitk, int* glds);
 
 
-// ---- K-split kernel for 1 .. 512 rows (gemm_ks.h; kernels instantiated in gemm.hip)
-#define RQ_WP_BLOCK_BYTES 4096
-// Packs W[N][K] (row-major bf16) into the fragment layout of gemm_ks.h; Wp must hold rq_packed_w_elems(N, K) bf16.
-static inline long rq_packed_w_elems(int N, int K) { return (long)((N + 31) / 32) * (K / 64) * (RQ_WP_BLOCK_BYTES / 2); }
-int rq_pack_w(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t stream);
-// Tile choice of the K-split kernel for a decode-step GEMM of M rows: false when another kernel should run (M > 512, the
-// classifier's N, ...).  bm = 64 / 128, bn = 32 / 64 / 96, nwave = 8 / 4; splitk > 1 only with allow_splitk.
-bool rq_gemm_pick_ks(int M, int N, int K, bool allow_splitk, int* bm, int* bn, int* nwave, int* splitk);
-// a.W = the packed copy
-int rq_gemm_launch_ks(const GemmArgs& a, int bm, int bn, int nwave, hipStream_t stream);
-
 // -------------------------------------------------------------------------------------------------
 // Weight-streaming GEMM for the small-batch decode steps (M <= 128 rows per m-tile: the per-GPU batches of 64 / 100 that
 // SURVEY 8d names).  At these sizes a GEMM is one pass over W with almost no arithmetic, and what decides its time is how
@@ -1446,7 +1421,9 @@ int rq_gemm_launch_ks(const GemmArgs& a, int bm, int bn, int nwave, hipStream_t 
 // (K-tiles of a slice dealt round-robin to four accumulators, MFMA order inside a tile, reduction order) does not depend on
 // BM, so the 64- and 128-row forms agree bit for bit.
 #ifdef RQ_STREAM_TRACE
-// Diagnostics build only (scripts/stream_trace.py): constant-clock (100 MHz) stamps of every workgroup's phases
+// Diagnostics build only (scripts/stream_trace.py): constant-clock (100 MHz) stamps of every workgroup's phases -- entry, first
+// DMA burst issued, first K-tile landed, main loop done, after the barrier, partial tiles in LDS, stores issued, stores
+// acknowledged, and (slots 8 ..) tile landed / MFMAs issued for the first eight K-tiles of wavefronts 0 and 3
 static __device__ unsigned long long g_stream_trace[1024 * 2 * 24];
 #define RQ_ST(slot) do { if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3) && blockIdx.y == 0) { \
         const int wg_ = blockIdx.x + gridDim.x * blockIdx.z;                                                                          \
@@ -1454,20 +1431,26 @@ static __device__ unsigned long long g_stream_trace[1024 * 2 * 24];
 #else
 #define RQ_ST(slot) do { } while (0)
 #endif
-template <int BM>
+template <int BM, int BN = 32>
 __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
     RQ_ST(0);
-    constexpr int BN = 32, BK = 64, NW = 4;
+    // BN = 64 (BM = 64 only, round 4): for GEMMs whose 32-row tiles would not fit one round of the 256 CUs -- fc1 of the E = 2560
+    // models (N = 10240: 320 workgroups, 23 us against ~12 for one round) and their fc2 (K = 10240: two K slices of 80 tiles each)
+    // -- a workgroup owns 64 weight rows: half the workgroups, each reading the activation rows once for twice the columns.  The
+    // arithmetic of an output element is the same as with 32-row tiles (same K-tile -> wavefront assignment, same reduction order).
+    constexpr int BK = 64, NW = 4, NB = BN / 32;
+    static_assert(BN == 32 || (BN == 64 && BM == 64), "tile shapes: BM x 32, or 64 x 64");
     constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, SLOT = A_BYTES + W_BYTES;
 #ifdef RQ_STREAM_NS
-    constexpr int NS = RQ_STREAM_NS;                   // (diagnostics: ring-depth sensitivity)
+    constexpr int NS = RQ_STREAM_NS;                   // (diagnostics: ring-depth sensitivity; 2 == 3, profiles/r04_stream_trace_ring2.txt)
 #else
-    constexpr int NS = BM == 64 ? 3 : 2;               // slots per wavefront
+    constexpr int NS = (BM == 64 && BN == 32) ? 3 : 2; // slots per wavefront
 #endif
     constexpr int A_G = BM / 8, W_G = BN / 8, PER = A_G + W_G;      // 1-KB (8-row) DMA groups per K-tile
     constexpr int MI = BM / 32;
     constexpr int RS = BN + 1;                         // row stride (floats) of a partial tile in LDS
     static_assert(NW * NS * SLOT <= 160 * 1024 && NW * BM * RS * 4 <= NW * NS * SLOT, "LDS budget");
+    static_assert(2 * PER <= 63, "vmcnt range");
     RQ_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = rq_uniform(tid >> 6);
@@ -1514,11 +1497,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rd[ks] = (unsigned)(frow * (BK * 2) + (((ks * 2 + fk) ^ ((frow >> 1) & 7)) << 4));
 
-    f32x16 acc[MI];
+    f32x16 acc[MI][NB];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
@@ -1531,61 +1516,18 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
     const int epi = p.epi;
     const bool accum = epi == EPI_F32_PARTIAL && p.accum;
     if (epi == EPI_F32_PARTIAL && !accum) bias = nullptr;
-    const int c0 = (tid & 3) * 8;
-    float bv[8], xr[BM / 64][8];
-    {
-        const int n = n0 + c0;
+    const int c0 = (tid & 3) * 8;                      // this thread's 8 columns inside every 32-column block
+    float bv[NB][8], xr[BM / 64][NB][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < p.N) ? bias[n + e] : 0.f;
+    for (int cb = 0; cb < NB; ++cb) {
+        const int n = n0 + 32 * cb + c0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[cb][e] = (bias && n + e < p.N) ? bias[n + e] : 0.f;
 #pragma unroll
         for (int rr = 0; rr < BM / 64; ++rr) {
             const int m = m0 + (tid >> 2) + 64 * rr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xr[rr][e] = (accum && m < p.M && n + e < p.N) ? ((const float*)p.out)[(long)m * p.ldo + n + e] : 0.f;
-        }
-    }
-    // LayerNorm applied in the epilogue (GemmArgs::ln_part_in): the row's mean / rstd are merged here, while the first K-tiles are in
-    // flight, from the producer's per-workgroup partials (sum, M2 about the partial's own mean, 32 columns each).  The four threads
-    // of a row take every fourth partial, two passes over registers (mean first, then M2 += 32 (mean_j - mean)^2: Chan's update with
-    // equal counts), quad butterflies by DPP -- a fixed order, so a row's statistics depend on nothing but the row.
-    constexpr int LN_PS = 32;                        // partials per thread: ln_n_part <= 128, i.e. K <= 4096
-    float c1v[8], ln_mu[BM / 64], ln_rs[BM / 64];
-#pragma unroll
-    for (int rr = 0; rr < BM / 64; ++rr) { ln_mu[rr] = 0.f; ln_rs[rr] = 1.f; }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) c1v[e] = 0.f;
-    if (p.ln_part_in) {                              // uniform
-        const int n = n0 + c0, sub = tid & 3;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) c1v[e] = (n + e < p.N) ? p.ln_c1[n + e] : 0.f;
-        const float inv_k = 1.0f / (float)p.K;
-#pragma unroll
-        for (int rr = 0; rr < BM / 64; ++rr) {
-            int m = m0 + (tid >> 2) + 64 * rr;
-            m = m < p.M ? m : p.M - 1;
-            f32x2 ps[LN_PS];
-#pragma unroll
-            for (int i = 0; i < LN_PS; ++i) {
-                const int j = 4 * i + sub;
-                ps[i] = (f32x2){0.f, 0.f};
-                if (j < p.ln_n_part) ps[i] = *(const f32x2*)(p.ln_part_in + ((long)j * p.M + m) * 2);
-            }
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_PS; ++i) s += ps[i].x;
-            s += rq_dpp_xor1(s);
-            s += rq_dpp_xor2(s);
-            const float mean = s * inv_k;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < LN_PS; ++i) {
-                const float d = ps[i].x * (1.0f / 32.0f) - mean;
-                if (4 * i + sub < p.ln_n_part) q += fmaf(32.0f * d, d, ps[i].y);
-            }
-            q += rq_dpp_xor1(q);
-            q += rq_dpp_xor2(q);
-            ln_mu[rr] = mean;
-            ln_rs[rr] = 1.0f / sqrtf(q * inv_k + p.ln_eps);
+            for (int e = 0; e < 8; ++e) xr[rr][cb][e] = (accum && m < p.M && n + e < p.N) ? ((const float*)p.out)[(long)m * p.ldo + n + e] : 0.f;
         }
     }
     int slot = 0;
@@ -1598,12 +1540,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
         if (i == 0) RQ_ST(2);
         if (i < 8) RQ_ST(8 + 2 * i);
         const char* sb = (const char*)smem + (wave * NS + slot) * SLOT;
-        bf16x8 af[MI][4], bfr[4];
+        bf16x8 af[MI][4], bfr[NB][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) af[mi][ks] = as_bf16x8(ld128(sb + rd[ks] + mi * (32 * BK * 2)));
-            bfr[ks] = as_bf16x8(ld128(sb + A_BYTES + rd[ks]));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bfr[j][ks] = as_bf16x8(ld128(sb + A_BYTES + rd[ks] + j * (32 * BK * 2)));
         }
         rq_wait_lgkmcnt<0>();                        // the fragments are in registers: the slot may be refilled
         rq_wave_sync();
@@ -1612,9 +1555,11 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi] = rq_mfma_32x32x16_bf16(af[mi][ks], bfr[ks], acc[mi]);
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[mi][j] = rq_mfma_32x32x16_bf16(af[mi][ks], bfr[j][ks], acc[mi][j]);
 #ifdef RQ_STREAM_TRACE
-        if (i < 8) { rq_opaque_acc(acc[0]); RQ_ST(9 + 2 * i); }
+        if (i < 8) { rq_opaque_acc(acc[0][0]); RQ_ST(9 + 2 * i); }
 #endif
         slot = slot + 1 == NS ? 0 : slot + 1;
     }
@@ -1627,83 +1572,64 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * fk;
-            sRed[(wave * BM + row) * RS + frow] = acc[mi][r];
-        }
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                sRed[(wave * BM + row) * RS + 32 * j + frow] = acc[mi][j][r];
+            }
     rq_syncthreads();
     RQ_ST(5);
 #pragma unroll
     for (int rr = 0; rr < BM / 64; ++rr) {
-        const int row = (tid >> 2) + 64 * rr;
-        const int m = m0 + row, n = n0 + c0;
-        const bool ln_out = accum && p.xb;           // uniform: every lane stays for the quad reductions of the LayerNorm partials
-        const bool valid = m < p.M && n < p.N;
-        if (!valid && !ln_out) continue;
-        float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = sRed[row * RS + c0 + e];
+        for (int cb = 0; cb < NB; ++cb) {
+            const int row = (tid >> 2) + 64 * rr, cc = 32 * cb + c0;
+            const int m = m0 + row, n = n0 + cc;
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) a += sRed[(w * BM + row) * RS + c0 + e];
-            v[e] = a;
-        }
-        const bool full = n + 7 < p.N;
-        if (epi <= EPI_BF16_RESID) {
-            if (p.ln_part_in) {                      // uniform: Linear(LayerNorm(x)) from the raw row, see GemmArgs::ln_part_in
+            for (int e = 0; e < 8; ++e) {
+                float a = sRed[row * RS + cc + e];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaf(ln_rs[rr], fmaf(-ln_mu[rr], c1v[e], v[e]), bv[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                for (int w = 1; w < NW; ++w) a += sRed[(w * BM + row) * RS + cc + e];
+                v[e] = a;
             }
-            if (epi == EPI_BF16_GELU) {
-                float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
-                rq_gelu4(lo, p.gelu_v2);
-                rq_gelu4(hi, p.gelu_v2);
+            const bool full = n + 7 < p.N;
+            if (epi <= EPI_BF16_RESID) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-            }
-            if (epi == EPI_BF16_RESID)
-                for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
-            bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
-            if (full && (p.ldo & 7) == 0) {
-                rq_u128 u;
-                u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
-                st128(o, u);
-            } else {
-                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = f32_to_bf16(v[e]);
-            }
-        } else {
-            float* o = (float*)p.out + ((epi == EPI_F32_PARTIAL && !accum) ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
-            if (ln_out || (full && (p.ldo & 3) == 0)) {      // (ln_out: the launcher checked N % 32 == 0 and ldo % 4 == 0)
-                f32x4 lo, hi;
+                for (int e = 0; e < 8; ++e) v[e] += bv[cb][e];
+                if (epi == EPI_BF16_GELU) {
+                    float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+                    rq_gelu4(lo, p.gelu_v2);
+                    rq_gelu4(hi, p.gelu_v2);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    lo[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
-                    hi[e] = accum ? (xr[rr][4 + e] + v[4 + e]) + bv[4 + e] : v[4 + e] + bv[4 + e];
+                    for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
                 }
-                if (valid) {
+                if (epi == EPI_BF16_RESID)
+                    for (int e = 0; e < 8 && n + e < p.N; ++e) v[e] += bf16_to_f32(p.resid[(long)m * p.ldr + n + e]);
+                bf16_t* o = (bf16_t*)p.out + (long)m * p.ldo + n;
+                if (full && (p.ldo & 7) == 0) {
+                    rq_u128 u;
+                    u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]); u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
+                    st128(o, u);
+                } else {
+                    for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = f32_to_bf16(v[e]);
+                }
+            } else {
+                float* o = (float*)p.out + ((epi == EPI_F32_PARTIAL && !accum) ? (long)blockIdx.z * p.M * p.ldo : 0) + (long)m * p.ldo + n;
+                if (full && (p.ldo & 3) == 0) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = accum ? (xr[rr][cb][e] + v[e]) + bv[cb][e] : v[e] + bv[cb][e];
+                        hi[e] = accum ? (xr[rr][cb][4 + e] + v[4 + e]) + bv[cb][4 + e] : v[4 + e] + bv[cb][4 + e];
+                    }
                     *(f32x4*)o = lo;
                     *(f32x4*)(o + 4) = hi;
+                } else {
+                    for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = accum ? (xr[rr][cb][e] + v[e]) + bv[cb][e] : v[e] + bv[cb][e];
                 }
-                if (ln_out) {                        // the LayerNorm hand-off, GemmArgs::xb / ln_part_out
-                    rq_u128 u;
-                    u.x = pack_bf16x2(lo[0], lo[1]); u.y = pack_bf16x2(lo[2], lo[3]); u.z = pack_bf16x2(hi[0], hi[1]); u.w = pack_bf16x2(hi[2], hi[3]);
-                    if (valid) st128(p.xb + (long)m * p.N + n, u);
-                    float sm = ((lo[0] + lo[1]) + (lo[2] + lo[3])) + ((hi[0] + hi[1]) + (hi[2] + hi[3]));
-                    sm += rq_dpp_xor1(sm);           // the four threads of a row: its 32 columns in this workgroup
-                    sm += rq_dpp_xor2(sm);
-                    const float mu = sm * (1.0f / 32.0f);
-                    float q = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float dl = lo[e] - mu, dh = hi[e] - mu; q = fmaf(dl, dl, q); q = fmaf(dh, dh, q); }
-                    q += rq_dpp_xor1(q);
-                    q += rq_dpp_xor2(q);
-                    if (valid && (tid & 3) == 0) *(f32x2*)(p.ln_part_out + ((long)blockIdx.x * p.M + m) * 2) = (f32x2){sm, q};
-                }
-            } else {
-                for (int e = 0; e < 8 && n + e < p.N; ++e) o[e] = accum ? (xr[rr][e] + v[e]) + bv[e] : v[e] + bv[e];
             }
         }
     }

@@ -1,6 +1,5 @@
 // gemm.hip -- launcher / tile selection for the bf16 MFMA GEMM (see gemm.h)
 #include "gemm.h"
-#include "gemm_ks.h"
 #include <stdlib.h>
 #include "rq_common.h"
 
@@ -108,92 +107,18 @@ static int launch_p8(const GemmArgs& a, hipStream_t stream) {
 }
 
 // weight-streaming kernel for small batches (gemm.h): dense operands, 32 weight rows x BM activation rows per workgroup
-template <int BM>
+template <int BM, int BN = 32>
 static int launch_stream(const GemmArgs& a, hipStream_t stream) {
 #ifdef RQ_STREAM_NS
-    constexpr size_t smem = (size_t)4 * RQ_STREAM_NS * ((BM + 32) * 64 * 2);
+    constexpr size_t smem = (size_t)4 * RQ_STREAM_NS * ((BM + BN) * 64 * 2);
 #else
-    constexpr size_t smem = (size_t)4 * (BM == 64 ? 3 : 2) * ((BM + 32) * 64 * 2);
+    constexpr size_t smem = (size_t)4 * ((BM == 64 && BN == 32) ? 3 : 2) * ((BM + BN) * 64 * 2);
 #endif
     static RqDeviceOnce attr_once;
     if (attr_once.first())
-        (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    RQ_LAUNCH(gemm_stream_kernel<BM>, dim3((a.N + 31) / 32, (a.M + BM - 1) / BM, a.splitk), dim3(256), smem, stream, a);
+        (void)hipFuncSetAttribute((const void*)gemm_stream_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    RQ_LAUNCH((gemm_stream_kernel<BM, BN>), dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk), dim3(256), smem, stream, a);
     return rq_check_launch("gemm_stream_kernel");
-}
-
-// K-split kernel (gemm_ks.h): a.W is the fragment-packed copy
-template <int BM, int BN, int NWAVE>
-static int launch_ks(const GemmArgs& a, hipStream_t stream) {
-    constexpr size_t ring = (size_t)NWAVE * 2 * BM * 128, frag = (size_t)(NWAVE / 2) * (BM / 32) * (BN / 32) * 16 * 64 * 4, tile = (size_t)BM * (BN + 1) * 4;
-    constexpr size_t smem = ring > frag ? (ring > tile ? ring : tile) : (frag > tile ? frag : tile);
-    static RqDeviceOnce attr_once;
-    if (attr_once.first())
-        (void)hipFuncSetAttribute((const void*)gemm_ks_kernel<BM, BN, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    RQ_LAUNCH((gemm_ks_kernel<BM, BN, NWAVE>), dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.splitk), dim3(NWAVE * 64), smem, stream, a);
-    return rq_check_launch("gemm_ks_kernel");
-}
-
-int rq_gemm_launch_ks(const GemmArgs& a_in, int bm, int bn, int nwave, hipStream_t stream) {
-    GemmArgs a = a_in;
-    if (a.splitk < 1) a.splitk = 1;
-    if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0 || a.conv)
-        return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm ks: dense operands, K=%d a positive multiple of 64 (M=%d N=%d)", a.K, a.M, a.N);
-    if (2.0 * a.M * a.lda >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm ks: A larger than 4 GiB");
-    if (a.splitk > 1 && a.epi != EPI_F32_PARTIAL) return rq_fail(RQAMD_ERR_INVALID, "gemm ks: split-K needs the partial-slab epilogue");
-    if (a.accum && (a.epi != EPI_F32_PARTIAL || a.splitk != 1)) return rq_fail(RQAMD_ERR_INVALID, "gemm ks: in-place accumulation needs the slab epilogue and one K split");
-    if (a.epi == EPI_BF16_RESID || a.xb || a.ln_part_in || a.ln_part_out) return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm ks: epilogue family not built");
-    if (bm == 64 && bn == 32 && nwave == 8) return launch_ks<64, 32, 8>(a, stream);
-    if (bm == 128 && bn == 32 && nwave == 4) return launch_ks<128, 32, 4>(a, stream);
-    if (bm == 128 && bn == 64 && nwave == 4) return launch_ks<128, 64, 4>(a, stream);
-    if (bm == 128 && bn == 96 && nwave == 4) return launch_ks<128, 96, 4>(a, stream);
-    return rq_fail(RQAMD_ERR_INVALID, "gemm ks: no tile %dx%d with %d wavefronts", bm, bn, nwave);
-}
-
-int rq_pack_w(const bf16_t* W, bf16_t* Wp, int N, int K, hipStream_t stream) {
-    if (K % 64 != 0 || N < 1) return rq_fail(RQAMD_ERR_UNSUPPORTED, "pack_w: K=%d must be a multiple of 64", K);
-    const long pieces = rq_packed_w_elems(N, K) / 8;
-    RQ_LAUNCH(rq_pack_w_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, W, Wp, N, K);
-    return rq_check_launch("rq_pack_w_kernel");
-}
-
-// Tile choice of the K-split kernel (gemm_ks.h).  <= 64 rows: 64 x 32 tiles, eight wavefronts.  65 .. 512 rows: 128-row m-tiles,
-// four wavefronts, and the weight-tile width (32 / 64 / 96) and K split that move the fewest bytes per workgroup while the whole
-// launch fits ONE round of the 256 CUs -- a launch is as slow as its slowest workgroup, and a second round doubles it
-// (profiles/r04_launch_probe.txt: ~100 GB/s per CU once the first bytes are there).  A function of (row class, N, K) only.
-bool rq_gemm_pick_ks(int M_rows, int N, int K, bool allow_splitk, int* bm, int* bn, int* nwave, int* splitk) {
-    static const bool off = false;                                 // (the engine-level switch is RQAMD_NO_KS, read at rqamd_rqt_create)
-    static const int max_rows = getenv("RQAMD_KS_MAX_ROWS") ? atoi(getenv("RQAMD_KS_MAX_ROWS")) : 512;
-    const long M = (long)M_rows * g_rq_row_scale;
-    if (off || M > max_rows || K % 64 != 0 || N >= 16384 || N < 64) return false;
-    const int kt = K / 64;
-    if (M <= 64) {
-        *bm = 64; *bn = 32; *nwave = 8;
-        int sk = 1;
-        if (allow_splitk) {
-            const int nt = (N + 31) / 32;
-            while (sk < 8 && nt * (sk * 2) <= 256 && kt % (sk * 2) == 0 && kt / (sk * 2) >= 4) sk *= 2;
-        }
-        *splitk = sk;
-        return true;
-    }
-    const int mt = (int)((M + 127) / 128);
-    double best = 1e30;
-    int best_bn = 32, best_sk = 1;
-    for (int cbn = 96; cbn >= 32; cbn -= 32) {
-        const int nt = (N + cbn - 1) / cbn;
-        for (int sk = 1; sk <= (allow_splitk ? 8 : 1); sk *= 2) {
-            if (kt % sk != 0 || kt / sk < 4) continue;
-            const long wgs = (long)mt * nt * sk;
-            const long rounds = (wgs + 255) / 256;
-            // us: operand bytes of a workgroup at ~100 GB/s per CU, per round; + what every extra slab costs its producer and consumer
-            double t = (double)rounds * (128.0 + cbn) * (K / sk) * 2.0 / 100e3 + (sk > 1 ? 0.6 * sk : 0.0);
-            if (wgs < 128) t += 1.0;                 // few workgroups: the weights arrive through few CUs
-            if (t < best) { best = t; best_bn = cbn; best_sk = sk; }
-        }
-    }
-    *bm = 128; *bn = best_bn; *nwave = 4; *splitk = best_sk;
-    return true;
 }
 
 template <int BM, int BN>
@@ -233,16 +158,10 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
         return rq_fail(RQAMD_ERR_INVALID, "gemm: virtual split-K needs a conv with a bf16 epilogue, one real split and an even number of K-tiles per chunk");
     if (a.accum && (a.epi != EPI_F32_PARTIAL || a.splitk != 1 || (a.N & 3) || (a.ldo & 3) || (bm == 64 && bn == 32)))
         return rq_fail(RQAMD_ERR_INVALID, "gemm: in-place accumulation needs the slab epilogue, one K split and N, ldo multiples of 4");
-    if (a.xb || a.ln_part_out || a.ln_part_in) {      // LayerNorm folded into the GEMMs around it: gemm_stream_kernel only
-        if (!((bm == 66 || bm == 130) && bn == 32) || a.conv)
-            return rq_fail(RQAMD_ERR_INVALID, "gemm: the folded-LayerNorm epilogues exist in the weight-streaming kernel only");
-        if ((a.xb || a.ln_part_out) && (!a.xb || !a.ln_part_out || !a.accum || (a.N & 31) || (a.ldo & 3)))
-            return rq_fail(RQAMD_ERR_INVALID, "gemm: LayerNorm partials need the in-place residual epilogue, xb and ln_part_out, N %% 32 == 0");
-        if (a.ln_part_in && (a.epi > EPI_BF16_GELU || !a.ln_c1 || a.ln_n_part < 1 || a.ln_n_part > 128 || a.ln_n_part * 32 != a.K))
-            return rq_fail(RQAMD_ERR_INVALID, "gemm: the folded LayerNorm needs a bf16 epilogue, ln_c1 and K / 32 <= 128 partials");
-    }
-    if ((bm == 66 || bm == 130) && bn == 32) {      // tile codes 66x32 / 130x32: the weight-streaming kernel on 64 / 128 activation rows
+    if (((bm == 66 || bm == 130) && bn == 32) || (bm == 66 && bn == 64)) {
+        // tile codes 66x32 / 130x32: the weight-streaming kernel on 64 / 128 activation rows; 66x64: its 64-row weight tiles
         if (a.conv) return rq_fail(RQAMD_ERR_UNSUPPORTED, "gemm stream: dense operands only");
+        if (bn == 64) return launch_stream<64, 64>(a, stream);
         return bm == 66 ? launch_stream<64>(a, stream) : launch_stream<128>(a, stream);
     }
     if (bm == 64 && bn == 32) {       // skinny kernel (M <= 64): 32 weight rows per workgroup, in-workgroup split-K over 8 wavefronts
@@ -339,6 +258,15 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
         if (allow_splitk) {
             const int nt = (N + 31) / 32, kt = K / 64;
             while (sk < 8 && nt * (sk * 2) <= 256 && kt % (sk * 2) == 0 && kt / (sk * 2) >= 4) sk *= 2;
+        }
+        // 64-row GEMMs whose 32-row weight tiles do not fit ONE round of the 256 CUs take 64-row tiles (round 4; E = 2560: fc1 has
+        // 320 tiles, 23.0 us = two rounds; fc2's 80 tiles allow only two K slices of 80 K-tiles each, 21.8 us): half the workgroups,
+        // the same arithmetic per output element.  (65 .. 128 rows keep 32-row tiles: a 128 x 64 slot pair does not fit the LDS.)
+        static const bool no_bn64 = getenv("RQAMD_NO_STREAM_BN64") != nullptr;      // A/B switch
+        if (M <= 64 && !no_bn64) {
+            const int nt32 = (N + 31) / 32, nt64 = (N + 63) / 64, kt = K / 64;
+            if (nt32 > 256) *bn = 64;
+            else if (allow_splitk && kt >= 128 && nt32 * 4 > 256 && nt64 * 4 <= 256 && kt % 4 == 0) { *bn = 64; sk = 4; }
         }
         *splitk = sk;
         return;
@@ -445,9 +373,7 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
 extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, int K, const float* bias, int epi,
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
-    int flags = 0, glds = 0, accum = 0, ks = 0;
-    if (epi >= 4096) { ks = 1; epi -= 4096; }                 // epi + 4096: the K-split kernel (gemm_ks.h); W is the PACKED copy (rqamd_dbg_pack_w),
-                                                              // bm = 64 (bn 32, eight wavefronts) or 128 (bn 32 / 64 / 96, four); bm <= 0: its own choice
+    int flags = 0, glds = 0, accum = 0;
     if (epi >= 2048) { accum = 1; epi -= 2048; }              // 4 + 2048: in-place residual accumulation (splitk 1)
     if (epi >= 1024) { flags |= 128; epi -= 1024; }           // epi + 1024: 256x256 kernel with four phases per K-tile (A/B)
     if (epi >= 512) { flags |= 64; epi -= 512; }              // epi + 512: 256x256 kernel with two phases per K-tile (A/B)
@@ -457,17 +383,6 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
     GemmArgs a{};
     a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.epi = epi;
     a.bias = bias; a.out = out; a.ldo = N; a.splitk = splitk; a.dbg = flags; a.glds = glds; a.accum = accum;
-    if (ks) {
-        int nwave = bm == 64 ? 8 : 4;
-        if (bm <= 0 || bn <= 0) {
-            int sk = 1;
-            if (!rq_gemm_pick_ks(M, N, K, epi == EPI_F32_PARTIAL && !accum, &bm, &bn, &nwave, &sk))
-                return rq_fail(RQAMD_ERR_UNSUPPORTED, "dbg_gemm: the K-split kernel does not take M=%d N=%d K=%d", M, N, K);
-            if (splitk <= 0) a.splitk = sk;
-        }
-        if (a.splitk <= 0) a.splitk = 1;
-        return rq_gemm_launch_ks(a, bm, bn, nwave, (hipStream_t)stream);
-    }
     if (bm <= 0 || bn <= 0) {
         int sk, gl = 0;
         rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);
@@ -477,36 +392,6 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
     }
     if (a.splitk <= 0) a.splitk = 1;
     return rq_gemm_launch(a, bm, bn, (hipStream_t)stream);
-}
-
-// diagnostics: W[N][K] row-major bf16 -> the fragment-packed copy of gemm_ks.h; Wp holds ceil(N / 32) * (K / 64) * 2048 bf16
-extern "C" int rqamd_dbg_pack_w(const void* W, int N, int K, void* Wp, void* stream) {
-    if (!W || !Wp) return rq_fail(RQAMD_ERR_INVALID, "dbg_pack_w: null argument");
-    return rq_pack_w((const bf16_t*)W, (bf16_t*)Wp, N, K, (hipStream_t)stream);
-}
-// diagnostics: the tile the K-split kernel would take for (M, N, K): out[4] = {bm, bn, wavefronts, splitk}; returns 1 when it applies
-extern "C" int rqamd_dbg_pick_ks(int M, int N, int K, int allow_splitk, int* out) {
-    if (!out) return rq_fail(RQAMD_ERR_INVALID, "dbg_pick_ks: null argument");
-    out[0] = out[1] = out[2] = out[3] = 0;
-    return rq_gemm_pick_ks(M, N, K, allow_splitk != 0, &out[0], &out[1], &out[2], &out[3]) ? 1 : 0;
-}
-
-// diagnostics: the two halves of a LayerNorm folded into the GEMMs around it (gemm_stream_kernel; GemmArgs::xb / ln_part_in).
-//  mode 0 (producer): x[M][N] fp32 is updated in place, x = (x + A W^T) + bias; xb[M][N] bf16 and part[N / 32][M][2] are written.
-//  mode 1 (consumer): out[M][N] bf16 = epi(rstd_m (A W^T - mean_m c1) + bias), statistics merged from part[K / 32][M][2]; epi 0 / 1.
-extern "C" int rqamd_dbg_gemm_ln(const void* A, const void* W, int M, int N, int K, const float* bias, int mode, int epi, float* x,
-                                 void* xb, float* part, const float* c1, void* out, int bm, void* stream) {
-    if (!A || !W || !part) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
-    GemmArgs a{};
-    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.M = M; a.N = N; a.K = K; a.lda = K; a.bias = bias; a.splitk = 1;
-    if (mode == 0) {
-        if (!x || !xb) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
-        a.epi = EPI_F32_PARTIAL; a.accum = 1; a.out = x; a.ldo = N; a.xb = (bf16_t*)xb; a.ln_part_out = part;
-    } else {
-        if (!out || !c1) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm_ln: null argument");
-        a.epi = epi; a.out = out; a.ldo = N; a.ln_part_in = part; a.ln_c1 = c1; a.ln_n_part = K / 32; a.ln_eps = 1e-5f;
-    }
-    return rq_gemm_launch(a, bm == 130 ? 130 : 66, 32, (hipStream_t)stream);
 }
 
 // diagnostics: one implicit-GEMM convolution launch.  x NHWC bf16 [B][H>>ups][W>>ups][Cin], w [Cout][k][k][Cin] bf16,

@@ -186,13 +186,6 @@ static __device__ __forceinline__ int wave_sum_i(int v) {
 struct __attribute__((aligned(16))) rq_u128 { uint32_t x, y, z, w; };
 static __device__ __forceinline__ rq_u128 ld128(const void* p) { return *(const rq_u128*)p; }
 static __device__ __forceinline__ void st128(void* p, rq_u128 v) { *(rq_u128*)p = v; }
-// a 16-byte global load that sits between LDS-DMAs of a counted-vmcnt schedule (the host emulator gives it a place in the lane's queue)
-static __device__ __forceinline__ rq_u128 ldg128_counted(const void* p) {
-#ifdef RQ_EMU
-    rq_emu_count_load();
-#endif
-    return *(const rq_u128*)p;
-}
 static __device__ __forceinline__ rq_u128 zero128() { rq_u128 z; z.x = z.y = z.z = z.w = 0; return z; }
 static __device__ __forceinline__ bf16x8 as_bf16x8(rq_u128 v) {
     union { rq_u128 u; bf16x8 b; } c; c.u = v; return c.b;

@@ -160,7 +160,8 @@ static int launch_resid_ln_wave(const ResidLnArgs& a, hipStream_t s) {
 }
 
 int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s) {
-    if ((long)a.rows * g_rq_row_scale >= 512 && a.E % 256 == 0) {       // plenty of rows: a wavefront per row keeps every CU busy
+    static const long wave_min_rows = getenv("RQAMD_LN_WAVE_MIN_ROWS") ? atol(getenv("RQAMD_LN_WAVE_MIN_ROWS")) : 512;      // A/B switch
+    if ((long)a.rows * g_rq_row_scale >= wave_min_rows && a.E % 256 == 0) {       // plenty of rows: a wavefront per row keeps every CU busy
         int rc = 1;
         switch (a.E / 256) {
             case 4: rc = launch_resid_ln_wave<4>(a, s); break;     // E = 1024 (355M)

@@ -78,10 +78,6 @@ _SIGS = {
     'rqamd_rqt_get_profile_attn': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'rqamd_dbg_gemm_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'rqamd_dbg_pack_w': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    'rqamd_dbg_pick_ks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
-    'rqamd_dbg_gemm_ln': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -305,61 +301,6 @@ def dbg_gemm(a_bf16, w_bf16, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
             out = torch.empty((M, N), dtype=torch.float32 if kind == 3 else torch.bfloat16, device=a_bf16.device)
     check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias), epi,
                                     ptr(out), bm, bn, splitk, stream_of(a_bf16)))
-    return out
-
-
-def dbg_pack_w(w_bf16):
-    """diagnostics: w (N,K) bf16 -> the fragment-packed copy the K-split decode GEMM reads (csrc/gemm_ks.h)."""
-    N, K = w_bf16.shape
-    wp = torch.empty((((N + 31) // 32) * (K // 64) * 2048,), dtype=torch.bfloat16, device=w_bf16.device)
-    check(lib().rqamd_dbg_pack_w(ptr(w_bf16, torch.bfloat16), N, K, ptr(wp), stream_of(w_bf16)))
-    return wp
-
-
-def dbg_gemm_ks(a_bf16, wp_bf16, N, bias=None, epi=3, bm=0, bn=0, splitk=0, out=None):
-    """diagnostics: dbg_gemm through the K-split kernel; wp = dbg_pack_w(w), N = w.shape[0]."""
-    M, K = a_bf16.shape
-    if out is None:
-        kind = epi % 16
-        if kind == 4:
-            out = torch.empty((splitk if splitk > 0 else 8, M, N), dtype=torch.float32, device=a_bf16.device)
-        else:
-            out = torch.empty((M, N), dtype=torch.float32 if kind == 3 else torch.bfloat16, device=a_bf16.device)
-    check(lib().rqamd_dbg_gemm_bf16(ptr(a_bf16, torch.bfloat16), ptr(wp_bf16, torch.bfloat16), M, N, K, ptr(bias), epi + 4096,
-                                    ptr(out), bm, bn, splitk, stream_of(a_bf16)))
-    return out
-
-
-def dbg_pick_ks(M, N, K, allow_splitk=False):
-    """diagnostics: (bm, bn, wavefronts, splitk) of the K-split kernel for this shape, or None when another kernel runs."""
-    out = (C.c_int * 4)()
-    r = lib().rqamd_dbg_pick_ks(int(M), int(N), int(K), int(bool(allow_splitk)), out)
-    if r < 0:
-        check(r)
-    return tuple(out) if r == 1 else None
-
-
-def dbg_gemm_ln_producer(a_bf16, w_bf16, bias, x, bm=66):
-    """diagnostics: the residual-producing half of a folded LayerNorm: x (M,N) fp32 is updated in place, x = (x + a @ w^T) + bias;
-    returns (xb, part): bf16(x) and the per-32-column LayerNorm partials (N / 32, M, 2)."""
-    M, K = a_bf16.shape
-    N = w_bf16.shape[0]
-    xb = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
-    part = torch.empty((N // 32, M, 2), dtype=torch.float32, device=x.device)
-    check(lib().rqamd_dbg_gemm_ln(ptr(a_bf16, torch.bfloat16), ptr(w_bf16, torch.bfloat16), M, N, K, ptr(bias, torch.float32), 0, 0,
-                                  ptr(x, torch.float32), ptr(xb), ptr(part), None, None, bm, stream_of(x)))
-    return xb, part
-
-
-def dbg_gemm_ln_consumer(xb, wg_bf16, c1, c2, part, gelu=False, bm=66):
-    """diagnostics: Linear(LayerNorm(x)) from the raw bf16 rows xb (M,K), the gain-folded weight wg (N,K), c1 = wg.sum(1),
-    c2 = bias + W @ beta and the producer's partials; returns (M,N) bf16."""
-    M, K = xb.shape
-    N = wg_bf16.shape[0]
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=xb.device)
-    check(lib().rqamd_dbg_gemm_ln(ptr(xb, torch.bfloat16), ptr(wg_bf16, torch.bfloat16), M, N, K, ptr(c2, torch.float32), 1,
-                                  1 if gelu else 0, None, None, ptr(part, torch.float32), ptr(c1, torch.float32), ptr(out), bm,
-                                  stream_of(xb)))
     return out
 
 

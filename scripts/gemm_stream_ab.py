@@ -42,17 +42,17 @@ for M in [int(x) for x in os.environ.get('RQ_MS', '8,64,100,128,256,500').split(
         out_old = _native.dbg_gemm(a, ws[0], b, epi, 0, 0, 0)
         t_old = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, 0, 0, 0, out=out_old))
         best = None
-        for bm in ((66,) if M <= 64 else (130,)):
+        for bm, bn in (((66, 32), (66, 64)) if M <= 64 else ((130, 32),)):      # 66x64: 64-row weight tiles (round 4)
             for sk in ((1, 2, 4, 8) if epi == 4 else (1,)):
                 if (K // 64) % sk:
                     continue
-                out = _native.dbg_gemm(a, ws[0], b, epi, bm, 32, sk)
+                out = _native.dbg_gemm(a, ws[0], b, epi, bm, bn, sk)
                 got = out.float().sum(0) if epi == 4 else out.float()
                 err = ((got - ref).abs().max() / ref.abs().max()).item()
-                t = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, bm, 32, sk, out=out))
-                res.append(f'{bm}sk{sk}:{t:5.1f}')
+                t = timed(lambda i: _native.dbg_gemm(a, ws[i % 12], b, epi, bm, bn, sk, out=out))
+                res.append(f'{bm}x{bn}sk{sk}:{t:5.1f}')
                 if best is None or t < best[0]:
-                    best = (t, f'{bm}/sk{sk}', err)
+                    best = (t, f'{bm}x{bn}/sk{sk}', err)
         tot_old += t_old if name != 'cls' else 0
         tot_new += best[0] if name != 'cls' else 0
         print(f'M={M:4d} {name:5s} N={N:5d} K={K:5d}: tiled/auto {t_old:6.1f} us | stream {best[0]:6.1f} us ({best[1]}, err {best[2]:.1e}; '

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Small-batch sampling A/B (round 4): RQTransformer.sample of the 1.4B model (or RQ_MODEL) at the per-GPU batches SURVEY 8d names, on
-engine variants that live in one process and are timed interleaved (the switches are read when an engine is created):
-  base  the round-3 kernels (RQAMD_NO_KS=1)      ks  the K-split decode GEMM (default)      fold  base + LayerNorm fold (RQAMD_LNFOLD=1)
-RQ_VARIANTS=base,ks  RQ_BS=64,100,200,500  RQ_MODEL=huge.  Prints AR ms per batch and images/s (AR only).  The codes of two variants
-differ wherever rounding differs (other summation orders): the parity of each is what the GPU tests check."""
+engine variants that live in one process and are timed interleaved.  A variant is a name plus environment switches that are read
+when an engine is created, e.g. RQ_VARIANTS='base,nostream:RQAMD_NO_STREAM=1' (switches that a launcher caches in a function-local
+static on first use cannot be A/B'd this way).  RQ_BS=64,100,200,500  RQ_MODEL=huge.  Prints AR ms per batch and images/s (AR only);
+the codes of two variants differ wherever rounding differs -- the parity of each is what the GPU tests check."""
 import os
 import sys
 import time
@@ -19,19 +19,24 @@ torch.set_grad_enabled(False)
 dev = torch.device('cuda', 0)
 model = os.environ.get('RQ_MODEL', 'huge')
 batches = [int(b) for b in os.environ.get('RQ_BS', '64,100,128').split(',')]
-variants = os.environ.get('RQ_VARIANTS', 'base,ks').split(',')
+variants = os.environ.get('RQ_VARIANTS', 'base').split(',')
 engines = {}
 vae = None
-ENV = {'base': {'RQAMD_NO_KS': '1'}, 'ks': {}, 'fold': {'RQAMD_NO_KS': '1', 'RQAMD_LNFOLD': '1'}}
+# a variant = environment switches that the engine / launchers read when first used ("name:VAR=val+VAR2=val2"; "base" = none)
+def _env_of(v):
+    return dict(kv.split('=', 1) for kv in v.split(':', 1)[1].split('+')) if ':' in v else {}
+
+
+ALL_KEYS = sorted({k for v in variants for k in _env_of(v)})
 for v in variants:
-    for k in ('RQAMD_NO_KS', 'RQAMD_LNFOLD'):
+    for k in ALL_KEYS:
         os.environ.pop(k, None)
-    os.environ.update(ENV[v])
+    os.environ.update(_env_of(v))
     vae, ar, cfg = presets.build(model, device=dev, seed=0)
     part = torch.zeros((2,) + tuple(ar.block_size), device=dev, dtype=torch.long)
     ar.sample(part, model_aux=vae, cond=torch.zeros((2, ar.block_size_cond), device=dev, dtype=torch.long), top_k=1024, top_p=0.95)
     engines[v] = ar
-for k in ('RQAMD_NO_KS', 'RQAMD_LNFOLD'):
+for k in ALL_KEYS:
     os.environ.pop(k, None)
 for B in batches:
     part = torch.zeros((B,) + tuple(engines[variants[0]].block_size), device=dev, dtype=torch.long)

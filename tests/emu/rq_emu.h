@@ -68,8 +68,7 @@ struct Fiber {
 extern bool g_dma_late;
 inline void dma_land_until(Fiber& f, size_t keep) {
     size_t n = f.dma.size() > keep ? f.dma.size() - keep : 0;
-    for (size_t i = 0; i < n; ++i)
-        if (f.dma[i].dst) memcpy(f.dma[i].dst, f.dma[i].data, 16);       // (dst == nullptr: a plain global load that only counts)
+    for (size_t i = 0; i < n; ++i) memcpy(f.dma[i].dst, f.dma[i].data, 16);
     if (n) f.dma.erase(f.dma.begin(), f.dma.begin() + (long)n);
 }
 
@@ -154,16 +153,6 @@ static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
         rqemu::g_cur->dma.push_back(pd);
     } else {
         memcpy(dst, gsrc, 16);
-    }
-}
-// a plain 16-byte global load issued BETWEEN LDS-DMAs of a counted schedule (gemm_ks_kernel's W fragments): the value is available
-// at once here; in the late-landing mode it takes a place in the lane's queue so that counted waits see what the hardware counts
-struct rq_u128;
-static inline void rq_emu_count_load() {
-    if (rqemu::g_dma_late) {
-        rqemu::PendingDma pd;
-        pd.dst = nullptr;
-        rqemu::g_cur->dma.push_back(pd);
     }
 }
 static inline void rq_glds16_s(uintptr_t lds_base, const void* sbase, unsigned voff) { rq_glds16(lds_base, (const char*)sbase + voff); }

@@ -640,7 +640,7 @@ def test_emu_gemm_256x256_eight_phase(nat):
             a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
 
 
-@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream', 'ksplit'])
+@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream'])
 def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
     """The LDS-DMA GEMMs again with RQ_EMU_DMA=late: a DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it --
     the latest moment the hardware allows -- so a fragment read that is not ordered behind the covering wait (+ a barrier for other
@@ -651,8 +651,6 @@ def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
         test_emu_gemm_tiles_and_lds_dma(nat)
     elif which == 'eight_phase':
         test_emu_gemm_256x256_eight_phase(nat)
-    elif which == 'ksplit':
-        test_emu_gemm_ksplit(nat)          # (its W loads are plain global loads between the DMAs: they take their place in the count)
     else:
         test_emu_gemm_stream(nat)
 
@@ -704,6 +702,16 @@ def test_emu_gemm_stream(nat):
                 slab = nat.dbg_gemm(a, w, None, epi=4, bm=bm, bn=32, splitk=1)[0]
                 assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm)
         assert np.array_equal(outs[66], outs[130]), (M, N, K)
+        if M <= 64:
+            # 64-row weight tiles (round 4: GEMMs too wide for one round of 32-row tiles): the same arithmetic per output element
+            assert np.array_equal(nat.dbg_gemm(a, w, bias, epi=3, bm=66, bn=64, splitk=1).numpy(), outs[66]), (M, N, K)
+            assert torch.equal(nat.dbg_gemm(a, w, bias, epi=0, bm=66, bn=64, splitk=1), nat.dbg_gemm(a, w, bias, epi=0, bm=66, bn=32, splitk=1))
+            if K >= 512:
+                assert torch.equal(nat.dbg_gemm(a, w, None, epi=4, bm=66, bn=64, splitk=2), nat.dbg_gemm(a, w, None, epi=4, bm=66, bn=32, splitk=2))
+            if N % 4 == 0:
+                x64 = x0.clone()
+                nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=66, bn=64, splitk=1, out=x64)
+                assert torch.equal(x64, xs), (M, N, K)
     # GELU epilogue vs torch
     a = torch.from_numpy(rng.standard_normal((48, 256)).astype(np.float32)).to(torch.bfloat16)
     w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
@@ -711,141 +719,7 @@ def test_emu_gemm_stream(nat):
     ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
     out = nat.dbg_gemm(a, w, bias, epi=1, bm=66, bn=32, splitk=1).float().numpy()
     assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
-
-
-def _pack_w_numpy(w):
-    """Wp[ceil(N / 32)][K / 64][4][64][8] of csrc/gemm_ks.h: lane l of k-step ks holds W[32 nb + (l & 31)][64 kt + 16 ks + 8 (l >> 5) + 0..7]"""
-    N, K = w.shape
-    nbt, kt = (N + 31) // 32, K // 64
-    wz = np.zeros((nbt * 32, K), w.dtype)
-    wz[:N] = w
-    v = wz.reshape(nbt, 32, kt, 4, 2, 8)                   # nb, row, kt, ks, half, e
-    return np.ascontiguousarray(v.transpose(0, 2, 3, 4, 1, 5)).reshape(-1)   # nb, kt, ks, half, row, e -> lane = row + 32 half
-
-
-def _check_gemm_ks(nat, rng, M, N, K, bm, bn):
-    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
-    w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
-    wp = nat.dbg_pack_w(w)
-    assert np.array_equal(wp.view(torch.int16).numpy(), _pack_w_numpy(w.view(torch.int16).numpy())), (N, K)
-    bias = T(rng.standard_normal(N).astype(np.float32))
-    ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
-    scale = np.abs(ref).max()
-    out = nat.dbg_gemm_ks(a, wp, N, bias, epi=3, bm=bm, bn=bn, splitk=1).numpy()
-    assert np.abs(out - ref).max() < 2e-3 * scale, (M, N, K, bm, bn)
-    out16 = nat.dbg_gemm_ks(a, wp, N, bias, epi=0, bm=bm, bn=bn, splitk=1).float().numpy()
-    assert np.abs(out16 - ref).max() < 1e-2 * scale, (M, N, K, bm, bn)
-    if (K // 64) % 2 == 0:
-        slabs = nat.dbg_gemm_ks(a, wp, N, None, epi=4, bm=bm, bn=bn, splitk=2).numpy()
-        assert np.abs(slabs.sum(0) - (ref - bias.numpy())).max() < 2e-3 * scale, (M, N, K, bm, bn)
-    x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32))
-    xs = x0.clone()
-    nat.dbg_gemm_ks(a, wp, N, bias, epi=4 + 2048, bm=bm, bn=bn, splitk=1, out=xs)
-    slab = nat.dbg_gemm_ks(a, wp, N, None, epi=4, bm=bm, bn=bn, splitk=1)[0]
-    assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm, bn)           # the additions of slab + resid_ln, in their order
-    return out
-
-
-def test_emu_gemm_ksplit(nat):
-    """K-split decode GEMM (csrc/gemm_ks.h: wavefronts take every NWAVE-th K-tile, A through private two-slot LDS-DMA rings, W through
-    registers from the fragment-packed copy, pairwise tree reduction through LDS): the packed layout against its definition; every
-    tile (64 x 32 with eight wavefronts, 128 x 32 / 64 / 96 with four) on ragged M / N, several m-tiles, K-tile counts that leave
-    wavefronts with one, several or no tiles; fp32 / bf16 / GELU / split-K slab / in-place residual epilogues vs numpy; a row's
-    result does not depend on the rows around it."""
-    rng = np.random.default_rng(31)
-    for (M, N, K) in ((64, 96, 512), (37, 70, 1536), (1, 64, 128), (64, 160, 1024)):
-        _check_gemm_ks(nat, rng, M, N, K, 64, 32)
-    for bn in (32, 64, 96):
-        for (M, N, K) in ((128, 192, 384), (100, 200, 640), (300, 96, 256)):
-            _check_gemm_ks(nat, rng, M, N, K, 128, bn)
-    # GELU epilogue vs torch; batch independence of a row (same tile: rows 0..4 alone == inside 50 rows)
-    a = torch.from_numpy(rng.standard_normal((50, 256)).astype(np.float32)).to(torch.bfloat16)
-    w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
-    wp = nat.dbg_pack_w(w)
-    bias = T(rng.standard_normal(64).astype(np.float32))
-    ref = torch.nn.functional.gelu(a.float() @ w.float().T + bias).numpy()
-    for bm, bn in ((64, 32), (128, 64)):
-        out = nat.dbg_gemm_ks(a, wp, 64, bias, epi=1, bm=bm, bn=bn, splitk=1).float().numpy()
-        assert np.abs(out - ref).max() < 1e-2 * np.abs(ref).max()
-        few = nat.dbg_gemm_ks(a[:5].contiguous(), wp, 64, bias, epi=1, bm=bm, bn=bn, splitk=1).float().numpy()
-        assert np.array_equal(few, out[:5])
-    # the picker: <= 64 rows -> 64 x 32 / eight wavefronts; 65 .. 512 rows -> 128-row tiles in one round of 256 workgroups
-    assert nat.dbg_pick_ks(64, 4608, 1536)[:3] == (64, 32, 8)
-    assert nat.dbg_pick_ks(64, 1536, 6144, True) == (64, 32, 8, 4)
-    for M in (100, 200, 500):
-        for N, K, sk in ((4608, 1536, False), (1536, 1536, True), (6144, 1536, False), (1536, 6144, True)):
-            bm, bn, nw, s = nat.dbg_pick_ks(M, N, K, sk)
-            assert (bm, nw) == (128, 4) and ((M + 127) // 128) * ((N + bn - 1) // bn) * s <= 256, (M, N, K, bn, s)
-    assert nat.dbg_pick_ks(1000, 4608, 1536) is None and nat.dbg_pick_ks(64, 16384, 1536) is None
-
-
-def test_emu_gemm_folded_layernorm(nat):
-    """LayerNorm folded into the GEMMs on either side of it (gemm_stream_kernel, GemmArgs::xb / ln_part_in -- the <= 128-row decode
-    step's ln2 + mlp.0, attentions.py:135): the producer updates the fp32 stream in place exactly like the plain in-place epilogue
-    and hands over bf16(x) plus per-32-column (sum, M2) partials; the consumer multiplies the RAW rows by the gain-folded weight and
-    normalises in the epilogue.  Checked against numpy LayerNorm + Linear on the fp32 rows; 64- and 128-row forms bit-identical;
-    ragged M, several m-tiles, partial counts that leave some of a row's four threads without work."""
-    rng = np.random.default_rng(29)
-    for (M, E, N2, K0) in ((64, 128, 96, 256), (37, 192, 64, 128), (128, 64, 160, 64), (200, 320, 64, 192)):
-        a = torch.from_numpy(rng.standard_normal((M, K0)).astype(np.float32)).to(torch.bfloat16)
-        wp = torch.from_numpy((0.1 * rng.standard_normal((E, K0))).astype(np.float32)).to(torch.bfloat16)
-        bp = T(rng.standard_normal(E).astype(np.float32))
-        x0 = torch.from_numpy((rng.standard_normal((M, E)) * 1.5 + 0.3).astype(np.float32))
-        gamma = (1.0 + 0.2 * rng.standard_normal(E)).astype(np.float32)
-        beta = (0.1 * rng.standard_normal(E)).astype(np.float32)
-        w1 = (0.1 * rng.standard_normal((N2, E))).astype(np.float32)
-        b1 = rng.standard_normal(N2).astype(np.float32)
-        wg = torch.from_numpy(w1 * gamma[None, :]).to(torch.bfloat16)
-        c1 = wg.float().sum(1).contiguous()
-        c2 = T(b1 + w1 @ beta)
-        outs = {}
-        for bm in (66, 130):
-            x = x0.clone()
-            xb, part = nat.dbg_gemm_ln_producer(a, wp, bp, x, bm=bm)
-            slab = nat.dbg_gemm(a, wp, None, epi=4, bm=bm, bn=32, splitk=1)[0]
-            assert torch.equal(x, (x0 + slab) + bp), (M, E, bm)                   # the plain in-place epilogue's additions
-            assert torch.equal(xb, x.to(torch.bfloat16)), (M, E, bm)
-            xg = x.numpy().reshape(M, E // 32, 32).astype(np.float64)
-            want = np.stack([xg.sum(-1), ((xg - xg.mean(-1, keepdims=True)) ** 2).sum(-1)], -1).transpose(1, 0, 2)
-            assert np.allclose(part.numpy(), want, rtol=2e-5, atol=2e-5), (M, E, bm)
-            for gelu in (False, True):
-                out = nat.dbg_gemm_ln_consumer(xb, wg, c1, c2, part, gelu=gelu, bm=bm).float().numpy()
-                xn = x.numpy().astype(np.float64)
-                ln = (xn - xn.mean(-1, keepdims=True)) / np.sqrt(xn.var(-1, keepdims=True) + 1e-5) * gamma + beta
-                ref = ln @ w1.T.astype(np.float64) + b1
-                if gelu:
-                    ref = torch.nn.functional.gelu(torch.from_numpy(ref)).numpy()
-                assert np.abs(out - ref).max() < 1.5e-2 * max(np.abs(ref).max(), 1.0), (M, E, bm, gelu, np.abs(out - ref).max())
-                outs[(bm, gelu)] = out
-        for gelu in (False, True):
-            assert np.array_equal(outs[(66, gelu)], outs[(130, gelu)]), (M, E, gelu)
-
-
-def test_emu_rqt_folded_layernorm_late_parameters(nat, golden):
-    """The fold of ln2 into mlp.0 is made from the fp32 weight when the LayerNorm parameters are already there (state_dict order);
-    a LayerNorm that arrives AFTER the weight (a caller editing ln2 in place) is folded into the bf16 copy when the tables are
-    finalised.  Both orders give the fixture's logits (the late order within the extra bf16 rounding of the weight), and
-    RQAMD_NO_LNFOLD-free engines agree with the un-folded large-batch path within bf16 noise (test_emu_rqt_tiny_logits)."""
-    g = golden('rqt_tiny.npz')
-    cfg = C.RQT_TINY
-    hps, dd = C.VAE_TINY
-    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
-    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
-    codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
-    eng = _rqt_engine(nat, cfg, params)
-    first = eng.logits(codes, cond, [T(cb)] * 4).numpy()
-    late = dict((k, v) for k, v in params.items() if '.ln2.' not in k)
-    late.update((k, v) for k, v in params.items() if '.ln2.' in k)             # ln2 last
-    eng2 = _rqt_engine(nat, cfg, late)
-    second = eng2.logits(codes, cond, [T(cb)] * 4).numpy()
-    for out in (first, second):
-        err = np.abs(out - g['logits'])
-        assert err.max() < 0.06 and err.mean() < 0.01
-    assert np.abs(first - second).max() < 0.02
-    # re-pushing in state_dict order over the late-order engine restores the single-rounding fold bit for bit
-    for k, v in params.items():
-        eng2.set_param(k, T(v))
-    assert np.array_equal(eng2.logits(codes, cond, [T(cb)] * 4).numpy(), first)
+    assert np.array_equal(nat.dbg_gemm(a, w, bias, epi=1, bm=66, bn=64, splitk=1).float().numpy(), out)
 
 
 def test_emu_conv_halo(nat):
