@@ -232,7 +232,9 @@ def gemm_roofline(ar, vae, empty_sample, empty_cond, top_k, top_p, device, model
     else:
         roofline = {'bound': 'mfma', 'achieved': tfl, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tfl / MFMA_BF16_PEAK_TFLOPS}
     traffic, traffic_src, traffic_note = None, None, None
-    tp = os.path.join(ROOT, 'profiles', f'r03_gemm_traffic_m{B}.json')
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_gemm_traffic_m{B}.json')))      # the newest round's file
+    tp = cands[-1] if cands else os.path.join(ROOT, 'profiles', f'r04_gemm_traffic_m{B}.json')
     if model == 'huge' and os.path.exists(tp):
         # PMC counters cannot be collected from inside the timed run; this is the committed result of `scripts/gpu.sh pmc`
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes) for the same GEMM shapes at the same batch rows,
