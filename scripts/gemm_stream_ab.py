@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch  # noqa: E402
 from rqvae import _native  # noqa: E402
 
+if os.environ.get('RQ_LIB'):          # A/B a differently-built kernel library (scripts/build_variant.py; diagnostics only)
+    _native.LIB_PATH = os.environ['RQ_LIB']
 dev = 'cuda'
 E = int(os.environ.get('RQ_E', 1536))      # 1536: the 1.4B model; 2560: the 3.8B model (BASELINE configs[3]); 1024: the 355M model
 SHAPES = (('qkv', 3 * E, E, 0), ('proj', E, E, 4), ('fc1', 4 * E, E, 1), ('fc2', E, 4 * E, 4), ('cls', 16384 if E != 1024 else 2048, E, 3))
