@@ -27,8 +27,8 @@ assert n % 6 == 0 and n >= 30, n
 import os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rq-vae-transformer_amd'))
 from rqvae import _native  # noqa: E402
-fused = not os.environ.get('RQAMD_NO_FUSE_RESID')
-rb = 8 if fused else 4          # residual epilogue: fp32 stream read + written in place; slab epilogue: one fp32 slab written
+fused = not os.environ.get('RQAMD_NO_FUSE_RESID') and M >= 2048      # (below 2048 rows the engine's tile choice splits K: slab epilogue, as gemm_traffic.py launches it)
+rb = 8 if fused else 4          # residual epilogue: fp32 stream read + written in place; slab epilogue: fp32 slabs written (counted as one: the ratio then includes the extra slabs)
 shapes = [('qkv', 4608, 1536, 2, 4224), ('proj (in-place residual epilogue)' if fused else 'proj (split-K slab)', 1536, 1536, rb, 4224),
           ('fc1', 6144, 1536, 2, 4224), ('fc2 (in-place residual epilogue)' if fused else 'fc2 (split-K slab)', 1536, 6144, rb, 4224),
           ('classifier', 16384, 1536, 4, 256)]
