@@ -682,6 +682,22 @@ def test_vae_batch_invariance_full_size(nat, golden):
     assert torch.equal(vae.get_codes(x)[2:3], vae.get_codes(x[2:3].contiguous()))
 
 
+def test_vae_small_chunk_reserves_its_split_k_slab(nat, golden, monkeypatch):
+    """with RQAMD_VAE_CHUNK <= 8 the FULL chunks of a longer batch take the split-K path too and need the slab (chunk 8,
+    batch 9 used to fail with 'split-K slab ... was not reserved': only the 1-image tail was sized for).  Same bits as the default
+    chunking (the engine is batch-invariant)."""
+    g = golden('vae_imagenet.npz')
+    rng = np.random.default_rng(4)
+    codes = G(rng.integers(0, 16384, (9, 8, 8, 4)), torch.long)
+    x = G(np.clip(rng.standard_normal((9, 3, 256, 256), dtype=np.float32), -1, 1))
+    vae0, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    d0, z0 = vae0.decode_code(codes), vae0.encode(x)
+    monkeypatch.setenv('RQAMD_VAE_CHUNK', '8')             # read when the engine is created
+    vae1, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    assert torch.equal(vae1.decode_code(codes), d0)
+    assert torch.equal(vae1.encode(x), z0)
+
+
 def test_vae_decode_code_read_ahead(nat, golden):
     """The reference drivers decode ONE image per call out of the batch they sampled (measure_throughput/__main__.py:297-299:
     torch.cat([decode_code(chunk) for chunk in codes.chunk(B)]); main_sampling_fid.py:223: decode_code(pixels[i:i+1])).  Those
