@@ -27,7 +27,8 @@ per-GPU share, 100 / 200 / 500 = the reference's Fig. 4; each with its own roofl
 one-image-per-call loop as "driver_loop"), "per_image_decode" (that loop on its own), "per_image_recon", "roofline_rq"
 (the residual quantiser), "rqvae_encode" (codes/sec) and "cpu_baseline" (the REFERENCE's own modules -- oracle/_ref -- on the
 host cores, a bounded sample of a 32-image batch scaled to the metric's unit, kind "reference"; the numpy oracle port only when
-oracle/_ref is absent; rank 0, N=1 only)."""
+oracle/_ref is absent; rank 0, N=1 only) and "baseline_8gpu_models_per_gpu_point" (round 4: the two models BASELINE.json quotes on
+8 GPUs -- 3.8B at a global batch of 512, the 3.9B text-to-image shape -- at their per-GPU share of 64 images, on this one GPU)."""
 import argparse
 import json
 import os
@@ -73,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument('--top-k', type=int, default=1024)
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--sweep', type=str, default='64,100,200,500', help='extra per-GPU batches measured after the timed region ("" = none)')
+    ap.add_argument('--also', type=str, default='xhuge:64,txt3900m:64',
+                    help='model:batch points measured after everything else on rank 0 at N = 1 (default: the two models BASELINE.json quotes on '
+                         '8 GPUs, at their per-GPU share of 64 images; "" = none)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
@@ -784,6 +788,38 @@ def main(argv=None):
         except Exception as e:  # the baseline is reported, never required
             cpu = {'value': None, 'unit': 'images/sec', 'cores': os.cpu_count(), 'kind': 'port', 'sample': f'failed: {e!r}'}
 
+    # ---- the two models BASELINE.json quotes on 8 GPUs (configs[3]: 3.8B at a global batch of 512 = 64 per GPU; configs[4]: the 3.9B
+    # text-to-image shape, batch-sharded the same way) at their PER-GPU operating point, on this one GPU: what each of the 8 ranks
+    # of those configurations would run.  Random-init weights of the named architecture, like the headline.  The headline model and its
+    # 180-GB KV cache are released first.
+    also = []
+    if rank == 0 and world == 1 and args.also and args.model == 'huge' and not args.overlap:
+        try:
+            del empty_sample, empty_cond
+            if getattr(ar, '_engine', None) is not None:
+                ar._engine.close()
+                ar._engine = None
+            del ar
+            torch.cuda.empty_cache()
+            for spec in [x for x in args.also.split(',') if x]:
+                name, b = spec.split(':')
+                b = int(b)
+                _, ar2, cfg2 = presets.build(name, device=device, seed=0)
+                ips, a_ms, d_ms, es, ec = timed_batch(vae, ar2, b, device, args.top_k, args.top_p, steps=3, warmup=1)
+                codes2 = ar2.sample(es, model_aux=vae, cond=ec, top_k=args.top_k, top_p=args.top_p)
+                also.append({'model': name, 'workload': WORKLOADS.get(name, name), 'batch_per_gpu': b, 'images_per_sec': ips, 'ar_ms_per_batch': a_ms * b,
+                             'decode_ms_per_image': d_ms, 'params_M': sum(p.numel() for p in ar2.parameters()) / 1e6,
+                             'codes_in_range': bool(int(codes2.min()) >= 0 and int(codes2.max()) < cfg2['vocab_size']),
+                             'what': 'sample -> decode_code -> clamp, 3 timed steps after 1 warm-up, as batch_sweep; parity of this model at full depth: '
+                                     'tests/test_gpu_parity_big.py (rqt_in3800m / rqt_txt3900m fixtures)'})
+                if getattr(ar2, '_engine', None) is not None:
+                    ar2._engine.close()
+                    ar2._engine = None
+                del ar2, es, ec, codes2
+                torch.cuda.empty_cache()
+        except Exception as e:            # reported, never required
+            also.append({'error': repr(e)})
+
     if rank == 0:
         n_img = world * B * args.steps
         value = n_img / elapsed
@@ -819,7 +855,7 @@ def main(argv=None):
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
             'verified': None if verify is None else verify['verified'], 'verify': verify,
             'roofline': roofline, 'roofline_attn': roofline_attn, 'roofline_decode': roofline_decode,
-            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
