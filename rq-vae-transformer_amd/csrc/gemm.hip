@@ -252,7 +252,10 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     // Split-K (slab GEMMs): as many slices as keep (N / 32) x slices within one round of 256 CUs -- the kernel holds 144-160 KB of
     // LDS, one workgroup per CU (fc2: 4 slices 7.9 us, 8 slices 11.3) -- a function of (N, K) only.
     static const bool no_stream = getenv("RQAMD_NO_STREAM") != nullptr;      // A/B switch
-    if (!no_stream && M <= 128 && K % 64 == 0 && N < 16384 && N >= 64) {
+    // (the classifier's N = 16384 only at <= 64 rows, where the 64-row weight tiles below cover it in one round: 15.0 vs 16.9 us at
+    // E = 1536, 21.0 vs 25.0 at E = 2560, profiles/r04_gemm_stream_bn64_e2560.txt / r04_stream_k_rotation_ab.txt; at 65 .. 128 rows the
+    // tiled kernel stays ahead, 20.4 vs 23.0)
+    if (!no_stream && M <= 128 && K % 64 == 0 && (N < 16384 || (M <= 64 && N == 16384)) && N >= 64) {
         *bm = M <= 64 ? 66 : 130; *bn = 32;
         int sk = 1;
         if (allow_splitk) {
@@ -266,7 +269,9 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
         if (M <= 64 && !no_bn64) {
             const int nt32 = (N + 31) / 32, nt64 = (N + 63) / 64, kt = K / 64;
             if (nt32 > 256) *bn = 64;
-            else if (allow_splitk && kt >= 128 && nt32 * 4 > 256 && nt64 * 4 <= 256 && kt % 4 == 0) { *bn = 64; sk = 4; }
+            // (slab GEMMs of the wide models: four K slices of 64-row tiles move fewer bytes per workgroup than two of 32-row tiles --
+            // fc2 21.8 -> 18.0 us, proj 7.9 -> 7.2 at E = 2560)
+            else if (allow_splitk && kt >= 32 && nt32 * 4 > 256 && nt64 * 4 <= 256 && kt % 4 == 0) { *bn = 64; sk = 4; }
         }
         *splitk = sk;
         return;
