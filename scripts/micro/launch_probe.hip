@@ -96,6 +96,25 @@ __global__ __launch_bounds__(256) void k_rows_dma(const char* a, const char* w, 
     for (int i = tid; i < out_words; i += 256) out[(long)blockIdx.x * out_words + i] = acc + i;
 }
 
+// the shared rows once more, every load in flight, but addressed the way the GEMM's LDS-DMA addresses them: a wavefront instruction
+// covers 8 ROWS x 128 bytes (row stride 3072 bytes = K 1536 bf16; lane -> row lane / 8, 16-byte chunk lane % 8), wavefront w takes
+// K-tiles w, w + 4, ...: 48 loads per thread = the same 196 KB as k_rows_deep<48, 0>, which reads them as contiguous 4-KB blocks
+__global__ __launch_bounds__(256) void k_rows_gather(const char* a, unsigned* out, int out_words) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane >> 3, lc = lane & 7;
+    u32x4 r[48];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)              // K-tile wave + 4 i
+#pragma unroll
+        for (int g = 0; g < 8; ++g)          // 8-row group
+            r[i * 8 + g] = *(const u32x4*)(a + (long)(8 * g + lr) * 3072 + (wave + 4 * i) * 128 + lc * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) acc += r[i].x ^ r[i].y ^ r[i].z ^ r[i].w;
+    for (int i = tid; i < out_words; i += 256) out[(long)blockIdx.x * out_words + i] = acc + i;
+}
+
 template <typename F> static double time_graph(F enqueue, int n_launch, int reps) {
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -165,6 +184,12 @@ int main() {
         deep("deep: 196 KB shared + 56 KB own", k_rows_deep<48, 14>, wgs);
         deep("deep: 49 KB shared + 56 KB own", k_rows_deep<12, 14>, wgs);
         deep("deep: 49 KB shared + 16 KB own", k_rows_deep<12, 4>, wgs);
+    }
+    for (int wgs : {144, 256}) {
+        const double t = time_graph([&](hipStream_t s, int i) {
+            hipLaunchKernelGGL(k_rows_gather, dim3(wgs), dim3(256), 0, s, (const char*)((i & 1) ? o0 : o1), (i & 1) ? o1 : o0, OUT_WORDS);
+        }, NL, REPS);
+        printf("  %-34s %3d wgs  %.2f\n", "deep: 196 KB shared, 8 rows x 128 B", wgs, t);
     }
     // plain loads vs LDS-DMA at equal traffic: 128 KB shared rows + 16 KB own weights per workgroup, everything in flight
     auto dma = [&](const char* label, auto kern, int wgs, int smem) {
