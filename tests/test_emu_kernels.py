@@ -712,6 +712,14 @@ def test_emu_gemm_stream(nat):
                 x64 = x0.clone()
                 nat.dbg_gemm(a, w, bias, epi=4 + 2048, bm=66, bn=64, splitk=1, out=x64)
                 assert torch.equal(x64, xs), (M, N, K)
+    # the engine's own tile choice (bm = bn = 0) for a 64-row GEMM wider than one round of 32-row tiles (N / 32 > 256: fc1 of the
+    # E = 2560 models, the classifier): 64-row weight tiles, ragged last tile -- same bits as the 32-row tiles
+    a = torch.from_numpy(rng.standard_normal((5, 128)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.1 * rng.standard_normal((8240, 128))).astype(np.float32)).to(torch.bfloat16)
+    bias = T(rng.standard_normal(8240).astype(np.float32))
+    auto = nat.dbg_gemm(a, w, bias, epi=3, bm=0, bn=0, splitk=0).numpy()
+    assert np.abs(auto - (a.float().numpy() @ w.float().numpy().T + bias.numpy())).max() < 2e-3 * np.abs(auto).max()
+    assert np.array_equal(auto, nat.dbg_gemm(a, w, bias, epi=3, bm=66, bn=32, splitk=1).numpy())
     # GELU epilogue vs torch
     a = torch.from_numpy(rng.standard_normal((48, 256)).astype(np.float32)).to(torch.bfloat16)
     w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
