@@ -24,6 +24,9 @@
 #include <type_traits>
 #include "rq_hip.h"
 
+#ifndef RQ_TILED_W_NT        // weight DMAs of the LDS-DMA tiled kernels with the non-temporal policy (A/B switch)
+#define RQ_TILED_W_NT 0
+#endif
 #ifndef RQ_GEMM_VARIANT
 #define RQ_GEMM_VARIANT 0
 #endif
@@ -265,7 +268,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
         RQ_GT(4);
         constexpr int CPR = BN / 8;                // 16-byte chunks per row
         const bool v16 = (p.N & 7) == 0 && (p.ldo & 7) == 0;
-        if (FULL) {
+        if constexpr (FULL) {
             // piece k of a thread = 16-byte chunk tid % CPR of tile row tid / CPR + (NTH / CPR) k: all reads, then all stores
             static_assert(NTH % CPR == 0 && (BM * CPR) % NTH == 0, "whole rows per pass");
             constexpr int IT = BM * CPR / NTH, RSTEP = NTH / CPR;
@@ -703,7 +706,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     // past the last tile re-read the last tile (harmless), so the compiler can use counted vmcnt waits.
     const int nk = kt1 - kt0, last = kt1 - 1;
     if constexpr (GL > 0) {
-        static_assert(MODE == 0 && GL >= 2 && GL <= 4, "LDS-DMA staging: dense operands, 2..4 stages");
+        static_assert(MODE == 0 && GL >= 2 && GL <= 6, "LDS-DMA staging: dense operands, 2..6 stages");
         constexpr int NW = WGM * WGN;
         constexpr int A_PER = BM / 8 / NW, B_PER = BN / 8 / NW;      // 8-row (1 KB) groups per wavefront and tile
         constexpr int PER = A_PER + B_PER;
@@ -734,22 +737,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
             for (int q = 0; q < A_PER; ++q) rq_glds16(base + (rq_lds_t)((uw * A_PER + q) * 1024), gA + (ga[q] + kb));
 #pragma unroll
-            for (int q = 0; q < B_PER; ++q) rq_glds16(base + (rq_lds_t)(BM * 128 + (uw * B_PER + q) * 1024), gW + (gb[q] + kb));
+            for (int q = 0; q < B_PER; ++q) {
+#if RQ_TILED_W_NT
+                rq_glds16_nt(base + (rq_lds_t)(BM * 128 + (uw * B_PER + q) * 1024), gW + (gb[q] + kb));
+#else
+                rq_glds16(base + (rq_lds_t)(BM * 128 + (uw * B_PER + q) * 1024), gW + (gb[q] + kb));
+#endif
+            }
         };
+        static_assert((GL - 2) * PER <= 63, "vmcnt range");
+        // diagnostics (scripts only): dbg bit1 = no staging at all (MFMAs + fragment reads + barriers on whatever the LDS holds),
+        // bit2 = staging, waits and barriers only (no fragment reads, no MFMAs): which side of the loop a tile shape is bound by
+        const bool no_dma = p.dbg & 2, no_mma = p.dbg & 4;
         if (nk > 0) {
 #pragma unroll
             for (int s0 = 0; s0 < GL - 1; ++s0)
-                if (s0 < nk) issue(kt0 + s0, s0);
+                if (s0 < nk && !no_dma) issue(kt0 + s0, s0);
             int st = 0;
             for (int t = 0; t < nk; ++t) {
-                // tile t has landed once at most (tiles issued after it) * PER loads are outstanding
+                // tile t has landed once at most (tiles issued after it: up to GL - 2) * PER loads are outstanding
                 const int newer = nk - 1 - t;
-                if (GL >= 4 && newer >= 2) rq_wait_vmcnt<2 * PER>();
+                if (GL >= 6 && newer >= 4) rq_wait_vmcnt<(GL >= 6 ? 4 : 0) * PER>();
+                else if (GL >= 5 && newer >= 3) rq_wait_vmcnt<(GL >= 5 ? 3 : 0) * PER>();
+                else if (GL >= 4 && newer >= 2) rq_wait_vmcnt<(GL >= 4 ? 2 : 0) * PER>();
                 else if (GL >= 3 && newer >= 1) rq_wait_vmcnt<PER>();
                 else rq_wait_vmcnt<0>();
                 rq_barrier_raw();            // publishes stage st; every wave is past its reads of stage st-1 (refilled next)
-                if (t + GL - 1 < nk) issue(kt0 + t + GL - 1, st == 0 ? GL - 1 : st - 1);
-                compute(st);
+                if (t + GL - 1 < nk && !no_dma) issue(kt0 + t + GL - 1, st == 0 ? GL - 1 : st - 1);
+                if (!no_mma) compute(st);
                 st = st + 1 == GL ? 0 : st + 1;
             }
         }
@@ -1420,6 +1435,9 @@ void rq_gemm_pick_tile(int M, int N, int K, bool allow_splitk, int* bm, int* bn,
 // pieces.  blockIdx.z = split-K slice (fp32 partial slabs, residual-producing GEMMs).  The arithmetic of an output element
 // (K-tiles of a slice dealt round-robin to four accumulators, MFMA order inside a tile, reduction order) does not depend on
 // BM, so the 64- and 128-row forms agree bit for bit.
+#ifndef RQ_STREAM_W_NT       // weight DMAs of gemm_stream_kernel with the non-temporal policy (A/B: profiles/r05_stream_nt_ab.txt)
+#define RQ_STREAM_W_NT 0
+#endif
 #ifdef RQ_STREAM_TRACE
 // Diagnostics build only (scripts/stream_trace.py): constant-clock (100 MHz) stamps of every workgroup's phases -- entry, first
 // DMA burst issued, first K-tile landed, main loop done, after the barrier, partial tiles in LDS, stores issued, stores
@@ -1489,7 +1507,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmArgs p) {
 #pragma unroll
         for (int g = 0; g < A_G; ++g) rq_glds16(base + (rq_lds_t)(g * 1024), gA + (ga[g] + kb));
 #pragma unroll
-        for (int g = 0; g < W_G; ++g) rq_glds16(base + (rq_lds_t)(A_BYTES + g * 1024), gW + (gb[g] + kb));
+        for (int g = 0; g < W_G; ++g) {
+#if RQ_STREAM_W_NT
+            rq_glds16_nt(base + (rq_lds_t)(A_BYTES + g * 1024), gW + (gb[g] + kb));
+#else
+            rq_glds16(base + (rq_lds_t)(A_BYTES + g * 1024), gW + (gb[g] + kb));
+#endif
+        }
     };
     // fragment reads: row = 32 i + (lane & 31), chunk 2 ks + (lane >> 5), swizzled
     const int frow = lane & 31, fk = lane >> 5;

@@ -206,6 +206,37 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
                 if (gl == 2) return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 2>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 2>(a, stream); \
                 return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 3>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 3>(a, stream);               \
             }
+#ifdef RQ_GEMM_SWEEP
+            // diagnostics build (scripts/gemm_mid_sweep.py): tile code = BM + wave layout (0: 2 x 2, 1: 4 x 1, 4: 4 x 2 wavefronts), 2 .. 6 stages
+#define RQ_SW_GL(BM_, BN_, WM_, WN_, G_)                                                                                  \
+            if (gl == G_) {                                                                                                \
+                if constexpr ((BM_ + BN_) * 128 * G_ <= 160 * 1024)                                                        \
+                    return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, G_>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, G_>(a, stream); \
+                else return rq_fail(RQAMD_ERR_INVALID, "gemm sweep: %d stages of a %d x %d tile exceed the LDS", G_, BM_, BN_);         \
+            }
+#define RQ_SW_CASE(CODE_, BM_, BN_, WM_, WN_)                                                                             \
+            if (bm == CODE_ && bn == BN_) {                                                                                \
+                RQ_SW_GL(BM_, BN_, WM_, WN_, 2) RQ_SW_GL(BM_, BN_, WM_, WN_, 3) RQ_SW_GL(BM_, BN_, WM_, WN_, 4)             \
+                RQ_SW_GL(BM_, BN_, WM_, WN_, 5) RQ_SW_GL(BM_, BN_, WM_, WN_, 6)                                             \
+            }
+            RQ_SW_CASE(128, 128, 64, 2, 2)
+            RQ_SW_CASE(128, 128, 128, 2, 2)
+            RQ_SW_CASE(129, 128, 64, 4, 1)
+            RQ_SW_CASE(129, 128, 96, 4, 1)
+            RQ_SW_CASE(129, 128, 128, 4, 1)
+            RQ_SW_CASE(129, 128, 160, 4, 1)
+            RQ_SW_CASE(129, 128, 192, 4, 1)
+            RQ_SW_CASE(132, 128, 64, 4, 2)
+            RQ_SW_CASE(132, 128, 128, 4, 2)
+            RQ_SW_CASE(132, 128, 192, 4, 2)
+            RQ_SW_CASE(64, 64, 128, 2, 2)
+            RQ_SW_CASE(64, 64, 192, 2, 2)
+            RQ_SW_CASE(258, 256, 64, 4, 1)
+            RQ_SW_CASE(258, 256, 96, 4, 1)
+            RQ_SW_CASE(260, 256, 64, 4, 2)
+#undef RQ_SW_CASE
+#undef RQ_SW_GL
+#endif
             RQ_GL_CASE(128, 64, 2, 2)
             RQ_GL_CASE(128, 128, 2, 2)
             RQ_GL_CASE(256, 128, 4, 2)
@@ -379,6 +410,8 @@ extern "C" int rqamd_dbg_gemm_bf16(const void* A, const void* W, int M, int N, i
                                    void* out, int bm, int bn, int splitk, void* stream) {
     if (!A || !W || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_gemm: null argument");
     int flags = 0, glds = 0, accum = 0;
+    if (epi >= 8192) { flags |= 4; epi -= 8192; }             // epi + 8192: LDS-DMA kernels without fragment reads / MFMAs (ablation)
+    if (epi >= 4096) { flags |= 2; epi -= 4096; }             // epi + 4096: LDS-DMA kernels without operand staging (ablation)
     if (epi >= 2048) { accum = 1; epi -= 2048; }              // 4 + 2048: in-place residual accumulation (splitk 1)
     if (epi >= 1024) { flags |= 128; epi -= 1024; }           // epi + 1024: 256x256 kernel with four phases per K-tile (A/B)
     if (epi >= 512) { flags |= 64; epi -= 512; }              // epi + 512: 256x256 kernel with two phases per K-tile (A/B)

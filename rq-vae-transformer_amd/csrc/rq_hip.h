@@ -83,6 +83,13 @@ static __device__ __forceinline__ void rq_glds16(unsigned lds_base, const void* 
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// the same with the non-temporal policy (` nt`): for bytes that ONE compute unit reads once (a decode step's weight stream;
+// MI355X_MICROARCH.md, row nt-weights) -- not for operands that other workgroups re-read from the L2
+static __device__ __forceinline__ void rq_glds16_nt(unsigned lds_base, const void* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
 // Same DMA with the source as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit byte offset): the per-lane offset is
 // loop invariant and the K-tile advance is one scalar add on the base, so a staging instruction costs no VALU work at all.
 static __device__ __forceinline__ void rq_glds16_s(unsigned lds_base, const void* sbase, unsigned voff) {

@@ -155,6 +155,7 @@ static inline void rq_glds16(uintptr_t lds_base, const void* gsrc) {
         memcpy(dst, gsrc, 16);
     }
 }
+static inline void rq_glds16_nt(uintptr_t lds_base, const void* gsrc) { rq_glds16(lds_base, gsrc); }      // (cache policy: not modelled)
 static inline void rq_glds16_s(uintptr_t lds_base, const void* sbase, unsigned voff) { rq_glds16(lds_base, (const char*)sbase + voff); }
 template <int POL = 0>
 static inline void rq_glds16_s2(uintptr_t lds_base, const void* sbase, unsigned voff0, unsigned voff1) {

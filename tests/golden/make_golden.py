@@ -235,6 +235,66 @@ def gen_rqt():
              logits=logits)
 
 
+# ------------------------------------------------------------------ 4b. statistics of the reference's OWN sample()
+SAMPLE_STATS_N = 20000
+SAMPLE_STATS_COARSE = 25          # pairwise tables: codes bucketed by code // 25 (20 x 20 cells)
+
+
+def sample_stats_inputs(cfg, case, n=SAMPLE_STATS_N):
+    """(partial_sample, cond or None, start_loc) of one case -- shared with tests/test_gpu_sample_stats.py, which replays them on the GPU"""
+    H, W, D = cfg['block_size']
+    part = np.zeros((n, H, W, D), dtype=np.int64)
+    cond = (np.arange(n) % cfg['vocab_size_cond']).reshape(n, 1).astype(np.int64)
+    start = (0, 0)
+    if case == 'nocond':
+        cond = None
+    if case == 'start':
+        part[:, 0] = np.random.default_rng(77).integers(0, cfg['vocab_size'], (W, D))[None]      # one fixed first row for every sample
+        start = (1, 0)
+    return part, cond, start
+
+
+def sample_stats_counts(xs, cfg, start):
+    """code marginals of the first three sampled positions x all depths, and two coarse pairwise tables"""
+    H, W, D = cfg['block_size']
+    V, q = cfg['vocab_size'], SAMPLE_STATS_COARSE
+    flat = xs.reshape(xs.shape[0], H * W, D)
+    p0 = start[0] * W + start[1]
+    marg = np.stack([np.stack([np.bincount(flat[:, p0 + i, d], minlength=V) for d in range(D)]) for i in range(3)]).astype(np.int32)
+    nb = (V + q - 1) // q
+    def pair(a, b):
+        return np.bincount((a // q) * nb + (b // q), minlength=nb * nb).reshape(nb, nb).astype(np.int32)
+    return marg, pair(flat[:, p0, 0], flat[:, p0 + 1, 0]), pair(flat[:, p0, 0], flat[:, p0, 1])
+
+
+def gen_rqt_sample_stats():
+    """RQTransformer.sample of the REFERENCE (transformers.py:294-369: cached_forward + sample_from_logits + torch.multinomial), tiny
+    4 x 4 x 4 model, 20 000 images per case, full softmax (no top-k / top-p: a filter's boundary moves with bf16 rounding)."""
+    hps, dd = C.VAE_TINY
+    vae, _ = ref_rqvae(hps, dd, seed=31)
+    cfg = C.RQT_TINY
+    m, _ = ref_rqt(cfg, seed=41)
+    out = {}
+    for ci, case in enumerate(('cond', 'nocond', 'start')):
+        part, cond, start = sample_stats_inputs(cfg, case)
+        torch.manual_seed(9000 + ci)
+        xs = m.sample(torch.from_numpy(part), vae, cond=None if cond is None else torch.from_numpy(cond), start_loc=start,
+                      temperature=1.0, top_k=None, top_p=None, is_tqdm=False).numpy()
+        marg, p_sp, p_dp = sample_stats_counts(xs, cfg, start)
+        out[f'marg_{case}'], out[f'pair_spatial_{case}'], out[f'pair_depth_{case}'] = marg, p_sp, p_dp
+        # a second, independent reference run of the same case: its chi^2 against the first is what "agreement" looks like
+        torch.manual_seed(9100 + ci)
+        xs2 = m.sample(torch.from_numpy(part), vae, cond=None if cond is None else torch.from_numpy(cond), start_loc=start,
+                       temperature=1.0, top_k=None, top_p=None, is_tqdm=False).numpy()
+        marg2, _, _ = sample_stats_counts(xs2, cfg, start)
+        a, b = marg[0, 0].astype(np.float64), marg2[0, 0].astype(np.float64)
+        keep = (a + b) >= 10
+        print(f'  sample stats [{case}]: first position, depth 0: {int((marg[0, 0] > 0).sum())} of {cfg["vocab_size"]} codes drawn, '
+              f'most frequent {marg[0, 0].max()} / {SAMPLE_STATS_N}; reference vs reference chi^2 {((a - b)[keep] ** 2 / (a + b)[keep]).sum():.1f} '
+              f'on {int(keep.sum()) - 1} dof')
+    save('rqt_tiny_sample_stats.npz', n=SAMPLE_STATS_N, seed=41, vae_seed=31, coarse=SAMPLE_STATS_COARSE, **out)
+
+
 # ------------------------------------------------------------------ 5. RQ-Transformer at the benchmarked / released shapes
 class CodebookAux:
     """minimal model_aux: the reference only calls get_code_emb_with_depth on it (transformers.py:109-111)"""
@@ -394,11 +454,11 @@ def gen_param_counts():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'vae_batch', 'rqt', 'rqt_big', 'rqt_var', 'ema', 'counts']
+    which = sys.argv[1:] or ['rq', 'sampler', 'vae', 'vae_batch', 'rqt', 'rqt_sample', 'rqt_big', 'rqt_var', 'ema', 'counts']
     for w in which:
         print(f'[{w}]')
         if w.startswith('rqt_big:'):                      # e.g. rqt_big:txt32,txt64
             gen_rqt_big(w.split(':', 1)[1].split(','))
             continue
-        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'vae_batch': gen_vae_batch, 'rqt': gen_rqt, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
+        {'rq': gen_rq, 'sampler': gen_sampler, 'vae': gen_vae, 'vae_batch': gen_vae_batch, 'rqt': gen_rqt, 'rqt_sample': gen_rqt_sample_stats, 'rqt_big': gen_rqt_big, 'rqt_var': gen_rqt_variants,
          'ema': gen_ema, 'counts': gen_param_counts}[w]()
