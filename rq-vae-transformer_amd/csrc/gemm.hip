@@ -1,5 +1,6 @@
 // gemm.hip -- launcher / tile selection for the bf16 MFMA GEMM (see gemm.h)
 #include "gemm.h"
+#include <math.h>
 #include <stdlib.h>
 #include "rq_common.h"
 
@@ -229,6 +230,9 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
             RQ_SW_CASE(132, 128, 64, 4, 2)
             RQ_SW_CASE(132, 128, 128, 4, 2)
             RQ_SW_CASE(132, 128, 192, 4, 2)
+            RQ_SW_CASE(136, 128, 128, 4, 4)
+            RQ_SW_CASE(136, 128, 256, 4, 4)
+            RQ_SW_CASE(264, 256, 128, 4, 4)
             RQ_SW_CASE(64, 64, 128, 2, 2)
             RQ_SW_CASE(64, 64, 192, 2, 2)
             RQ_SW_CASE(258, 256, 64, 4, 1)
@@ -237,6 +241,16 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
 #undef RQ_SW_CASE
 #undef RQ_SW_GL
 #endif
+            // round 5: eight / sixteen wavefronts per tile, three stages (tile code = rows + 4: 4 x 2 wavefronts, + 8: 4 x 4)
+#define RQ_G3_CASE(CODE_, BM_, BN_, WM_, WN_)                                                                              \
+            if (bm == CODE_ && bn == BN_ && gl == 3)                                                                        \
+                return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 3>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 3>(a, stream);
+            RQ_G3_CASE(132, 128, 64, 4, 2)
+            RQ_G3_CASE(132, 128, 128, 4, 2)
+            RQ_G3_CASE(132, 128, 192, 4, 2)
+            RQ_G3_CASE(264, 256, 128, 4, 4)
+            RQ_G3_CASE(136, 128, 256, 4, 4)
+#undef RQ_G3_CASE
             RQ_GL_CASE(128, 64, 2, 2)
             RQ_GL_CASE(128, 128, 2, 2)
             RQ_GL_CASE(256, 128, 4, 2)
@@ -311,6 +325,49 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     if (skinny && !allow_splitk && (long)M_rows * g_rq_row_scale <= 32 && K % 512 == 0 && N >= 256 && N < 16384) {
         *bm = 64; *bn = 32; *splitk = 1;
         return;
+    }
+    // 129 .. 2047 rows (round 5; the reference's own metric batches 200 / 500 are here): eight- and sixteen-wavefront tiles of the
+    // LDS-DMA kernel -- tile codes 132 x {64, 128, 192} = 128 rows as 4 x 2 wavefronts, 264 x 128 = 256 rows and 136 x 256 = 128 rows
+    // as 4 x 4 -- three ring stages.  What the sweep showed (profiles/r05_gemm_mid_sweep*.txt, in-graph, weights from HBM): at these row
+    // counts a launch is bound by how fast a CU takes its operands in, not by MFMAs (the loop without MFMAs takes as long as the whole
+    // kernel; ~70 GB/s per CU and ~11 TB/s over the chip, whatever the ring depth or the wavefront count), the four-wavefront tiles
+    // lose to their own fragment-read latency (one wavefront per SIMD: 23 us of compute where eight wavefronts take 14), and an XCD
+    // that is dealt more than 32 workgroups runs a second round while others idle.  So: among the tiles and K splits, take the one
+    // with the smallest modelled time  c0 + max(stream, mma) + 0.4 min(stream, mma) + epilogue (+ the consumer's slab reads), with
+    // stream = max(rounds x bytes per workgroup / 110 GB/s, all bytes / 17 TB/s), mma at 5 TFLOP/s per CU, rounds counted per XCD
+    // (constants fitted to 370 measured (shape, tile, split) points, rms error 8 %; the pick is within 2 % of the measured best on
+    // the 50 shapes of the sweep at E = 1024 / 1536 / 2560, 200 .. 1536 rows: 1599 -> 1334 us summed, best possible 1291).
+    static const bool no_mid = getenv("RQAMD_NO_MID") != nullptr;        // A/B switch: the round-1..4 tile rules below
+    if (glds && !no_glds && !no_mid && M > 128 && M < 2048 && K % 64 == 0 && N >= 64) {
+        const bool wide_f32 = !allow_splitk && N >= 8192;                  // classifier: fp32 rows
+        if (wide_f32 && M > 256) {
+            // (measured: 128 x 256 sixteen-wavefront tiles 30.8 us at 300 rows against 36.2 for 128 x 128, 56.5 at 768; from 1024 rows
+            // the 256 x 128 three-stage tile of round 1 is level or ahead and stays)
+            if (M < 1024) { *bm = 136; *bn = 256; *splitk = 1; *glds = 3; return; }
+        } else {
+            static const int cand[5][3] = {{132, 128, 64}, {132, 128, 128}, {132, 128, 192}, {264, 256, 128}, {136, 128, 256}};
+            static const int sks[6] = {1, 2, 3, 4, 6, 8};
+            const int kt = K / 64;
+            double best = 1e30;
+            for (const auto& c : cand) {
+                const int BM = c[1], BN = c[2];
+                const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
+                for (int si = 0; si < (allow_splitk ? 6 : 1); ++si) {
+                    const int sk = sks[si];
+                    if (kt % sk != 0 || (sk > 1 && kt / sk < 4)) continue;
+                    const double W = (double)MT * NT * sk;
+                    const double bw = (double)(BM + BN) * 128.0 * (kt / sk);
+                    const int wx = NT >= 8 ? ((NT + 7) / 8) * MT * sk : ((MT + 7) / 8) * NT * sk;      // workgroups of the busiest XCD
+                    const int rounds = (wx + 31) / 32;
+                    const double ts = fmax(rounds * bw / 110e3, W * bw / 17e6);
+                    const double tm = rounds * 2.0 * BM * BN * (double)K / sk / 5e6;
+                    double t = 2.0 + fmax(ts, tm) + 0.4 * fmin(ts, tm) + 2.5 + (double)BM * BN * (allow_splitk || wide_f32 ? 4 : 2) / 32e3;
+                    if (allow_splitk && sk > 1) t += 0.3 * sk * M / 500.0;             // sk fp32 slabs read again by the LayerNorm that follows
+                    if (t < best) { best = t; *bm = c[0]; *bn = BN; *splitk = sk; }
+                }
+            }
+            if (best < 1e29) { *glds = 3; return; }
+        }
     }
     // 256 x 256 kernel (gemm_p8_kernel): one workgroup per CU, so what decides is how the tile count fills rounds of 256 CUs.  A
     // small cost model fitted to the interleaved A/B runs on MI355X (profiles/r02_gemm_p8_ab.txt, r02_gemm_p8_picker.txt; within

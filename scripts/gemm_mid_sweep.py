@@ -5,7 +5,7 @@ captured graph (what a launch costs in the sampler), rotating weights (> 400 MB 
 
   RQ_LIB=rq-vae-transformer_amd/variants/librqamd_sweep.so RQ_MS=200,500 python scripts/gemm_mid_sweep.py
 
-Tile code = BM + wave layout (0: 2 x 2 wavefronts, 1: 4 x 1, 4: 4 x 2), `g<stages>`; `r` = register-staged (the shipped kernels
+Tile code = BM + wave layout (0: 2 x 2 wavefronts, 1: 4 x 1, 4: 4 x 2, 8: 4 x 4), `g<stages>`; `r` = register-staged (the shipped kernels
 below 512 rows).  Ablations of the best variants: `-dma` = no operand staging (MFMAs + fragment reads + barriers only), `-mma` =
 staging, waits and barriers only."""
 import os
@@ -27,8 +27,14 @@ REPS = 48
 # (code, bn, BM, stages list)
 TILES = [(128, 64, 128, (3, 6)), (128, 128, 128, (3, 5)), (129, 64, 128, (3, 6)), (129, 96, 128, (3, 5)), (129, 128, 128, (3, 5)),
          (129, 160, 128, (3, 4)), (129, 192, 128, (3, 4)), (132, 64, 128, (3, 6)), (132, 128, 128, (3, 5)), (132, 192, 128, (3, 4)),
-         (64, 128, 64, (3, 6)), (64, 192, 64, (3, 5)), (258, 64, 256, (3, 4)), (258, 96, 256, (3,)), (260, 64, 256, (3, 4))]
+         (64, 128, 64, (3, 6)), (64, 192, 64, (3, 5)), (258, 64, 256, (3, 4)), (258, 96, 256, (3,)), (260, 64, 256, (3, 4)),
+         (136, 128, 128, (2, 3, 5)), (136, 256, 128, (2, 3)), (264, 128, 256, (2, 3))]
+if os.environ.get('RQ_TILES'):          # e.g. RQ_TILES=129x128,132x128,136x128: only these tile codes
+    keep = set(os.environ['RQ_TILES'].split(','))
+    TILES = [t for t in TILES if f'{t[0]}x{t[1]}' in keep]
 REG = [(64, 64), (128, 64), (64, 128), (128, 128)]
+if os.environ.get('RQ_TILES'):
+    REG = [t for t in REG if f'{t[0]}x{t[1]}r' in os.environ['RQ_TILES'].split(',')]
 
 
 def graph_time(fn):
@@ -116,7 +122,7 @@ for M in [int(x) for x in os.environ.get('RQ_MS', '200,500').split(',')]:
         print('     ' + '  '.join(f'{tag}:{t:.1f}' for t, tag, *_ in results[:14]), flush=True)
         # ablations of the three best LDS-DMA variants
         abl = []
-        for t, tag, bm, bn, sk, ecode, accum in [r for r in results if 'g' in r[1] and not r[6]][:3]:
+        for t, tag, bm, bn, sk, ecode, accum in [r for r in results if 'g' in r[1] and not r[6]][:int(os.environ.get('RQ_NABL', 3))]:
             out = _native.dbg_gemm(a, ws[0], b, ecode, bm, bn, sk)
             t1 = graph_time(lambda i: _native.dbg_gemm(a, ws[i % nrot], b, ecode + 4096, bm, bn, sk, out=out))
             t2 = graph_time(lambda i: _native.dbg_gemm(a, ws[i % nrot], b, ecode + 8192, bm, bn, sk, out=out))

@@ -640,7 +640,46 @@ def test_emu_gemm_256x256_eight_phase(nat):
             a[:, :64].contiguous(), w[:, :64].contiguous(), bias, epi=3, bm=256, bn=256, splitk=1)   # a single K-tile is refused
 
 
-@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream'])
+def test_emu_gemm_mid_batch_tiles(nat):
+    """Round 5: the eight- / sixteen-wavefront LDS-DMA tiles of the 129 .. 2047 row decode step (tile codes 132 x {64, 128, 192},
+    264 x 128, 136 x 256; three ring stages): every epilogue family incl. K splits and the in-place residual update, ragged M / N,
+    and the engine's own choice (bm = bn = 0) for row counts in that range -- vs fp32 matmul, and auto == the explicit launch."""
+    rng = np.random.default_rng(29)
+    for (M, N, K) in ((200, 200, 448), (300, 132, 640)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
+        scale = np.abs(ref).max()
+        for (bm, bn) in ((132, 64), (132, 128), (132, 192), (264, 128), (136, 256)):
+            out = nat.dbg_gemm(a, w, bias, epi=3 + 96, bm=bm, bn=bn, splitk=1).numpy()
+            assert np.abs(out - ref).max() < 2e-3 * scale, (M, N, K, bm, bn)
+            out = nat.dbg_gemm(a, w, bias, epi=0 + 96, bm=bm, bn=bn, splitk=1).float().numpy()
+            assert np.abs(out - ref).max() < 1e-2 * scale, (M, N, K, bm, bn)
+            out = nat.dbg_gemm(a, w, None, epi=4 + 96, bm=bm, bn=bn, splitk=K // 64 // 2 if K == 448 else 2).numpy().sum(0)
+            assert np.abs(out - (ref - bias.numpy())).max() < 2e-3 * scale, (M, N, K, bm, bn)
+            x0 = T(rng.standard_normal((M, N)).astype(np.float32))
+            xs = x0.clone()
+            nat.dbg_gemm(a, w, bias, epi=4 + 96 + 2048, bm=bm, bn=bn, splitk=1, out=xs)
+            slab = nat.dbg_gemm(a, w, None, epi=4 + 96, bm=bm, bn=bn, splitk=1)[0]
+            assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm, bn)
+    # the engine's own tile choice in the mid range: a slab GEMM (K split allowed), a bf16 GEMM and wide fp32 rows
+    for (M, N, K, epi) in ((200, 256, 1024, 4), (500, 384, 256, 0), (300, 8192, 128, 3)):
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+        w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+        bias = T(rng.standard_normal(N).astype(np.float32))
+        ref = a.float().numpy() @ w.float().numpy().T + (0 if epi == 4 else bias.numpy())
+        out = nat.dbg_gemm(a, w, None if epi == 4 else bias, epi=epi, bm=0, bn=0, splitk=0)
+        got = out.float().numpy()
+        if epi == 4:
+            # (the diagnostics entry sizes the slab buffer for 8 splits and the picker may use fewer: sum the written ones)
+            full = torch.zeros((8, M, N))
+            nat.dbg_gemm(a, w, None, epi=epi, bm=0, bn=0, splitk=0, out=full)
+            got = full.numpy().sum(0)
+        assert np.abs(got - ref).max() < (1e-2 if epi == 0 else 2e-3) * np.abs(ref).max(), (M, N, K, epi)
+
+
+@pytest.mark.parametrize('which', ['tiles', 'eight_phase', 'stream', 'mid'])
 def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
     """The LDS-DMA GEMMs again with RQ_EMU_DMA=late: a DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it --
     the latest moment the hardware allows -- so a fragment read that is not ordered behind the covering wait (+ a barrier for other
@@ -651,6 +690,8 @@ def test_emu_gemm_lds_dma_lands_late(nat, monkeypatch, which):
         test_emu_gemm_tiles_and_lds_dma(nat)
     elif which == 'eight_phase':
         test_emu_gemm_256x256_eight_phase(nat)
+    elif which == 'mid':
+        test_emu_gemm_mid_batch_tiles(nat)
     else:
         test_emu_gemm_stream(nat)
 
