@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 4
+#define RQAMD_ABI_VERSION 5
 
 typedef enum {
     RQAMD_OK = 0,
@@ -58,6 +58,11 @@ int rqamd_rq_quantize(const float* x, const float* const* codebooks, const float
 int rqamd_rq_soft_codes(const float* x, const float* const* codebooks, const float* const* code_norms, const int* n_embed,
                         int depth, int64_t n_vec, int dim, float temp, int stochastic, uint64_t seed, uint64_t offset,
                         float* soft_out, int64_t* codes, void* workspace, int64_t workspace_bytes, void* stream);
+/* rqamd_rq_distances <- VQEmbedding.compute_distances (quantizations.py:43-62) on its own: dist_out[v][k] =
+ * ||x_v||^2 + ||c_k||^2 - 2 x_v . c_k  (n_vec, n_embed) fp32, the values the quantiser's argmin and the soft codes are formed
+ * from (same kernel, same summation order), for ONE codebook.  workspace: n_vec * 64 * 8 bytes of device scratch.  (ABI v5) */
+int rqamd_rq_distances(const float* x, const float* codebook, const float* code_norms, int n_embed, int64_t n_vec, int dim,
+                       float* dist_out, void* workspace, int64_t workspace_bytes, void* stream);
 /* rqamd_rq_code_norms <- the codebook_t.pow(2).sum(0) term of compute_distances (quantizations.py:51-52). */
 int rqamd_rq_code_norms(const float* codebook, int n_embed, int dim, float* norms_out, void* stream);
 

@@ -78,6 +78,12 @@ RQT_TINY_NOCUMSUM = _variant(RQT_TINY, cumsum_depth_ctx=False)
 # codebook embeddings into the body, one shared learned embedding into the head
 RQT_TINY_MIXED = _variant(RQT_TINY, head_emb_vqvae=False)
 
+# bias-free attention / MLP layers (AttentionBlockConfig.attn_bias / mlp_bias = False, configs.py:21-40, attentions.py:48-55,117-122):
+# mixed on purpose -- the body without attention biases, the head without MLP biases
+RQT_TINY_NOBIAS = _variant(RQT_TINY)
+RQT_TINY_NOBIAS['body']['block']['attn_bias'] = False
+RQT_TINY_NOBIAS['head']['block']['mlp_bias'] = False
+
 PARAM_COUNTS_M = {  # BASELINE.md §2 / reference README.md:38-47
     'RQT_FFHQ_355M': 355.4, 'RQT_IN_480M': 480.9, 'RQT_IN_821M': 820.9,
     'RQT_IN_1400M': 1387.5, 'RQT_IN_3800M': 3822.5, 'RQT_CC3M_654M': 654.1,

@@ -87,7 +87,7 @@ class RQTransformerOracle:
         hs = C // n_head
 
         def proj(n):
-            return linear(x, p[f'{pre}.attn.{n}.weight'], p[f'{pre}.attn.{n}.bias']) \
+            return linear(x, p[f'{pre}.attn.{n}.weight'], p.get(f'{pre}.attn.{n}.bias')) \
                 .reshape(B, T, n_head, hs).transpose(0, 2, 1, 3)
         k, q, v = proj('key'), proj('query'), proj('value')
         Tp = 0
@@ -100,7 +100,7 @@ class RQTransformerOracle:
         att = np.where(mask[None, None], att, -np.inf)
         att = _softmax(att).astype(np.float32)
         y = (att @ v).transpose(0, 2, 1, 3).reshape(B, T, C)
-        y = linear(y, p[f'{pre}.attn.proj.weight'], p[f'{pre}.attn.proj.bias'])
+        y = linear(y, p[f'{pre}.attn.proj.weight'], p.get(f'{pre}.attn.proj.bias'))
         return (y, (k, v)) if caching else y
 
     def _block(self, pre, x, n_head, past=None, caching=False):
@@ -113,8 +113,8 @@ class RQTransformerOracle:
             a, present = self._attn(pre, h, n_head), None
         x = x + a
         h = layer_norm(x, p[f'{pre}.ln2.weight'], p[f'{pre}.ln2.bias'])
-        h = gelu(linear(h, p[f'{pre}.mlp.0.weight'], p[f'{pre}.mlp.0.bias']), self.gelu)
-        x = x + linear(h, p[f'{pre}.mlp.2.weight'], p[f'{pre}.mlp.2.bias'])
+        h = gelu(linear(h, p[f'{pre}.mlp.0.weight'], p.get(f'{pre}.mlp.0.bias')), self.gelu)
+        x = x + linear(h, p[f'{pre}.mlp.2.weight'], p.get(f'{pre}.mlp.2.bias'))
         return x, present
 
     def _stack(self, name, x, n_layer, n_head):

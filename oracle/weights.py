@@ -145,19 +145,24 @@ def rqt_param_shapes(cfg):
         else:
             d['tok_emb.weight'] = (sum(vs), E)
             d['tok_emb.offsets'] = (D,)              # registered buffer of TupleEmbedding (primitives.py:60-61)
-    for stack, nl in (('body_transformer', cfg['body']['n_layer']),
-                      ('head_transformer', cfg['head']['n_layer'])):
+    for stack, key in (('body_transformer', 'body'), ('head_transformer', 'head')):
+        nl = cfg[key]['n_layer']
+        attn_bias = cfg[key].get('block', {}).get('attn_bias', True)      # nn.Linear(..., bias=config.attn_bias), attentions.py:48-55
+        mlp_bias = cfg[key].get('block', {}).get('mlp_bias', True)        # attentions.py:117-122
         for i in range(nl):
             p = f'{stack}.blocks.{i}'
             _norm(d, p + '.ln1', E)
             _norm(d, p + '.ln2', E)
             for n in ('key', 'query', 'value', 'proj'):
                 d[f'{p}.attn.{n}.weight'] = (E, E)
-                d[f'{p}.attn.{n}.bias'] = (E,)
+                if attn_bias:
+                    d[f'{p}.attn.{n}.bias'] = (E,)
             d[f'{p}.mlp.0.weight'] = (4 * E, E)
-            d[f'{p}.mlp.0.bias'] = (4 * E,)
+            if mlp_bias:
+                d[f'{p}.mlp.0.bias'] = (4 * E,)
             d[f'{p}.mlp.2.weight'] = (E, 4 * E)
-            d[f'{p}.mlp.2.bias'] = (E,)
+            if mlp_bias:
+                d[f'{p}.mlp.2.bias'] = (E,)
     _norm(d, 'classifier.layer_norm', E)
     if cfg.get('shared_cls_emb', True):
         d['classifier.linear.weight'] = (vs[0], E)

@@ -479,6 +479,37 @@ extern "C" int rqamd_rq_soft_codes(const float* x, const float* const* codebooks
     return RQAMD_OK;
 }
 
+// VQEmbedding.compute_distances (quantizations.py:43-62) as a stand-alone call: the split-mode kernel's logit output with
+// inv_temp = -1 is the distance itself (-d * -1, exact); the partial minima it also writes go to the workspace and are not used.
+extern "C" int rqamd_rq_distances(const float* x, const float* codebook, const float* code_norms, int n_embed, int64_t n_vec, int dim,
+                                  float* dist_out, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_vec == 0) return RQAMD_OK;
+    if (!x || !codebook || !code_norms || !dist_out || !workspace) return rq_fail(RQAMD_ERR_INVALID, "rq_distances: null argument");
+    if (dim % 64 != 0 || dim < 64 || dim > 256) return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_distances: dim %d must be 64, 128, 192 or 256", dim);
+    if (n_embed < 1) return rq_fail(RQAMD_ERR_INVALID, "rq_distances: empty codebook");
+    const long ntiles = (n_vec + QT_M - 1) / QT_M;
+    const int tiles_k = (n_embed + QT_N - 1) / QT_N;
+    int S = (int)(512 / ntiles);
+    S = S < 1 ? 1 : (S > 64 ? 64 : S);
+    S = S > tiles_k ? tiles_k : S;
+    const size_t need = (size_t)n_vec * 64 * 8;
+    if ((size_t)workspace_bytes < need) return rq_fail(RQAMD_ERR_INVALID, "rq_distances: workspace of %zu bytes needed", need);
+    RqQuantArgs a{};
+    a.cb[0] = codebook; a.K[0] = n_embed; a.cn[0] = code_norms;
+    a.depth = 1; a.dim = dim; a.n_vec = n_vec; a.codes = nullptr; a.quant_cum = nullptr; a.x = x; a.dep = 0;
+    a.part_v = (float*)workspace;
+    a.part_i = (int*)(a.part_v + (size_t)n_vec * 64);
+    a.logit_out = dist_out;
+    a.inv_temp = -1.0f;
+    a.tiles_per_split = (tiles_k + S - 1) / S;
+    a.n_split = (tiles_k + a.tiles_per_split - 1) / a.tiles_per_split;
+    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float) + (4 * QT_M + QT_M) * sizeof(int);
+    static RqDeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, (hipStream_t)stream, a);
+    return rq_check_launch("rq_quantize_kernel<split>");
+}
+
 extern "C" int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,
                               int64_t n_vec, int dim, int mode, float* out, void* stream) {
     if (n_vec == 0) return RQAMD_OK;

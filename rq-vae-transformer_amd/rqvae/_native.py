@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class RqamdError(RuntimeError):
@@ -48,6 +48,7 @@ _SIGS = {
     'rqamd_rq_soft_codes': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int64,
                                       C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p]),
+    'rqamd_rq_distances': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'rqamd_rq_ema_accumulate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_rq_ema_update': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     'rqamd_rq_ema_normalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
@@ -235,6 +236,19 @@ def rq_soft_codes(x, codebooks, norms, temp=1.0, stochastic=False, seed=0, offse
                                         int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(soft), ptr(codes), ptr(ws), ws.numel(),
                                         stream_of(x)))
     return soft, codes
+
+
+def rq_distances(x, codebook, norms):
+    """x (n_vec, dim) fp32, codebook (K, dim) fp32 -> (n_vec, K) fp32 squared distances ||x||^2 + ||c||^2 - 2 x.c:
+    VQEmbedding.compute_distances (quantizations.py:43-62), the values the quantiser's argmin is taken over."""
+    n_vec, dim = x.shape
+    K = codebook.shape[0]
+    out = torch.empty((n_vec, K), dtype=torch.float32, device=x.device)
+    ws = torch.empty((max(n_vec, 1) * 512,), dtype=torch.uint8, device=x.device)
+    with on_device_of(x):
+        check(lib().rqamd_rq_distances(ptr(x, torch.float32), ptr(codebook, torch.float32), ptr(norms, torch.float32), K, n_vec, dim,
+                                       ptr(out), ptr(ws), ws.numel(), stream_of(x)))
+    return out
 
 
 def rq_ema_accumulate(x, idx, n_embed):

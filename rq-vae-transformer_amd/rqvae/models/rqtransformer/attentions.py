@@ -34,14 +34,15 @@ class AttentionBlock(_Holder):
     def __init__(self, block_cfg):
         super().__init__()
         E = block_cfg['embed_dim']
-        if not (block_cfg.get('attn_bias', True) and block_cfg.get('mlp_bias', True)):
-            raise NotImplementedError('bias-free attention / MLP')
+        # attn_bias / mlp_bias = False (configs.py:21-40): the Linear layers carry no bias parameter, as in the reference; the engine is
+        # handed zero vectors for them (RQTransformer._eng), which adds nothing
+        attn_bias, mlp_bias = bool(block_cfg.get('attn_bias', True)), bool(block_cfg.get('mlp_bias', True))
         self.ln1 = nn.LayerNorm(E)
         self.ln2 = nn.LayerNorm(E)
-        self.attn = MultiSelfAttention(E, block_cfg['n_head'], True, block_cfg.get('attn_pdrop', 0.0),
+        self.attn = MultiSelfAttention(E, block_cfg['n_head'], attn_bias, block_cfg.get('attn_pdrop', 0.0),
                                        block_cfg.get('resid_pdrop', 0.1), mask=True)
-        self.mlp = nn.Sequential(nn.Linear(E, 4 * E, bias=True), GELU(block_cfg.get('gelu', 'v1')),
-                                 nn.Linear(4 * E, E, bias=True), nn.Dropout(block_cfg.get('resid_pdrop', 0.1), inplace=True))
+        self.mlp = nn.Sequential(nn.Linear(E, 4 * E, bias=mlp_bias), GELU(block_cfg.get('gelu', 'v1')),
+                                 nn.Linear(4 * E, E, bias=mlp_bias), nn.Dropout(block_cfg.get('resid_pdrop', 0.1), inplace=True))
         self._cache = None
 
 

@@ -119,6 +119,14 @@ class RQTransformer(Stage2Model):
                     shared_tok_emb=c.shared_tok_emb, shared_cls_emb=c.shared_cls_emb, cumsum_depth_ctx=c.cumsum_depth_ctx,
                     vocab_sizes=self.vocab_size)
             push_all(self, self._engine)
+            # bias-free layers (attn_bias / mlp_bias = False): the engine's epilogues always add a bias vector -- zeros here
+            dev = self.pos_emb_hw.device
+            for prefix, stack in (('body_transformer', self.body_transformer), ('head_transformer', self.head_transformer)):
+                for i, blk in enumerate(stack.blocks):
+                    for leaf, lin in (('attn.query', blk.attn.query), ('attn.key', blk.attn.key), ('attn.value', blk.attn.value),
+                                      ('attn.proj', blk.attn.proj), ('mlp.0', blk.mlp[0]), ('mlp.2', blk.mlp[2])):
+                        if lin.bias is None:
+                            self._engine.set_param(f'{prefix}.blocks.{i}.{leaf}.bias', torch.zeros(lin.out_features, device=dev))
             self._engine_sig = sig
         return self._engine
 
@@ -156,8 +164,48 @@ class RQTransformer(Stage2Model):
 
     # ------------------------------------------------------------------ reference API
     def init_cache(self):
-        """transformers.py:289-292 -- caches are engine-side and reset by every sample()/forward()."""
+        """transformers.py:289-292 -- caches are engine-side and reset by every sample()/forward(); a cached_forward sequence in
+        progress ends here."""
         self._cache = {'spatial_ctx_hw': None}
+        self._cf = None
+
+    @torch.no_grad()
+    def cached_forward(self, xs, model_aux=None, cond=None, amp=False, sample_loc=(0, 0, 0)):
+        """transformers.py:190-287: logits (B, vocab_size) fp32 of ONE step (h, w, d) from the KV caches of the steps before it, over
+        the engine's stepping entry points (rqamd_rqt_step_begin / _step_logits / _step_set_code: the arithmetic of sample()).  As in
+        the reference the calls of a sequence come in sampling order after init_cache(): a call with d == 0 that does not continue
+        the previous call starts a sequence -- the codes of the positions before (h, w) are taken from `xs` and only feed the body
+        stack's KV cache (the start_loc > (0, 0) prefill, :235-239) -- and a call with d > 0 must follow (h, w, d - 1).  `xs` holds
+        the codes drawn so far, (B, h + 1 .. H, W, D) as sample() passes them (:349); the codes of the step before are read from it
+        at every call, so a caller may write them in place like sample() does (:364).  The returned tensor is the caller's own."""
+        (h, w, d) = (int(v) for v in sample_loc)
+        (B, Hx, W, D) = xs.shape
+        (H, W_, D_) = self.block_size
+        assert (W, D) == (W_, D_) and h < Hx <= H and 0 <= w < W and 0 <= d < D
+        pos = h * W + w
+        eng = self._eng()
+        st = getattr(self, '_cf', None)
+        if st is None or st['next'] != (pos, d) or st['B'] != B:
+            if d != 0:
+                raise RuntimeError(f'cached_forward(sample_loc={tuple(sample_loc)}): depth {d} must follow depth {d - 1} of the same position '
+                                   '(the head stack attends its cached depths; call init_cache() and step in sampling order)')
+            cbs = self._checked_codebooks(model_aux)
+            full = torch.zeros((B, H, W, D), dtype=torch.long, device=xs.device)
+            full[:, :Hx] = xs
+            c = self._cond(cond, B, xs.device)
+            if c is None:
+                c = torch.zeros((B, self.block_size_cond), dtype=torch.long, device=xs.device)
+            eng.step_begin(full.contiguous(), c, cbs)
+            for p in range(pos):
+                eng.step_logits(p, -1)                 # given codes: body KV cache only
+        elif d > 0:
+            eng.step_set_code(pos, d - 1, xs[:, h, w, d - 1].to(torch.long).contiguous())
+        elif pos > 0:
+            hp, wp = divmod(pos - 1, W)
+            eng.step_set_code(pos - 1, D - 1, xs[:, hp, wp, D - 1].to(torch.long).contiguous())
+        logits = eng.step_logits(pos, d).clone()
+        self._cf = {'next': (pos, d + 1) if d + 1 < D else (pos + 1, 0), 'B': B}
+        return logits
 
     def embed_with_model_aux(self, xs, model_aux):
         xs_emb, _ = model_aux.get_code_emb_with_depth(xs)
@@ -168,6 +216,7 @@ class RQTransformer(Stage2Model):
         """transformers.py:113-188: teacher-forced logits (B,H,W,D,V) fp32, computed by stepping the
         engine's cached path over the given codes (identical to the uncached pass up to rounding --
         the reference's own cached==uncached invariant, transformers.py:352-356)."""
+        self._cf = None                                  # (any other engine call ends a cached_forward sequence)
         if self.block_size_cond > 1:
             # (seq_logits, cond_logits): cond_classifier over the body outputs of the first cond_len-1 positions
             # (transformers.py:150-153,185-186); the engine takes them from the multi-token prefill of the prefix
@@ -187,6 +236,7 @@ class RQTransformer(Stage2Model):
         """seq_logits of forward() (transformers.py:113-188) for any block_size_cond, via the engine's cached path."""
         (B, H, W, D) = xs.shape
         assert torch.Size([H, W, D]) == self.block_size
+        self._cf = None
         eng = self._eng()
         cbs = self._checked_codebooks(model_aux)
         codes = xs.to(torch.long).contiguous()
@@ -198,6 +248,7 @@ class RQTransformer(Stage2Model):
                amp=False, cached=True, is_tqdm=False, desc="Sampling", fast=True):
         """transformers.py:294-369"""
         assert self.block_size == partial_sample.shape[1:]
+        self._cf = None
         (H, W, D) = self.block_size
         if top_k is None:
             top_k_list = [self.vocab_size[i] for i in range(D)]

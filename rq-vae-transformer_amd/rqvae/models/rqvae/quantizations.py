@@ -56,6 +56,17 @@ class VQEmbedding(nn.Embedding):
         return super()._apply(fn, *args, **kwargs)
 
     @torch.no_grad()
+    def compute_distances(self, inputs):
+        """quantizations.py:43-62: squared L2 distances of every input vector to every code, (*inputs.shape[:-1], n_embed) fp32 in the
+        reference's expanded form ||x||^2 + ||c||^2 - 2 x.c -- the same kernel, summation order and values that
+        find_nearest_embedding takes its argmin over (csrc/quantize.hip: rqamd_rq_distances)."""
+        shape = inputs.shape
+        assert shape[-1] == self.weight.shape[1]
+        x = inputs.detach().reshape(-1, shape[-1]).to(torch.float32).contiguous()
+        dist = _native.rq_distances(x, self.codebook(), self.code_norms())
+        return dist.reshape(*shape[:-1], self.n_embed)
+
+    @torch.no_grad()
     def find_nearest_embedding(self, inputs):
         """quantizations.py:64-69"""
         shape = inputs.shape

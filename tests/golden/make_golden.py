@@ -21,6 +21,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 
 _m = types.ModuleType('omegaconf')
 _m.OmegaConf = type('OmegaConf', (), {})
@@ -236,35 +237,7 @@ def gen_rqt():
 
 
 # ------------------------------------------------------------------ 4b. statistics of the reference's OWN sample()
-SAMPLE_STATS_N = 20000
-SAMPLE_STATS_COARSE = 25          # pairwise tables: codes bucketed by code // 25 (20 x 20 cells)
-
-
-def sample_stats_inputs(cfg, case, n=SAMPLE_STATS_N):
-    """(partial_sample, cond or None, start_loc) of one case -- shared with tests/test_gpu_sample_stats.py, which replays them on the GPU"""
-    H, W, D = cfg['block_size']
-    part = np.zeros((n, H, W, D), dtype=np.int64)
-    cond = (np.arange(n) % cfg['vocab_size_cond']).reshape(n, 1).astype(np.int64)
-    start = (0, 0)
-    if case == 'nocond':
-        cond = None
-    if case == 'start':
-        part[:, 0] = np.random.default_rng(77).integers(0, cfg['vocab_size'], (W, D))[None]      # one fixed first row for every sample
-        start = (1, 0)
-    return part, cond, start
-
-
-def sample_stats_counts(xs, cfg, start):
-    """code marginals of the first three sampled positions x all depths, and two coarse pairwise tables"""
-    H, W, D = cfg['block_size']
-    V, q = cfg['vocab_size'], SAMPLE_STATS_COARSE
-    flat = xs.reshape(xs.shape[0], H * W, D)
-    p0 = start[0] * W + start[1]
-    marg = np.stack([np.stack([np.bincount(flat[:, p0 + i, d], minlength=V) for d in range(D)]) for i in range(3)]).astype(np.int32)
-    nb = (V + q - 1) // q
-    def pair(a, b):
-        return np.bincount((a // q) * nb + (b // q), minlength=nb * nb).reshape(nb, nb).astype(np.int32)
-    return marg, pair(flat[:, p0, 0], flat[:, p0 + 1, 0]), pair(flat[:, p0, 0], flat[:, p0, 1])
+from sample_stats import SAMPLE_STATS_N, SAMPLE_STATS_COARSE, sample_stats_inputs, sample_stats_counts  # noqa: E402  (tests/golden/sample_stats.py)
 
 
 def gen_rqt_sample_stats():
@@ -358,11 +331,12 @@ def gen_rqt_big(only=None):
 
 def gen_rqt_variants():
     """Stage-2 flag variants that no released config uses (TupleEmbedding / BatchLinear / LogitMask, primitives.py:25-165;
-    cumsum_depth_ctx off; shared learned head embedding): reference forward() logits on the tiny shape."""
+    cumsum_depth_ctx off; shared learned head embedding; round 5: bias-free attention / MLP layers, configs.py:21-40): reference
+    forward() logits on the tiny shape."""
     hps, dd = C.VAE_TINY
     vae, vparams = ref_rqvae(hps, dd, seed=31)
     cb = vparams['quantizer.codebooks.0.weight'][:-1]
-    for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED)):
+    for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED), ('nobias', C.RQT_TINY_NOBIAS)):
         m, params = ref_rqt(cfg, seed=47)
         H, W, D = cfg['block_size']
         vs = cfg['vocab_size'] if isinstance(cfg['vocab_size'], list) else [cfg['vocab_size']] * D

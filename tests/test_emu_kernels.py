@@ -318,14 +318,14 @@ def test_emu_rqt_long_prefix(nat):
     assert e1 < 0.06 and e2 < 0.06
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias'])
 def test_emu_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding + BatchLinear + per-depth vocabularies; cumsum_depth_ctx off; learned head
     embedding) through the mirror classes and the engine, against the reference's forward() logits."""
     from rqvae.models.rqtransformer import RQTransformer
     from rqvae.models.rqvae import RQVAE
     g = golden(f'rqt_var_{tag}.npz')
-    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED}[tag]
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS}[tag]
     hps, dd = C.VAE_TINY
     vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
     vae.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed'])).items()})
@@ -337,6 +337,12 @@ def test_emu_rqt_flag_variants(nat, golden, tag):
     print(f'emu rqt variant {tag}: max err {err.max():.4f} mean {err.mean():.5f}')
     assert err.max() < 0.06 and err.mean() < 0.01
     if tag == 'tuple':          # (the GPU test samples all three variants)
+        # TupleEmbedding.forward on its own (primitives.py:63-75 of the reference) through the library's gather: row code + offset_d
+        emb = ar.tok_emb(codes)
+        assert emb.shape == codes.shape + (ar.tok_emb.embedding_dim,)
+        assert torch.equal(emb, ar.tok_emb.weight.detach()[codes + ar.tok_emb.offsets.view(1, 1, 1, -1)])
+        with pytest.raises(RuntimeError):
+            ar.classifier.linear(torch.zeros(1, 4, 128))
         ar.use_graph = False
         out = ar.sample(torch.zeros_like(codes), None, cond=cond, top_k=50, top_p=0.9)
         vs = ar.vocab_size

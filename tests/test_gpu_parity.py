@@ -46,6 +46,32 @@ def test_rq_quantize_golden_small(nat, golden):
     np.testing.assert_array_equal(N(nat.rq_embed(codes, [cb] * 4, 1)).reshape(g['embed_with_depth'].shape), g['embed_with_depth'])
 
 
+def test_vq_compute_distances(nat, golden):
+    """VQEmbedding.compute_distances (quantizations.py:43-62) as a public method: (..., n_embed) squared distances
+    in the reference's expanded form vs the oracle (fp32 summation order differs: relative 1e-5), argmin == find_nearest_embedding
+    == the reference's codes of the fixture's first depth, on K = 500 / D = 64 and on the ImageNet codebook shape K = 16384 / D = 256."""
+    from rqvae.models.rqvae.quantizations import VQEmbedding
+    g = golden('rq_small.npz')
+    for x, cb in ((g['x'].astype(np.float32), g['codebook'].astype(np.float32)),
+                  (np.random.default_rng(3).standard_normal((3, 5, 7, 256), dtype=np.float32),
+                   np.random.default_rng(4).standard_normal((16384, 256), dtype=np.float32))):
+        K, Dm = cb.shape
+        vq = VQEmbedding(K, Dm).to(DEV)
+        with torch.no_grad():
+            vq.weight[:-1].copy_(G(cb))
+        vq.invalidate_code_norms()
+        dist = vq.compute_distances(G(x))
+        assert dist.shape == x.shape[:-1] + (K,) and dist.dtype == torch.float32
+        ref = oracle.rq.compute_distances(x.reshape(-1, Dm), cb).reshape(dist.shape)
+        rel = np.abs(N(dist) - ref).max() / np.abs(ref).max()
+        print(f'compute_distances K={K} D={Dm}: max rel err vs oracle {rel:.2e}')
+        assert rel < 2e-5
+        idx = vq.find_nearest_embedding(G(x))
+        assert torch.equal(dist.argmin(-1), idx)
+        if K == 500:
+            assert np.array_equal(N(idx), g['codes'][..., 0])          # the reference's first-depth codes of the fixture
+
+
 def test_rq_quantize_golden_full_size(nat, golden):
     """K=16384, D=256 (ImageNet RQ-VAE codebook shape), 16 images: every top-2 gap in the fixture is
     > 5e-3, far above the 3e-4 fp32 distance noise, so all 4096 codes must match the reference."""
@@ -302,6 +328,38 @@ def test_rqt_tiny_logits_golden(nat, golden):
     assert err.max() < 0.06 and err.mean() < 0.01
 
 
+def test_rqt_cached_forward_steps(nat, golden):
+    """RQTransformer.cached_forward (transformers.py:190-287) as a public method: the reference's own loop --
+    init_cache(), then one call per (h, w, d) on the codes so far -- reproduces the teacher-forced logits bit for bit (the stepping
+    entry points are what sample() and forward() run on) and the reference's logits within the bf16 bound; a call at
+    start_loc = (1, 2) on a fresh cache prefills the positions before it (:235-239); out-of-order depths raise."""
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    full = ar(codes, vae, cond=cond)
+    H, W, D = C.RQT_TINY['block_size']
+    ar.init_cache()
+    got = torch.empty_like(full)
+    for h in range(H):
+        for w in range(W):
+            for d in range(D):
+                out = ar.cached_forward(codes[:, :h + 1], vae, cond=cond, sample_loc=(h, w, d))
+                assert out.shape == (codes.shape[0], C.RQT_TINY['vocab_size']) and out.dtype == torch.float32
+                got[:, h, w, d] = out
+    ar.init_cache()
+    assert torch.equal(got, full)
+    err = np.abs(N(got) - g['logits'])
+    print('rqt tiny cached_forward loop: == teacher-forced logits bit for bit; vs reference max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.03 and err.mean() < 0.005
+    pl = ar.cached_forward(codes[:, :2], vae, cond=cond, sample_loc=(1, 2, 0))
+    assert torch.equal(pl, full[:, 1, 2, 0])
+    nxt = ar.cached_forward(codes[:, :2], vae, cond=cond, sample_loc=(1, 2, 1))
+    assert torch.equal(nxt, full[:, 1, 2, 1])
+    ar.init_cache()
+    with pytest.raises(RuntimeError):
+        ar.cached_forward(codes[:, :1], vae, cond=cond, sample_loc=(0, 0, 2))
+
+
 def test_rqt_real_width_logits_vs_oracle(nat):
     """E=1536 / 24 heads / V=16384 (the 1.4B layer shapes), 2 body + 1 head layers, B=3."""
     cfg = C.RQT_WIDE
@@ -487,12 +545,12 @@ def test_rqt_text_conditioned(nat, golden):
     assert torch.equal(a, b) and int(a.max()) < 500
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias'])
 def test_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding / BatchLinear / LogitMask, cumsum_depth_ctx off, learned head embedding):
     teacher-forced logits vs the reference's forward(), sampling inside each depth's vocabulary, graph == eager."""
     g = golden(f'rqt_var_{tag}.npz')
-    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED}[tag]
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS}[tag]
     vae, _, _, _ = _models(C.VAE_TINY, None, int(g['vae_seed']), 0)
     from rqvae.models.rqtransformer import RQTransformer
     ar = RQTransformer(cfg)
@@ -549,8 +607,9 @@ def test_vae_tiny_golden(nat, golden):
 @pytest.mark.parametrize('tag,cfg', [('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)])
 def test_vae_full_size_golden(nat, golden, tag, cfg):
     """Released RQ-VAE shapes (104.4 M params, 256x256): decode_code and encode vs the reference fp32
-    outputs on seeded weights.  Pixel tolerance: mean |err| <= 0.012 (outputs have std 0.31) and max |err| <= 5 %
-    of max |ref| (0.21 / 0.15 on outputs spanning about +-4.3 / +-3.0): bf16 activations through ~70 layers.
+    outputs on seeded weights.  Pixel tolerance: mean |err| <= 0.010 (outputs have std 0.31; measured 0.0068) and max |err| <= 4.5 %
+    of max |ref| (measured 3.3 % / 3.7 % on outputs spanning about +-4.3 / +-3.0): bf16 activations through ~70 layers; the encoder
+    output within 0.035 max / 0.005 mean (2 x the measured 0.018 / 0.0025).  (Round 4 carried 5 % / 0.012 and 0.05 / 0.01.)
     Measured mean 0.0068 for both shapes in every version of the kernels; the max is the tail of 196 608 pixels and
     moves with the summation order of the GroupNorm statistics (0.134 / 0.098 with a separate statistics pass,
     0.127 on the ffhq shape with the statistics taken in the conv epilogues)."""
@@ -560,14 +619,14 @@ def test_vae_full_size_golden(nat, golden, tag, cfg):
     ref = g['decode_code'].astype(np.float32)
     err = np.abs(dec - ref)
     print(f'vae {tag} decode_code: max err %.4f mean %.5f (|ref| max %.2f, std %.3f)' % (err.max(), err.mean(), np.abs(ref).max(), ref.std()))
-    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
+    assert err.max() < 0.045 * np.abs(ref).max() and err.mean() < 0.010
     rng = np.random.default_rng(int(g['data_seed']))
     rng.integers(0, cfg[0]['n_embed'], (1, 8, 8, 4))
     x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
     z_e = N(vae.encode(G(x)))
     err = np.abs(z_e - g['z_e'])
     print(f'vae {tag} encode: max err %.4f mean %.5f (|ref| max %.2f)' % (err.max(), err.mean(), np.abs(g['z_e']).max()))
-    assert err.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and err.mean() < 0.01
+    assert err.max() < 0.035 * max(1.0, np.abs(g['z_e']).max()) and err.mean() < 0.005
     codes = N(vae.get_codes(G(x)))
     cb = vparams['quantizer.codebooks.0.weight'][:-1]
     gaps, _ = oracle.rq_quantize_margins(g['z_e'], [cb] * 4)
@@ -633,14 +692,14 @@ def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
     err = np.abs(d1 - ref)
     print('vae imagenet decode_code, implicit GEMM at 32^2: max err %.4f mean %.5f; vs default path max %.4f mean %.5f'
           % (err.max(), err.mean(), np.abs(d1 - d0).max(), np.abs(d1 - d0).mean()))
-    assert err.max() < 0.05 * np.abs(ref).max() and err.mean() < 0.012
+    assert err.max() < 0.045 * np.abs(ref).max() and err.mean() < 0.010
     assert np.abs(d1 - d0).mean() < 0.01
     rng = np.random.default_rng(int(g['data_seed']))
     rng.integers(0, C.VAE_IMAGENET[0]['n_embed'], (1, 8, 8, 4))
     x = np.clip(rng.standard_normal((1, 3, 256, 256), dtype=np.float32), -1, 1)
     e = np.abs(N(vae1.encode(G(x))) - g['z_e'])
     print('vae imagenet encode, implicit GEMM at 32^2: max err %.4f mean %.5f' % (e.max(), e.mean()))
-    assert e.max() < 0.05 * max(1.0, np.abs(g['z_e']).max()) and e.mean() < 0.01
+    assert e.max() < 0.035 * max(1.0, np.abs(g['z_e']).max()) and e.mean() < 0.005
     codes64 = G(g['codes'], torch.long).repeat(64, 1, 1, 1).contiguous()
     d64 = N(vae0.decode_code(codes64))
     assert np.array_equal(d64, np.repeat(d0[:1], 64, axis=0))   # every copy decodes to the bits of the one-image call
