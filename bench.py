@@ -76,7 +76,9 @@ def parse_args(argv=None):
     ap.add_argument('--sweep', type=str, default='64,100,200,500', help='extra per-GPU batches measured after the timed region ("" = none)')
     ap.add_argument('--also', type=str, default='xhuge:64,txt3900m:64',
                     help='model:batch points measured after everything else on rank 0 at N = 1 (default: the two models BASELINE.json quotes on '
-                         '8 GPUs, at their per-GPU share of 64 images; "" = none)')
+                         '8 GPUs, at their per-GPU share of 64 images; "" = none).  Adds ~40 s to a default run: after the headline model is '
+                         'released, two ~3.8B-parameter models are built (random init), captured and timed; a failure is reported in the JSON '
+                         'line AND on stderr')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--overlap', action='store_true', help='experiment: decode batch i while sampling batch i+1 (two streams)')
@@ -179,6 +181,7 @@ def cpu_baseline_reference(model, top_k, top_p, batch=32, positions=16, n_dec=8,
         raise RuntimeError(f'oracle/ref_cpu_baseline.py failed: {r.stderr[-400:]}')
     d = json.loads(lines[-1])
     return {'value': d['images_per_sec'], 'unit': 'images/sec', 'cores': int(d['threads']), 'kind': 'reference',
+            'extrapolated': True, 'extrapolation_factor': d['of_positions'] / d['positions'],
             'sample': f"the reference's own modules (oracle/_ref), fp32 on torch CPU kernels, {d['threads']} threads: RQTransformer.sample over the "
                       f"last {d['positions']} of {d['of_positions']} spatial positions of a batch of {d['batch']} (prefix prefilled by its first "
                       f"cached step; top-k {top_k} / top-p {top_p}) = {d['ar_s']:.1f} s, scaled x{d['of_positions'] / d['positions']:.0f} -> "
@@ -210,7 +213,7 @@ def cpu_baseline(vae, ar, cfg, vcfg, n_pos=3, batch=32, n_dec=2):
         t_dec = (time.time() - t0) / n_dec
     finally:
         oracle.backend.use_torch(False)
-    return {'value': 1.0 / (t_ar + t_dec), 'unit': 'images/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+    return {'value': 1.0 / (t_ar + t_dec), 'unit': 'images/sec', 'cores': int(torch.get_num_threads()), 'kind': 'port', 'extrapolated': True,
             'sample': f'oracle (numpy restatement, heavy primitives on torch-CPU kernels), fp32: {n_pos} of {H * W} spatial positions at '
                       f'batch {batch} (scaled x{H * W / n_pos:.1f}) = {t_ar:.2f} s/img AR + full 256x256 decode_code of {n_dec} images = '
                       f'{t_dec:.2f} s/img'}
@@ -346,6 +349,40 @@ def decoder_flops_per_image(dd, embed_dim):
             res *= 2
             fl += conv(block_in, block_in, 3, res)
     return fl + conv(block_in, dd['out_ch'], 3, res)
+
+
+def encoder_flops_per_image(dd, embed_dim):
+    """Convolution + attention-GEMM FLOPs of Encoder.forward + quant_conv for one image (modules.py:14-98 of the reference), from
+    the ddconfig alone: 134.2 GFLOP for the released 256x256 shapes.  The residual quantiser's 2.1 GFLOP (fp32) are counted by
+    rq_roofline, not here."""
+    ch, mult, nrb = dd['ch'], list(dd['ch_mult']), dd['num_res_blocks']
+    res = dd['resolution']
+
+    def conv(cin, cout, k, hw):
+        return 2.0 * hw * hw * cin * cout * k * k
+
+    def resblock(cin, cout, hw):
+        f = conv(cin, cout, 3, hw) + conv(cout, cout, 3, hw)
+        return f + (conv(cin, cout, 1, hw) if cin != cout else 0.0)
+
+    def attn(c, hw):
+        t = hw * hw
+        return 4 * conv(c, c, 1, hw) + 2 * 2.0 * t * t * c
+    fl = conv(dd['in_channels'], ch, 3, res)
+    block_in = ch
+    for lvl in range(len(mult)):
+        block_out = ch * mult[lvl]
+        for _ in range(nrb):
+            fl += resblock(block_in, block_out, res)
+            block_in = block_out
+            if res in dd['attn_resolutions']:
+                fl += attn(block_in, res)
+        if lvl != len(mult) - 1:
+            res //= 2
+            fl += conv(block_in, block_in, 3, res)                   # Downsample: 3x3 stride-2 conv (layers.py:39-57)
+    fl += 2 * resblock(block_in, block_in, res) + attn(block_in, res)
+    z = dd['z_channels'] * (2 if dd.get('double_z') else 1)
+    return fl + conv(block_in, z, 3, res) + conv(dd['z_channels'], embed_dim, 1, res)
 
 
 def driver_loop(vae, ar, B, device, top_k, top_p, steps, warmup):
@@ -747,6 +784,10 @@ def main(argv=None):
             ips, a_ms, d_ms, es, ec = timed_batch(vae, ar, b, device, args.top_k, args.top_p, steps=3 if b >= 256 else 5, warmup=1)
             entry = {'batch_per_gpu': b, 'images_per_sec': ips, 'ar_ms_per_image': a_ms, 'decode_ms_per_image': d_ms,
                      'ar_ms_per_batch': a_ms * b}
+            if b == 500 and args.model == 'huge':
+                entry['vs_reference_fig4'] = {'ratio': ips / A100_FIG4_IMG_S, 'reference_images_per_sec': A100_FIG4_IMG_S,
+                                              'what': 'same model (1.4B, 8x8x4 codes) and batch (500) as the reference\'s Fig. 4 point; bf16 on one MI355X '
+                                                      'here against fp32 on one A100 there (BASELINE.md §1): same batch, other precision and hardware'}
             if not args.no_profile:
                 entry['roofline'], entry['roofline_attn'] = gemm_roofline(ar, vae, es, ec, args.top_k, args.top_p, device, args.model, b, cfg)
             del es, ec
@@ -774,6 +815,13 @@ def main(argv=None):
                'what': 'RQVAE.get_codes: 256x256 encode + depth-4 residual quantisation, 256 codes per image'}
         del xb
         rqr = rq_roofline(vae, device)
+        efl = encoder_flops_per_image(vcfg['ddconfig'], vcfg['hparams']['embed_dim'])
+        enc['roofline_encode'] = {'bound': 'mfma', 'achieved': efl * 256 / (ms * 1e-3) / 1e12, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': efl * 256 / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 'traffic': None,
+                                  'algorithmic_GFLOP_per_image': efl / 1e9,
+                                  'what': 'RQVAE.get_codes over 256 images: conv / attention-GEMM FLOPs of Encoder.forward (modules.py:73-98) over the '
+                                          'device time of the whole call (the fp32 residual quantiser, ~11 % of it, included in the time, not in the '
+                                          'FLOPs); kernel shares: profiles/r05_encode_kernel_stats.md'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -817,7 +865,8 @@ def main(argv=None):
                     ar2._engine = None
                 del ar2, es, ec, codes2
                 torch.cuda.empty_cache()
-        except Exception as e:            # reported, never required
+        except Exception as e:            # reported, never required -- and not buried: the line goes to stderr as well
+            print(f'bench.py: --also {args.also!r} failed: {e!r}', file=sys.stderr)
             also.append({'error': repr(e)})
 
     if rank == 0:
@@ -828,6 +877,7 @@ def main(argv=None):
         if not args.overlap and t_dec > 0:
             tf = dfl * B * args.steps / (t_dec * 1e-3) / 1e12
             roofline_decode = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_BF16_PEAK_TFLOPS,
+                               'traffic': None,
                                'algorithmic_GFLOP_per_image': dfl / 1e9, 'ms_per_image': t_dec / (args.steps * B),
                                'what': 'RQ-VAE decode_code + clamp of the timed region: conv / attention-GEMM FLOPs of Decoder.forward '
                                        '(modules.py:171-202) over its device time (events around the decode half of every step)'}
@@ -839,9 +889,9 @@ def main(argv=None):
             'metric': f'256x256 images/sec, AR sampling + decode (RQ-Transformer {args.model}, 8x8x4 codes)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            # context only: a B = 8192 bf16 MI355X number over the reference's B = 500 fp32 A100 number;
-            # the like-for-like batch is batch_sweep's 500 entry
-            'vs_baseline': value / (A100_FIG4_IMG_S * world) if args.model == 'huge' else None,
+            # BASELINE.json publishes no number for this metric (`published: {}`): null, as the contract says.  The one figure of the
+            # reference that exists -- Fig. 4, batch 500, one A100, fp32 -- is set against batch_sweep's 500 entry (`vs_reference_fig4`)
+            'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'RQ-Transformer {args.model} ({WORKLOADS.get(args.model, args.model)}) sampling 8x8x4 codes + RQ-VAE decode; '
                                    f'random-init weights, zero condition',
@@ -849,8 +899,8 @@ def main(argv=None):
                        'overlap_decode_with_next_sampling': bool(args.overlap), 'world_size': world, 'requested_gpus': args.gpus,
                        'per_rank_seconds': rank_times,
                        'parallelism': parallelism_note(world, B),
-                       'vs_baseline_ref': 'reference Fig.4: 52.6 img/s, 1.4B 8x8x4, batch 500, 1x A100 fp32 (BASELINE.md §1), per GPU; '
-                                          'different batch / precision / hardware -- context, not a like-for-like ratio'},
+                       'vs_baseline_note': 'null: BASELINE.json publishes no number for this metric; the reference\'s Fig. 4 point (batch 500) is '
+                                           'compared in batch_sweep[batch_per_gpu = 500].vs_reference_fig4'},
             'ar_ms_per_image': t_ar / (args.steps * B) if not args.overlap else None,
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
             'verified': None if verify is None else verify['verified'], 'verify': verify,
