@@ -246,7 +246,7 @@ int rq_gemm_launch(const GemmArgs& a_in, int bm, int bn, hipStream_t stream) {
             if (bm == CODE_ && bn == BN_ && gl == 3)                                                                        \
                 return tr ? launch_c<BM_, BN_, 0, 1, WM_, WN_, 3>(a, stream) : launch_c<BM_, BN_, 0, 0, WM_, WN_, 3>(a, stream);
             RQ_G3_CASE(132, 128, 64, 4, 2)
-            RQ_G3_CASE(132, 128, 128, 4, 2)
+            RQ_G3_CASE(136, 128, 128, 4, 4)
             RQ_G3_CASE(132, 128, 192, 4, 2)
             RQ_G3_CASE(264, 256, 128, 4, 4)
             RQ_G3_CASE(136, 128, 256, 4, 4)
@@ -295,7 +295,10 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
     // two forms agree bit for bit).  Not for the classifier (N = 16384: every workgroup re-reads the activations, 16.6 -> 19.7 us) and
     // not beyond 128 rows (the activation tile outgrows the per-CU fill rate: 256 rows 52 -> 64 us per layer).
     // Split-K (slab GEMMs): as many slices as keep (N / 32) x slices within one round of 256 CUs -- the kernel holds 144-160 KB of
-    // LDS, one workgroup per CU (fc2: 4 slices 7.9 us, 8 slices 11.3) -- a function of (N, K) only.
+    // LDS, one workgroup per CU (fc2: 4 slices 7.9 us, 8 slices 11.3) -- a function of (N, K) only for 32-row weight tiles; the
+    // 64-row tiles below (<= 64 activation rows only) change the slice count of some shapes, so THOSE shapes' bits depend on which
+    // side of 64 rows the batch falls: fc2 and proj at E = 2560 (four slices of 64-row tiles against two of 32-row tiles) and the
+    // N = 16384 classifier (this kernel at <= 64 rows, the tiled kernel above) -- DESIGN.md section 6.
     static const bool no_stream = getenv("RQAMD_NO_STREAM") != nullptr;      // A/B switch
     // (the classifier's N = 16384 only at <= 64 rows, where the 64-row weight tiles below cover it in one round: 15.0 vs 16.9 us at
     // E = 1536, 21.0 vs 25.0 at E = 2560, profiles/r04_gemm_stream_bn64_e2560.txt / r04_stream_k_rotation_ab.txt; at 65 .. 128 rows the
@@ -327,7 +330,7 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
         return;
     }
     // 129 .. 2047 rows (round 5; the reference's own metric batches 200 / 500 are here): eight- and sixteen-wavefront tiles of the
-    // LDS-DMA kernel -- tile codes 132 x {64, 128, 192} = 128 rows as 4 x 2 wavefronts, 264 x 128 = 256 rows and 136 x 256 = 128 rows
+    // LDS-DMA kernel -- tile codes 132 x {64, 192} = 128 rows as 4 x 2 wavefronts, 136 x {128, 256} = 128 rows and 264 x 128 = 256 rows
     // as 4 x 4 -- three ring stages.  What the sweep showed (profiles/r05_gemm_mid_sweep*.txt, in-graph, weights from HBM): at these row
     // counts a launch is bound by how fast a CU takes its operands in, not by MFMAs (the loop without MFMAs takes as long as the whole
     // kernel; ~70 GB/s per CU and ~11 TB/s over the chip, whatever the ring depth or the wavefront count), the four-wavefront tiles
@@ -345,7 +348,7 @@ void rq_gemm_pick_tile(int M_rows, int N, int K, bool allow_splitk, int* bm, int
             // the 256 x 128 three-stage tile of round 1 is level or ahead and stays)
             if (M < 1024) { *bm = 136; *bn = 256; *splitk = 1; *glds = 3; return; }
         } else {
-            static const int cand[5][3] = {{132, 128, 64}, {132, 128, 128}, {132, 128, 192}, {264, 256, 128}, {136, 128, 256}};
+            static const int cand[5][3] = {{132, 128, 64}, {136, 128, 128}, {132, 128, 192}, {264, 256, 128}, {136, 128, 256}};      // (128 x 128: sixteen wavefronts measured 1-2 % ahead of eight at every row count)
             static const int sks[6] = {1, 2, 3, 4, 6, 8};
             const int kt = K / 64;
             double best = 1e30;

@@ -647,8 +647,8 @@ def test_emu_gemm_256x256_eight_phase(nat):
 
 
 def test_emu_gemm_mid_batch_tiles(nat):
-    """Round 5: the eight- / sixteen-wavefront LDS-DMA tiles of the 129 .. 2047 row decode step (tile codes 132 x {64, 128, 192},
-    264 x 128, 136 x 256; three ring stages): every epilogue family incl. K splits and the in-place residual update, ragged M / N,
+    """Round 5: the eight- / sixteen-wavefront LDS-DMA tiles of the 129 .. 2047 row decode step (tile codes 132 x {64, 192},
+    136 x {128, 256}, 264 x 128; three ring stages): every epilogue family incl. K splits and the in-place residual update, ragged M / N,
     and the engine's own choice (bm = bn = 0) for row counts in that range -- vs fp32 matmul, and auto == the explicit launch."""
     rng = np.random.default_rng(29)
     for (M, N, K) in ((200, 200, 448), (300, 132, 640)):
@@ -657,7 +657,7 @@ def test_emu_gemm_mid_batch_tiles(nat):
         bias = T(rng.standard_normal(N).astype(np.float32))
         ref = a.float().numpy() @ w.float().numpy().T + bias.numpy()
         scale = np.abs(ref).max()
-        for (bm, bn) in ((132, 64), (132, 128), (132, 192), (264, 128), (136, 256)):
+        for (bm, bn) in ((132, 64), (136, 128), (132, 192), (264, 128), (136, 256)):
             out = nat.dbg_gemm(a, w, bias, epi=3 + 96, bm=bm, bn=bn, splitk=1).numpy()
             assert np.abs(out - ref).max() < 2e-3 * scale, (M, N, K, bm, bn)
             out = nat.dbg_gemm(a, w, bias, epi=0 + 96, bm=bm, bn=bn, splitk=1).float().numpy()
@@ -767,6 +767,17 @@ def test_emu_gemm_stream(nat):
     auto = nat.dbg_gemm(a, w, bias, epi=3, bm=0, bn=0, splitk=0).numpy()
     assert np.abs(auto - (a.float().numpy() @ w.float().numpy().T + bias.numpy())).max() < 2e-3 * np.abs(auto).max()
     assert np.array_equal(auto, nat.dbg_gemm(a, w, bias, epi=3, bm=66, bn=32, splitk=1).numpy())
+    # ... and the K-split branch of the same picker: a slab GEMM of the wide models (proj at E = 2560: N / 32 x 4 > 256
+    # workgroups, N / 64 x 4 <= 256) takes 64-row weight tiles with FOUR K slices -- the explicit launch, bit for bit, and the slabs
+    # sum to the fp32 product
+    a = torch.from_numpy(rng.standard_normal((5, 2560)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.05 * rng.standard_normal((2560, 2560))).astype(np.float32)).to(torch.bfloat16)
+    auto = torch.zeros((8, 5, 2560))
+    nat.dbg_gemm(a, w, None, epi=4, bm=0, bn=0, splitk=0, out=auto)
+    assert float(auto[4:].abs().max()) == 0.0 and float(auto[3].abs().max()) > 0.0          # exactly four slabs were written
+    assert torch.equal(auto[:4], nat.dbg_gemm(a, w, None, epi=4, bm=66, bn=64, splitk=4))
+    ref = a.float().numpy() @ w.float().numpy().T
+    assert np.abs(auto.numpy().sum(0) - ref).max() < 2e-3 * np.abs(ref).max()
     # GELU epilogue vs torch
     a = torch.from_numpy(rng.standard_normal((48, 256)).astype(np.float32)).to(torch.bfloat16)
     w = torch.from_numpy((0.2 * rng.standard_normal((64, 256))).astype(np.float32)).to(torch.bfloat16)
