@@ -309,6 +309,8 @@ def kv_bytes_per_image(cfg):
     cl = max(cfg.get('block_size_cond', 1), 1)
     body = sum(p + cl for p in range(H * W)) * cfg['body']['n_layer']
     head = H * W * sum(d + 1 for d in range(D)) * cfg['head']['n_layer']
+    if os.environ.get('RQAMD_KV', 'bf16') == 'int8k':      # opt-in: body keys as 64 bytes + an fp32 scale per head (68 B per 64 components), values bf16
+        return body * (E * 2 + E + (E // 64) * 4) + head * E * 2 * 2
     return (body + head) * E * 2 * 2
 
 
@@ -896,6 +898,8 @@ def main(argv=None):
             'config': {'workload': f'RQ-Transformer {args.model} ({WORKLOADS.get(args.model, args.model)}) sampling 8x8x4 codes + RQ-VAE decode; '
                                    f'random-init weights, zero condition',
                        'batch_per_gpu': B, 'global_batch': B * world, 'batch_note': batch_note, 'top_k': args.top_k, 'top_p': args.top_p,
+                       'kv_cache': os.environ.get('RQAMD_KV', 'bf16') + (' (opt-in: body-stack keys as bytes + one scale per token and head; default bf16)'
+                                                                          if os.environ.get('RQAMD_KV', 'bf16') != 'bf16' else ''),
                        'overlap_decode_with_next_sampling': bool(args.overlap), 'world_size': world, 'requested_gpus': args.gpus,
                        'per_rank_seconds': rank_times,
                        'parallelism': parallelism_note(world, B),

@@ -26,6 +26,7 @@ struct RqtLayer {
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
     float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
     bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
+    float* ksc;        // body layers with the opt-in 8-bit key cache (RQAMD_KV=int8k): per-key scales, `kc` then holds bytes; else null
 };
 
 struct GemmProfile {
@@ -76,6 +77,7 @@ struct rqamd_rqt {
     uint64_t* rng;      // {seed, offset}
     int* smp_redo;      // [rows] sampler workspace (rows the top-k kernel hands back to the general kernel)
     int max_slabs = 8;
+    bool kv_int8k = false;   // RQAMD_KV=int8k when the handle was created: body-stack keys cached as 64 bytes + one fp32 scale (rqt_kernels.hip)
 
     // graph cache
     // one captured position per 8-key bucket of the body context (the attention kernel variant is baked in)
@@ -119,6 +121,13 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     if (c->D < 1 || c->D > 8 || c->H < 1 || c->W < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: bad block_size");
     rqamd_rqt* h = new rqamd_rqt();
     h->cfg = *c;
+    {   // opt-in storage format of the body stack's key cache, fixed for the life of the handle (default: bf16, what BASELINE.json asks for)
+        const char* kvf = getenv("RQAMD_KV");
+        if (kvf && *kvf && strcmp(kvf, "bf16") != 0) {
+            if (strcmp(kvf, "int8k") != 0) { delete h; return rq_fail(RQAMD_ERR_INVALID, "rqt_create: RQAMD_KV=%s (bf16 or int8k)", kvf); }
+            h->kv_int8k = true;
+        }
+    }
     h->E = c->embed_dim; h->HW = c->H * c->W; h->D = c->D; h->V = c->vocab_size; h->Din = c->input_embed_dim;
     h->cond_len = c->block_size_cond < 1 ? 1 : c->block_size_cond;
     h->Tbody = h->HW + h->cond_len - 1;
@@ -323,8 +332,8 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     // (cap 0, no graphs), never pointing at freed memory; the caller may retry with a smaller batch.
     h->cap = 0;
     h->gvalid = false;
-    for (auto& L : h->body) L.kc = L.vc = nullptr;
-    for (auto& L : h->head) L.kc = L.vc = nullptr;
+    for (auto& L : h->body) { L.kc = L.vc = nullptr; L.ksc = nullptr; }
+    for (auto& L : h->head) { L.kc = L.vc = nullptr; L.ksc = nullptr; }
     const size_t E = h->E, V = h->V;
     const size_t brows = (size_t)B;
     const size_t prow = (size_t)prefill_chunk(h, B) * (h->cond_len - 1);
@@ -344,10 +353,15 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     h->st = (int*)take(64); h->rng = (uint64_t*)take(64); h->smp_redo = (int*)take(brows * 4);
     // KV caches: body [rows][nh][Tbody][64] x2 per layer, head Tcap = D
     const size_t kvb = al(brows * E * h->Tbody * 2), kvh = al(brows * E * h->D * 2);
-    RQ_TRY(h->kv.reserve(2 * kvb * h->body.size() + 2 * kvh * h->head.size()));
+    // (8-bit keys: half the bytes for K plus one fp32 scale per (row, head, position))
+    const size_t kkb = h->kv_int8k ? al(brows * E * h->Tbody) : kvb, ksb = h->kv_int8k ? al(brows * (E / 64) * h->Tbody * 4) : 0;
+    RQ_TRY(h->kv.reserve((kkb + ksb + kvb) * h->body.size() + 2 * kvh * h->head.size()));
     char* q = (char*)h->kv.p;
-    for (auto& L : h->body) { L.kc = (bf16_t*)q; q += kvb; L.vc = (bf16_t*)q; q += kvb; }
-    for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; }
+    for (auto& L : h->body) {
+        L.kc = (bf16_t*)q; q += kkb; L.vc = (bf16_t*)q; q += kvb;
+        L.ksc = h->kv_int8k ? (float*)q : nullptr; q += ksb;
+    }
+    for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; L.ksc = nullptr; }
     h->cap = B;
     return RQAMD_OK;
 }
@@ -425,12 +439,15 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     if (pf) {
         AttnPrefillArgs ap{};
         const long img_stride = (long)h->cfg.n_head * Tcap * 64;
-        ap.qkv = h->qkv; ap.kc = L.kc + pf->img0 * img_stride; ap.vc = L.vc + pf->img0 * img_stride; ap.y = h->ya;
+        ap.qkv = h->qkv; ap.vc = L.vc + pf->img0 * img_stride; ap.y = h->ya;
+        // (8-bit keys: a key is 64 bytes, i.e. half the bf16 stride, and has one scale)
+        ap.kc = L.ksc ? (bf16_t*)((unsigned char*)L.kc + pf->img0 * img_stride) : L.kc + pf->img0 * img_stride;
+        ap.ksc = L.ksc ? L.ksc + (long)pf->img0 * h->cfg.n_head * Tcap : nullptr;
         ap.n_img = pf->n_img; ap.P = pf->P; ap.nh = h->cfg.n_head; ap.E = E; ap.Tcap = Tcap;
         RQ_TRY(rq_launch_attn_prefill(ap, st));
     } else {
         AttnDecodeArgs at{};
-        at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.y = h->ya; at.step = step; at.step_off = step_off;
+        at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.ksc = L.ksc; at.y = h->ya; at.step = step; at.step_off = step_off;
         at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
         GemmProfile& pfl = h->prof;
         if (pfl.on) {

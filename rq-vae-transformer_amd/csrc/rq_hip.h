@@ -162,6 +162,9 @@ static __device__ __forceinline__ float rq_dot2_bf16(uint32_t a, uint32_t b, flo
     typedef __bf16 rq_bf16x2_v __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rq_bf16x2_v, a), __builtin_bit_cast(rq_bf16x2_v, b), acc, false);
 }
+// byte I (0..3) of a word as a float (the back end selects v_cvt_f32_ubyteI for this pattern: one instruction): the dequantisation
+// of the opt-in 8-bit key cache
+template <int I> static __device__ __forceinline__ float rq_ubyte_f32(uint32_t w) { return (float)((w >> (8 * I)) & 0xffu); }
 static __device__ __forceinline__ void rq_trap() { __builtin_trap(); }
 static __device__ __forceinline__ float rq_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 static __device__ __forceinline__ float rq_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }   // median: clamp in one op

@@ -32,6 +32,8 @@ struct AttnDecodeArgs {
     const bf16_t* qkv;      // [rows][3E]: q | k | v, head h at columns h*64..h*64+63 of each third
     bf16_t* kc;             // K cache [rows][nh][Tcap][64]
     bf16_t* vc;             // V cache [rows][nh][Tcap][64]
+    float* ksc;             // null: bf16 keys.  Non-null (opt-in RQAMD_KV=int8k, body stack): `kc` holds [rows][nh][Tcap][64] BYTES,
+                            // key component = (byte - 128) * ksc[row][head][position], one absmax / 127 scale per cached key
     bf16_t* y;              // [rows][E]
     const int* step;        // device-side step counter (or null)
     int step_off;           // t = *step + step_off = number of cached keys before this token
@@ -45,6 +47,7 @@ struct AttnPrefillArgs {
     const bf16_t* qkv;      // [n_img * P][3E], row = img * P + i (token i of image img)
     bf16_t* kc;             // K cache of the FIRST image of this chunk: [n_img][nh][Tcap][64]; positions 0..P-1 are written
     bf16_t* vc;
+    float* ksc;             // as AttnDecodeArgs::ksc (of the first image of the chunk), or null
     bf16_t* y;              // [n_img * P][E]
     int n_img, P, nh, E, Tcap;
 };

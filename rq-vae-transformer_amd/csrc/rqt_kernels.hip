@@ -199,6 +199,49 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
     f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+// ---- opt-in 8-bit key cache (RQAMD_KV=int8k; AttnDecodeArgs::ksc != null; body stack only).  A cached key is 64 bytes + one fp32
+// scale: component = (byte - 128) * scale, scale = max |k| / 127 over the key's 64 components (per token and head), byte =
+// rint(k / scale) + 128 in 1 .. 255.  Costed on the reference model in round 4 (profiles/r04_kv_cache_precision_costing.txt: K alone
+// adds 0.0053 max / 0.00063 mean to the logits, what bf16 storage itself adds); V stays bf16.  This token's own key is used as it
+// comes out of the qkv GEMM (bf16), like the bf16 path; it is quantised only on its way into the cache.
+struct __attribute__((aligned(8))) rq_u64w { uint32_t x, y; };
+static __device__ __forceinline__ rq_u64w ld64(const void* p) { return *(const rq_u64w*)p; }
+static __device__ __forceinline__ void st64(void* p, rq_u64w v) { *(rq_u64w*)p = v; }
+// the 8 lanes of a key group hold its 64 components, 8 bf16 each: bytes of this lane's chunk + the key's scale (uniform in the group)
+static __device__ __forceinline__ rq_u64w quant_key_chunk(rq_u128 kbf, float& scale) {
+    float kf[8];
+    unpack8(kbf, kf);
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(kf[e]));
+    am = fmaxf(am, rq_dpp_xor1(am));
+    am = fmaxf(am, rq_dpp_xor2(am));
+    am = fmaxf(am, rq_dpp_half_mirror(am));
+    scale = am > 0.f ? am * (1.0f / 127.0f) : 1.0f;
+    const float inv = am > 0.f ? 127.0f / am : 0.f;
+    uint32_t u[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = (uint32_t)((int)rintf(kf[e] * inv) + 128) & 0xffu;
+    rq_u64w w;
+    w.x = u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24);
+    w.y = u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24);
+    return w;
+}
+// this lane's share of sum_e q[e] * byte[e] over its 8 components
+static __device__ __forceinline__ float dot_q_bytes(const float* qf, rq_u64w w) {
+    float d = qf[0] * rq_ubyte_f32<0>(w.x);
+    d = fmaf(qf[1], rq_ubyte_f32<1>(w.x), d); d = fmaf(qf[2], rq_ubyte_f32<2>(w.x), d); d = fmaf(qf[3], rq_ubyte_f32<3>(w.x), d);
+    d = fmaf(qf[4], rq_ubyte_f32<0>(w.y), d); d = fmaf(qf[5], rq_ubyte_f32<1>(w.y), d);
+    d = fmaf(qf[6], rq_ubyte_f32<2>(w.y), d); d = fmaf(qf[7], rq_ubyte_f32<3>(w.y), d);
+    return d;
+}
+static __device__ __forceinline__ float group8_sum(float v) {
+    v += rq_dpp_xor1(v);
+    v += rq_dpp_xor2(v);
+    v += rq_dpp_half_mirror(v);
+    return v;
+}
+
 // Lane (g = lane >> 3, cc = lane & 7) owns 16-byte chunk cc of key / value row jj*8 + g of every 8-row block jj,
 // for K and V alike (both caches are [row][head][Tcap][64]): a block is one 1 KB contiguous wavefront load, the
 // number of load instructions follows the context length (2 * ceil((t+1)/8) + 2, not a fixed 25), the partial
@@ -210,7 +253,7 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
 // P = (row, head) pairs per wavefront (heads h0 .. h0+P-1 of one row), processed stage by stage so that the loads of
 // all P pairs are in flight together: at short contexts a wavefront's lifetime is one memory round trip, and with
 // 98 304 pairs per launch the launch time was 12 rounds of 8192 resident wavefronts x that latency (45 us at t = 0).
-template <int NJ, bool DYN, int P>
+template <int NJ, bool DYN, int P, bool KQ = false>
 static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, int b, int h0, int t) {
     const int E = p.E, Tcap = p.Tcap;
     const int cc = lane & 7, g = lane >> 3;
@@ -221,21 +264,29 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
     const bf16_t* qrow[P];
     bf16_t* kc[P];
     bf16_t* vc[P];
+    unsigned char* kc8[P];                              // KQ: the same cache as bytes, and its scales
+    float* ksc[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const long pair = (long)b * p.nh + h0 + i;
         qrow[i] = p.qkv + (long)b * 3 * E + (h0 + i) * 64;
         kc[i] = p.kc + pair * Tcap * 64;                // pair-major [rows][nh][Tcap][64]: a position-major layout
         vc[i] = p.vc + pair * Tcap * 64;                // measured +10 % at long contexts and no gain at short ones
+        kc8[i] = (unsigned char*)p.kc + pair * Tcap * 64;
+        ksc[i] = KQ ? p.ksc + pair * Tcap : nullptr;
     }
 
     // every global load is issued before the first use (q, this token's k|v, all K and V blocks); rows j >= t
     // read this token's k / v straight from qkv (the cache row is written by this launch), clamped, unmasked
-    rq_u128 qv[P], kv_new[P], kr[P][NJ], vr[P][NJ];
+    rq_u128 qv[P], kv_new[P], kr[P][KQ ? 1 : NJ], vr[P][NJ];
+    rq_u128 kn_all[P];                                  // KQ: this token's key chunk in EVERY group (the self score)
+    rq_u64w kr8[P][KQ ? NJ : 1];
+    float ksv[P][KQ ? NJ : 1];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         qv[i] = ld128(qrow[i] + cc * 8);
         kv_new[i] = ld128(qrow[i] + (lane < 8 ? E : 2 * E) + cc * 8);
+        if (KQ) kn_all[i] = ld128(qrow[i] + E + cc * 8);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -244,7 +295,13 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             if (DYN && jj >= nblk) continue;
             const int j = jj * 8 + g;
             const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
-            kr[i][jj] = ld128((j >= t) ? (qrow[i] + E + cc * 8) : (kc[i] + off));
+            if constexpr (KQ) {
+                // cached keys only (rows j >= t are masked or served by the self score): 8 bytes per lane + the key's scale
+                kr8[i][jj] = ld64(kc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
+                ksv[i][jj] = ksc[i][j < t ? j : tprev];
+            } else {
+                kr[i][jj] = ld128((j >= t) ? (qrow[i] + E + cc * 8) : (kc[i] + off));
+            }
         }
     }
 #pragma unroll
@@ -259,8 +316,17 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        if (lane < 8) st128(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
-        else if (lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+        if constexpr (KQ) {
+            // append: the key as 64 bytes + scale (lanes 0..7 hold it in kv_new), the value row as it is
+            float s_app;
+            const rq_u64w kb = quant_key_chunk(kv_new[i], s_app);              // (lanes >= 8 quantise their value chunk: unused)
+            if (lane < 8) st64(kc8[i] + (long)t * 64 + cc * 8, kb);
+            if (lane == 0) ksc[i][t] = s_app;
+            if (lane >= 8 && lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+        } else {
+            if (lane < 8) st128(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+            else if (lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+        }
     }
 
     float sc[P][NJ], mx[P], inv[P];
@@ -269,19 +335,36 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
         float qf[8];
         unpack8(qv[i], qf);
         mx[i] = NEG_INF;
+        float s_self = 0.f, qsum128 = 0.f;
+        if constexpr (KQ) {
+            float kf[8];
+            unpack8(kn_all[i], kf);
+            float d = 0.f, qs = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { d = fmaf(qf[e], kf[e], d); qs += qf[e]; }
+            s_self = group8_sum(d) * 0.125f;                        // q . k of this token, bf16 key (1/sqrt(64), attentions.py:87)
+            qsum128 = 128.0f * group8_sum(qs);                      // the byte offset's share of every cached score
+        }
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             float s = NEG_INF;
             if (!DYN || jj < nblk) {
-                float kf[8];
-                unpack8(kr[i][jj], kf);
-                float dot = 0.f;
+                if constexpr (KQ) {
+                    const float du = group8_sum(dot_q_bytes(qf, kr8[i][jj]));
+                    const int j = jj * 8 + g;
+                    if (j < t) s = (du - qsum128) * ksv[i][jj] * 0.125f;
+                    else if (j == t) s = s_self;
+                } else {
+                    float kf[8];
+                    unpack8(kr[i][jj], kf);
+                    float dot = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
-                dot += rq_dpp_xor1(dot);                            // the 8 lanes of a key group: DPP, no LDS round trip
-                dot += rq_dpp_xor2(dot);
-                dot += rq_dpp_half_mirror(dot);
-                if (jj * 8 + g <= t) s = dot * 0.125f;              // 1/sqrt(64), attentions.py:87
+                    for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+                    dot += rq_dpp_xor1(dot);                            // the 8 lanes of a key group: DPP, no LDS round trip
+                    dot += rq_dpp_xor2(dot);
+                    dot += rq_dpp_half_mirror(dot);
+                    if (jj * 8 + g <= t) s = dot * 0.125f;              // 1/sqrt(64), attentions.py:87
+                }
             }
             sc[i][jj] = s;
             mx[i] = fmaxf(mx[i], s);
@@ -345,7 +428,7 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
 // One kernel per register-block count: the launch picks the smallest NJ that covers the host-known bound on t
 // (engine_rqt.hip keeps one captured graph per NJ), so short contexts and the depth transformer (t < 8) run
 // with few VGPRs and 8 wavefronts per SIMD instead of inheriting the 64-key variant's register budget.
-template <int NJ, bool DYN, int P>
+template <int NJ, bool DYN, int P, bool KQ = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = rq_uniform((int)(threadIdx.x >> 6));
@@ -353,7 +436,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     if (h0 >= p.nh) return;                                        // whole wave exits together (nh % P == 0)
     const int t = (p.step ? *p.step : 0) + p.step_off;
     if ((t >> 3) >= NJ) rq_trap();                                 // host bound violated: never drop keys silently
-    attn_run<NJ, DYN, P>(p, lane, (int)blockIdx.y, h0, t);
+    attn_run<NJ, DYN, P, KQ>(p, lane, (int)blockIdx.y, h0, t);
 }
 
 // Contexts of at most 8 keys (t <= 7: every step of the depth transformer and the first 8 spatial positions -- 44 % of all
@@ -362,37 +445,63 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
 // its launch time at t = 0 was the texture-address path's instruction rate (7+ wavefront loads / stores per pair), not
 // bytes.  Here a wavefront instruction moves 1 KB of useful data for 8 pairs, the softmax over <= 8 keys stays inside
 // the lanes of a group (three DPP steps per dot product), and nothing crosses groups.
-template <int T>      // number of cached keys (t), 0..7
+template <int T, bool KQ = false>      // number of cached keys (t), 0..7; KQ: 8-bit key cache (see quant_key_chunk)
 static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, long pair, bool valid, int cc) {
     const int E = p.E, Tcap = p.Tcap;
     const int b = (int)(pair / p.nh), h = (int)(pair - (long)b * p.nh);
     const bf16_t* qrow = p.qkv + (long)b * 3 * E + h * 64 + cc * 8;
     bf16_t* kc = p.kc + pair * Tcap * 64 + cc * 8;
     bf16_t* vc = p.vc + pair * Tcap * 64 + cc * 8;
+    unsigned char* kc8 = (unsigned char*)p.kc + pair * Tcap * 64 + cc * 8;
+    float* ksc = KQ ? p.ksc + pair * Tcap : nullptr;
     const rq_u128 qv = ld128(qrow), kn = ld128(qrow + E), vn = ld128(qrow + 2 * E);
-    rq_u128 kr[T > 0 ? T : 1], vr[T > 0 ? T : 1];
+    rq_u128 kr[(!KQ && T > 0) ? T : 1], vr[T > 0 ? T : 1];
+    rq_u64w kr8[(KQ && T > 0) ? T : 1];
+    float ksv[(KQ && T > 0) ? T : 1];
 #pragma unroll
-    for (int j = 0; j < T; ++j) kr[j] = ld128(kc + j * 64);
+    for (int j = 0; j < T; ++j) {
+        if constexpr (KQ) { kr8[j] = ld64(kc8 + j * 64); ksv[j] = ksc[j]; }
+        else kr[j] = ld128(kc + j * 64);
+    }
 #pragma unroll
     for (int j = 0; j < T; ++j) vr[j] = ld128(vc + j * 64);
-    if (valid) {                                   // append this token's k / v
+    if constexpr (KQ) {                            // append: key as bytes + scale (every lane takes part in the group reduction)
+        float s_app;
+        const rq_u64w kb = quant_key_chunk(kn, s_app);
+        if (valid) {
+            st64(kc8 + T * 64, kb);
+            if (cc == 0) ksc[T] = s_app;
+            st128(vc + T * 64, vn);
+        }
+    } else if (valid) {                            // append this token's k / v
         st128(kc + T * 64, kn);
         st128(vc + T * 64, vn);
     }
     float qf[8], sc[T + 1];
     unpack8(qv, qf);
     float mx = -__int_as_float(0x7f800000);
+    float qsum128 = 0.f;
+    if constexpr (KQ) {
+        float qs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qs += qf[e];
+        qsum128 = 128.0f * group8_sum(qs);
+    }
 #pragma unroll
     for (int j = 0; j <= T; ++j) {
-        float kf[8];
-        unpack8(j < T ? kr[j < T ? j : 0] : kn, kf);
-        float dot = 0.f;
+        if (KQ && j < T) {
+            sc[j] = (group8_sum(dot_q_bytes(qf, kr8[j < T ? j : 0])) - qsum128) * ksv[j < T ? j : 0] * 0.125f;
+        } else {
+            float kf[8];
+            unpack8((!KQ && j < T) ? kr[(!KQ && j < T) ? j : 0] : kn, kf);
+            float dot = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
-        dot += rq_dpp_xor1(dot);
-        dot += rq_dpp_xor2(dot);
-        dot += rq_dpp_half_mirror(dot);
-        sc[j] = dot * 0.125f;                      // 1/sqrt(64), attentions.py:87
+            for (int e = 0; e < 8; ++e) dot = fmaf(qf[e], kf[e], dot);
+            dot += rq_dpp_xor1(dot);
+            dot += rq_dpp_xor2(dot);
+            dot += rq_dpp_half_mirror(dot);
+            sc[j] = dot * 0.125f;                  // 1/sqrt(64), attentions.py:87
+        }
         mx = fmaxf(mx, sc[j]);
     }
     float sum = 0.f;
@@ -421,6 +530,7 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
     }
 }
 
+template <bool KQ>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long total = (long)p.rows * p.nh;
@@ -429,14 +539,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
     if (!valid) pair = total - 1;                  // clamped loads, masked stores
     const int t = (p.step ? *p.step : 0) + p.step_off;
     switch (t) {
-        case 0: attn_small_run<0>(p, pair, valid, lane & 7); break;
-        case 1: attn_small_run<1>(p, pair, valid, lane & 7); break;
-        case 2: attn_small_run<2>(p, pair, valid, lane & 7); break;
-        case 3: attn_small_run<3>(p, pair, valid, lane & 7); break;
-        case 4: attn_small_run<4>(p, pair, valid, lane & 7); break;
-        case 5: attn_small_run<5>(p, pair, valid, lane & 7); break;
-        case 6: attn_small_run<6>(p, pair, valid, lane & 7); break;
-        case 7: attn_small_run<7>(p, pair, valid, lane & 7); break;
+        case 0: attn_small_run<0, KQ>(p, pair, valid, lane & 7); break;
+        case 1: attn_small_run<1, KQ>(p, pair, valid, lane & 7); break;
+        case 2: attn_small_run<2, KQ>(p, pair, valid, lane & 7); break;
+        case 3: attn_small_run<3, KQ>(p, pair, valid, lane & 7); break;
+        case 4: attn_small_run<4, KQ>(p, pair, valid, lane & 7); break;
+        case 5: attn_small_run<5, KQ>(p, pair, valid, lane & 7); break;
+        case 6: attn_small_run<6, KQ>(p, pair, valid, lane & 7); break;
+        case 7: attn_small_run<7, KQ>(p, pair, valid, lane & 7); break;
         default: rq_trap();                        // host bound violated
     }
 }
@@ -448,11 +558,13 @@ static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t
     // the long-context forms with two pairs were never launched but were compiled, with 104 spilled registers at 32 blocks
     if constexpr (!DYN && NJ <= 4) {
         if (pairs_per_wave == 2) {
-            RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+            if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2, true>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+            else RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
             return;
         }
     }
-    RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1, true>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    else RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
 }
 
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
@@ -466,7 +578,8 @@ int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     static const bool no_small = getenv("RQAMD_NO_ATTN_SMALL") != nullptr;      // A/B switch
     if (nj == 1 && !no_small) {                   // at most 8 keys: eight pairs per wavefront
         const long pairs = (long)a.rows * a.nh;
-        RQ_LAUNCH(attn_small_kernel, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
+        if (a.ksc) RQ_LAUNCH(attn_small_kernel<true>, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
+        else RQ_LAUNCH(attn_small_kernel<false>, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
         return rq_check_launch("attn_small_kernel");
     }
     if (a.Tcap <= 64) {
@@ -505,13 +618,28 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(AttnPrefillArgs p) {
     const bf16_t* q0 = p.qkv + (long)img * P * 3 * E + hh * 64;
     bf16_t* kc = p.kc + (long)pair * p.Tcap * 64;
     bf16_t* vc = p.vc + (long)pair * p.Tcap * 64;
-    for (int idx = lane; idx < P * 8; idx += 64) {
-        const int j = idx >> 3, c = idx & 7;
+    unsigned char* kc8 = (unsigned char*)p.kc + (long)pair * p.Tcap * 64;
+    float* ksc = p.ksc ? p.ksc + (long)pair * p.Tcap : nullptr;
+    for (int i0 = 0; i0 < P * 8; i0 += 64) {          // (whole wavefront per pass: the 8-bit append reduces over the 8 lanes of a key)
+        const int idx = i0 + lane;
+        const bool in = idx < P * 8;                  // whole 8-lane groups: P * 8 is a multiple of 8
+        const int j = in ? idx >> 3 : P - 1, c = idx & 7;
         const rq_u128 kv = ld128(q0 + (long)j * 3 * E + E + c * 8), vv = ld128(q0 + (long)j * 3 * E + 2 * E + c * 8);
-        st128(sK + j * 64 + c * 8, kv);
-        st128(sV + j * 64 + c * 8, vv);
-        st128(kc + j * 64 + c * 8, kv);
-        st128(vc + j * 64 + c * 8, vv);
+        if (ksc) {                                    // uniform: opt-in 8-bit key cache (the prefix attention itself runs on the bf16 keys)
+            float s_app;
+            const rq_u64w kb = quant_key_chunk(kv, s_app);
+            if (in) {
+                st64(kc8 + j * 64 + c * 8, kb);
+                if (c == 0) ksc[j] = s_app;
+            }
+        } else if (in) {
+            st128(kc + j * 64 + c * 8, kv);
+        }
+        if (in) {
+            st128(sK + j * 64 + c * 8, kv);
+            st128(sV + j * 64 + c * 8, vv);
+            st128(vc + j * 64 + c * 8, vv);
+        }
     }
     rq_syncthreads();
     const float NEG_INF = -__int_as_float(0x7f800000);

@@ -199,6 +199,7 @@ static inline void rq_trap() { abort(); }
 static inline float rq_fast_rcp(float x) { return 1.0f / x; }
 static inline float rq_med3(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline float rq_fast_exp2(float x) { return exp2f(x); }
+template <int I> static inline float rq_ubyte_f32(uint32_t w) { return (float)((w >> (8 * I)) & 0xffu); }
 
 static inline float rq_emu_bf16(short v) {
     union { uint32_t u; float f; } c;

@@ -318,6 +318,62 @@ def test_emu_rqt_long_prefix(nat):
     assert e1 < 0.06 and e2 < 0.06
 
 
+def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
+    """Opt-in 8-bit key cache of the body stack (RQAMD_KV=int8k, read when an engine is created): cached keys as
+    64 bytes + one fp32 absmax / 127 scale per (token, head), this token's own key and all values bf16 as before.  Through every
+    attention kernel that has the variant -- <= 8 keys (attn_small), register blocks with one / two heads per wavefront (the
+    diagnostics row factor), the DYN long-context form behind a 69-token prefix, the quantising prefill -- against the
+    reference's logits with the bound of the bf16 cache, and close to the bf16-cache engine; sampling stays inside the support of
+    its own teacher-forced logits; an unknown format name is refused."""
+    g = golden('rqt_tiny.npz')
+    cfg = C.RQT_TINY
+    hps, dd = C.VAE_TINY
+    cb = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed']))['quantizer.codebooks.0.weight'][:-1]
+    params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
+    codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
+    base = _rqt_engine(nat, cfg, params).logits(codes, cond, [T(cb)] * 4).numpy()
+    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    eng = _rqt_engine(nat, cfg, params)
+    logits = eng.logits(codes, cond, [T(cb)] * 4).numpy()
+    err = np.abs(logits - g['logits'])
+    print('emu rqt tiny logits, 8-bit key cache: max err %.4f mean %.5f vs the reference; max %.4f mean %.5f vs the bf16 cache'
+          % (err.max(), err.mean(), np.abs(logits - base).max(), np.abs(logits - base).mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01
+    assert 0 < np.abs(logits - base).max() < 0.02            # the cache format is really in use, and costs little
+    nat.dbg_set_row_scale(4096)                              # two heads per wavefront, large-batch GEMM tiles
+    try:
+        big = eng.logits(codes, cond, [T(cb)] * 4).numpy()
+    finally:
+        nat.dbg_set_row_scale(1)
+    assert np.abs(big - g['logits']).max() < 0.06 and np.abs(big - logits).max() < 0.02
+    # sampling on it
+    partial = torch.zeros((2, 4, 4, 4), dtype=torch.int64)
+    out = eng.sample(partial, cond[:2].contiguous(), [T(cb)] * 4, (0, 0), 1.0, [5] * 4, [0.9] * 4, seed=11, offset=0, use_graph=False)
+    tf = eng.logits(out, cond[:2].contiguous(), [T(cb)] * 4).numpy()
+    for h in range(4):
+        for w in range(4):
+            for d in range(4):
+                pr = oracle.filtered_probs(tf[:, h, w, d], 1.0, 5, 0.9)
+                assert (pr[np.arange(2), out[:, h, w, d].numpy()] > 0).all()
+    # text conditioning: quantising prefill (3 prefix tokens) and the 69-token prefix with the DYN decode kernel
+    gt = golden('rqt_tiny_txt.npz')
+    engt = _rqt_engine(nat, C.RQT_TINY_TXT, oracle.make_params(oracle.rqt_param_shapes(C.RQT_TINY_TXT), int(gt['seed'])))
+    lt = engt.logits(T(gt['codes'].astype(np.int64)), T(gt['cond'].astype(np.int64)), [T(cb)] * 4).numpy()
+    assert np.abs(lt - gt['logits']).max() < 0.06 and np.abs(lt - gt['logits']).mean() < 0.01
+    cfgl = C.rqt(128, 2, 1, 1, 500, vocab_cond=20, block_cond=70, block_size=(4, 4, 4), input_embed_dim=64)
+    pl = oracle.make_params(oracle.rqt_param_shapes(cfgl), 43)
+    rng = np.random.default_rng(44)
+    cbl = rng.standard_normal((500, 64), dtype=np.float32)
+    cl_codes, cl_cond = rng.integers(0, 500, (2, 4, 4, 4)), rng.integers(0, 20, (2, 70))
+    seq, _ = _rqt_engine(nat, cfgl, pl).forward(T(cl_codes), T(cl_cond), [T(cbl)] * 4)
+    ref = oracle.RQTransformerOracle(cfgl, pl).forward(cl_codes, [cbl] * 4, cl_cond, return_cond_logits=True)
+    print('emu rqt long prefix, 8-bit key cache: seq logits err %.4f' % np.abs(seq.numpy() - ref[0]).max())
+    assert np.abs(seq.numpy() - ref[0]).max() < 0.06
+    monkeypatch.setenv('RQAMD_KV', 'fp8')
+    with pytest.raises(Exception):
+        _rqt_engine(nat, cfg, params)
+
+
 @pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias'])
 def test_emu_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding + BatchLinear + per-depth vocabularies; cumsum_depth_ctx off; learned head

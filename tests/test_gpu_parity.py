@@ -360,6 +360,34 @@ def test_rqt_cached_forward_steps(nat, golden):
         ar.cached_forward(codes[:, :1], vae, cond=cond, sample_loc=(0, 0, 2))
 
 
+def test_rqt_int8k_key_cache_tiny(nat, golden, monkeypatch):
+    """Opt-in 8-bit key cache (RQAMD_KV=int8k) on the tiny fixtures: logits vs the reference with the bf16 bound and close to the
+    bf16-cache engine, the text-conditioned shape (quantising prefill), sample(): hipGraph == eager, cached == uncached."""
+    g = golden('rqt_tiny.npz')
+    vae, _, ar0, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    base = N(ar0(codes, vae, cond=cond))
+    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    _, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    logits = N(ar(codes, vae, cond=cond))
+    err = np.abs(logits - g['logits'])
+    print('rqt tiny logits, 8-bit key cache: max err %.4f mean %.5f vs the reference; max %.4f vs the bf16 cache'
+          % (err.max(), err.mean(), np.abs(logits - base).max()))
+    assert err.max() < 0.03 and err.mean() < 0.005
+    assert 0 < np.abs(logits - base).max() < 0.02
+    res = []
+    for graph, cached in ((True, True), (False, True), (False, False)):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(5)
+        res.append(ar.sample(torch.zeros_like(codes), vae, cond=cond, top_k=50, top_p=0.9, cached=cached))
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    gt = golden('rqt_tiny_txt.npz')
+    _, _, art, _ = _models(C.VAE_TINY, C.RQT_TINY_TXT, int(gt['vae_seed']), int(gt['seed']))
+    out = art(G(gt['codes'], torch.long), vae, cond=G(gt['cond'], torch.long))
+    lt = N(out[0] if isinstance(out, tuple) else out)
+    assert np.abs(lt - gt['logits']).max() < 0.03
+
+
 def test_rqt_real_width_logits_vs_oracle(nat):
     """E=1536 / 24 heads / V=16384 (the 1.4B layer shapes), 2 body + 1 head layers, B=3."""
     cfg = C.RQT_WIDE

@@ -172,6 +172,53 @@ def test_rqt_in1400m_through_the_benchmarked_kernels(golden):
     torch.cuda.empty_cache()
 
 
+def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch):
+    """Opt-in 8-bit key cache (RQAMD_KV=int8k) on the full 1.4B model against the REFERENCE's logits with the bound of
+    the bf16 cache: 2 rows (small-batch kernels, <= 8-key and register-block attention forms) and 2050 rows through the kernels of the
+    bench batch (two heads per wavefront at short contexts).  Costed in round 4 on the reference model itself: 0.0053 max / 0.00063 mean
+    added by 8-bit keys alone, what bf16 storage adds (profiles/r04_kv_cache_precision_costing.txt)."""
+    from rqvae import _native
+    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    g = golden('rqt_in1400m.npz')
+    cfg = C.RQT_IN_1400M
+    ar = _load(cfg, int(g['seed']))
+    V, D = cfg['vocab_size'], cfg['block_size'][2]
+    cb = np.random.default_rng(int(g['cb_seed'])).standard_normal((V, 256), dtype=np.float32)
+    aux = Aux(cb, D)
+    ref = g['logits'].astype(np.float32)
+    codes2, cond2 = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    out = ar(codes2, aux, cond=cond2)
+    got = torch.stack([out[:, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+    err = np.abs(got - ref)
+    print(f'rqt in1400m, 8-bit key cache: logits max err {err.max():.4f} mean {err.mean():.5f}')
+    assert err.max() < MAX_ERR and err.mean() < MEAN_ERR
+    reps = 1025
+    codes = G(np.tile(g['codes'], (reps, 1, 1, 1)), torch.long)
+    cond = G(np.tile(g['cond'], (reps, 1)), torch.long)
+    _native.dbg_set_row_scale(5)
+    try:
+        out = ar(codes, aux, cond=cond)
+    finally:
+        _native.dbg_set_row_scale(1)
+    worst = 0.0
+    for r0 in (0, 1024, 2048):
+        gb = torch.stack([out[r0:r0 + 2, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+        worst = max(worst, float(np.abs(gb - ref).max()))
+        assert np.abs(gb - ref).mean() < MEAN_ERR
+    print(f'rqt in1400m, 8-bit key cache, through the large-batch kernels (2050 rows): logits max err {worst:.4f}')
+    assert worst < MAX_ERR
+    # sampling on it: graph == eager, codes in range
+    part = torch.zeros_like(codes2)
+    res = []
+    for graph in (True, False):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(77)
+        res.append(ar.sample(part, aux, cond=cond2, top_k=1024, top_p=0.95))
+    assert torch.equal(res[0], res[1]) and int(res[0].min()) >= 0 and int(res[0].max()) < V
+    del out, ar
+    torch.cuda.empty_cache()
+
+
 def test_rqt_in1400m_sample_through_the_benchmarked_kernels(golden):
     """The timed configuration end to end: RQTransformer.sample on the full 1.4B model with bench.py's
     sampling settings (top-k 1024 / top-p 0.95), kernel selection seeing the bench batch (2050 rows x 5 = 10250: 256 x 256
