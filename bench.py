@@ -871,6 +871,29 @@ def main(argv=None):
             print(f'bench.py: --also {args.also!r} failed: {e!r}', file=sys.stderr)
             also.append({'error': repr(e)})
 
+    # ---- the opt-in 8-bit key cache next to the default bf16 one ("report both ways"), same model, one moderate batch, measured live;
+    # the headline batch both ways: profiles/r05_kv_int8k_ab.txt.  Engines read RQAMD_KV when they are created.
+    kv_formats = None
+    if rank == 0 and world == 1 and args.also and args.model == 'huge' and not args.overlap and os.environ.get('RQAMD_KV', 'bf16') == 'bf16':
+        kv_formats = []
+        try:
+            for fmt in ('bf16', 'int8k'):
+                os.environ['RQAMD_KV'] = fmt
+                _, ar3, cfg3 = presets.build('huge', device=device, seed=0)
+                ips, a_ms, d_ms, es, ec = timed_batch(vae, ar3, 2048, device, args.top_k, args.top_p, steps=2, warmup=1)
+                kv_formats.append({'kv_cache': fmt, 'batch_per_gpu': 2048, 'images_per_sec': ips, 'ar_ms_per_image': a_ms,
+                                   'kv_bytes_per_image_GB': kv_bytes_per_image(cfg3) / 1e9})
+                if getattr(ar3, '_engine', None) is not None:
+                    ar3._engine.close()
+                    ar3._engine = None
+                del ar3, es, ec
+                torch.cuda.empty_cache()
+        except Exception as e:
+            print(f'bench.py: kv-cache format comparison failed: {e!r}', file=sys.stderr)
+            kv_formats.append({'error': repr(e)})
+        finally:
+            os.environ.pop('RQAMD_KV', None)
+
     if rank == 0:
         n_img = world * B * args.steps
         value = n_img / elapsed
@@ -909,7 +932,7 @@ def main(argv=None):
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
             'verified': None if verify is None else verify['verified'], 'verify': verify,
             'roofline': roofline, 'roofline_attn': roofline_attn, 'roofline_decode': roofline_decode,
-            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'kv_cache_formats': kv_formats, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
