@@ -163,3 +163,26 @@ def test_bench_gather_plan_and_multi_gpu_defaults():
     note = bench.parallelism_note(8, 10752)
     assert f'{calls} all-gathers' in note and 'keeps only the last gathered slice' in note
     assert bench.DEFAULT_BATCH_MULTI == {'xhuge': 64, 'txt3900m': 64} and 'huge' not in bench.DEFAULT_BATCH_MULTI
+
+
+def test_read_ahead_torch_attributes():
+    """RQVAE's read-ahead behind per-row calls (rqvae/models/rqvae/rqvae.py: _ReadAhead) recognises "row i of the batch the previous call
+    saw" through two PRIVATE torch attributes: `Tensor._base` (a view's base tensor) and `Tensor._version` (bumped by in-place edits).
+    If a torch release drops or changes either, the window logic must be revisited -- this test fails first."""
+    import torch
+    base = torch.zeros((4, 3))
+    row = base[1:2]
+    assert hasattr(row, '_base') and row._base is base and base._base is None
+    v0 = base._version
+    base[2].add_(1.0)
+    assert base._version > v0 and row._version == base._version          # views share the version counter of their base
+    from rqvae.models.rqvae import rqvae as rqvae_mod
+    assert hasattr(rqvae_mod, '_ReadAhead')
+    with torch.inference_mode():
+        t = torch.zeros((2, 2))
+    try:                                                                  # inference tensors have no version counter: the read-ahead steps aside
+        t._version
+        has_version = True
+    except RuntimeError:
+        has_version = False
+    assert has_version is False
