@@ -236,6 +236,9 @@ int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const float* bias, co
 /* One launch of the MFMA Decoder.conv_out kernel (modules.py:165-169): x NHWC bf16 [B][H][W][Cin], w fp32
  * [Cout][3][3][Cin] (Cout <= 4), y NCHW fp32 [B][Cout][H][W]; gn as above (norm_out + swish fused into the
  * staging).  Needs H % 4 == 0, W % 32 == 0, Cin in {64, 128, 256}. */
+/* diagnostics: w (Cout,3,3,Cin) bf16 -> wsub (4,Cout,2,2,Cin) bf16, the pre-summed weights of the sub-pixel form of Upsample.conv
+ * (layers.py:20-35: nearest 2x + 3x3 conv = four 2x2 convs over the source image); rqamd_dbg_conv_halo_bf16 takes them with ups bit 6 set */
+int rqamd_dbg_ups_subpixel_weights(const void* w, int Cout, int Cin, void* wsub, void* stream);
 int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,
                             int Cin, int Cout, float* y, void* stream);
 

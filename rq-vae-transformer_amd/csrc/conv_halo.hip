@@ -564,13 +564,22 @@ constexpr int PK_RED = 8 * 16 * 4 * 4;                             // statistics
 static_assert(PK_P0 + PK_PATCH + PK_TILE + PK_RED <= PK_SMEM, "epilogue tile over spare + P1");
 static_assert(PK_P0 + PK_TILE + PK_RED <= PK_P1, "epilogue tile over P0 + spare");
 
-struct HaloTile { int img, ty0, tx0, n0, trem; };
+struct HaloTile { int img, ty0, tx0, n0, trem, cls; };      // (UPS = 2: ty0 / tx0 in SOURCE pixels, cls = output parity (oy & 1) * 2 + (ox & 1))
 
+// UPS = 2 (round 5): the nearest-2x upsample conv by SUB-PIXEL DECOMPOSITION.  Output pixel (2y + py, 2x + px) of a 3 x 3 conv over the
+// upsampled image reads source rows y + py - 1 and y + py only (taps ky = 0 | 1, 2 for py = 0; 0, 1 | 2 for py = 1) and likewise two
+// source columns: for each of the four output parities the layer is a 2 x 2 conv over the SOURCE image with the taps that share a
+// source pixel summed -- 4 taps per output pixel instead of 9.  A tile is one parity class of an 8 x 32 block of source pixels (256
+// output pixels, the 16 x 64 output block's every-other-pixel lattice): the plain kernel's patch geometry, four taps per chunk at patch
+// offsets (py + a, px + b), weights from the pre-summed tensor [class][Cout][2][2][Cin] (ups_subpixel_weights_kernel), outputs and
+// statistics written to the class's lattice.
 template <int FUSE_GN, int UPS, int RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p, int wpx) {
-    constexpr int TH = HT_H, NTH = 512, RPW = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3;
+    constexpr int TH = HT_H, NTH = 512, RPW = 2, W_IT = 2, TPX = TH * HT_W;
+    constexpr bool SUB = UPS == 2;
+    constexpr int TAPS = SUB ? 4 : 9, W_SETS = SUB ? 4 : 3;           // (W_SETS divides TAPS: the register-set rotation is static under the unrolled tap loop)
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
-    constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
+    constexpr int PW = UPS == 1 ? HT_W / 2 + 2 : HP_W, PH = UPS == 1 ? TH / 2 + 2 : TH + 2;
     constexpr int HP_N = PW * PH;
     constexpr int H_IT = (HP_N * 8 + NTH - 1) / NTH;
     RQ_DYN_SMEM(smem);
@@ -580,8 +589,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     const int wm = wave >> 1, wn = wave & 1;
 
     // ---- this workgroup's tiles: slots w, w + wpx, ... of its XCD's contiguous band (neighbours share halo rows in that L2)
-    const int tiles_x = p.W / HT_W, tiles_y = p.H / TH, NT = p.Cout / H_BN;
-    const int n_mt = p.B * tiles_y * tiles_x;
+    // (SUB: tiles of the SOURCE image x 4 parity classes, classes adjacent: the four tiles of a source block share its patch in the L2)
+    const int tiles_x = (SUB ? p.W >> 1 : p.W) / HT_W, tiles_y = (SUB ? p.H >> 1 : p.H) / TH, NT = p.Cout / H_BN;
+    constexpr int NCLS = SUB ? 4 : 1;
+    const int n_mt = p.B * tiles_y * tiles_x * NCLS;
     const int xcd = blockIdx.x & 7, w0 = blockIdx.x >> 3;
     const int per = (n_mt + 7) >> 3, nslot = per * NT;
     auto slot_ok = [&](int s) { return s < nslot && xcd * per + s / NT < n_mt; };
@@ -589,10 +600,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         HaloTile t;
         const int mtile = xcd * per + s / NT;
         t.n0 = (s - (s / NT) * NT) * H_BN;
-        t.img = mtile / (tiles_y * tiles_x);
-        t.trem = mtile - t.img * (tiles_y * tiles_x);
-        t.ty0 = (t.trem / tiles_x) * TH;
-        t.tx0 = (t.trem - (t.trem / tiles_x) * tiles_x) * HT_W;
+        const int st = SUB ? mtile >> 2 : mtile;
+        t.cls = SUB ? mtile & 3 : 0;
+        t.img = st / (tiles_y * tiles_x);
+        const int trem = st - t.img * (tiles_y * tiles_x);
+        t.trem = trem * NCLS + t.cls;                      // index of the tile's statistics partial inside its image
+        t.ty0 = (trem / tiles_x) * TH;
+        t.tx0 = (trem - (trem / tiles_x) * tiles_x) * HT_W;
         return t;
     };
     int slot = w0;
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
             const int hp = q >> 3, c8 = q & 7;
             const bool in = hp < HP_N;
             const int hy = hp / PW, hx = hp - hy * PW;
-            const int gy = (UPS ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS ? t.tx0 >> 1 : t.tx0) + hx - 1;
+            const int gy = (UPS == 1 ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS == 1 ? t.tx0 >> 1 : t.tx0) + hx - 1;
             const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
             const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
             const unsigned loff16 = in ? halo_lds_off<PW>(hy, hx, c8) >> 4 : 0u;
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
 #pragma unroll
         for (int it = 0; it < H_IT; ++it) {
             const unsigned in = (hd[it] >> 30) & 1u, lo = hd[it] & 0x1fff0000u;
-            const int gy = (UPS ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS ? t.tx0 >> 1 : t.tx0) + hx - 1;
+            const int gy = (UPS == 1 ? t.ty0 >> 1 : t.ty0) + hy - 1, gx = (UPS == 1 ? t.tx0 >> 1 : t.tx0) + hx - 1;
             const bool ok = in && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
             const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
             hd[it] = (unsigned)(cy * Ws + cx) | lo | (ok ? 1u << 29 : 0u) | (in << 30);
@@ -651,10 +665,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
         const int r = w_row + (NTH / 8) * i;
-        w_goff[i] = (unsigned)(((long)r * 9 * p.Cin + w_c8 * 8) * 2);
+        w_goff[i] = (unsigned)(((long)r * TAPS * p.Cin + w_c8 * 8) * 2);
         w_loff[i] = (unsigned)(r * 128 + ((w_c8 ^ ((r >> 1) & 7)) << 4));
     }
-    const unsigned w_per_n = 9u * (unsigned)p.Cin * 2u;            // bytes per output channel
+    const unsigned w_per_n = (unsigned)TAPS * (unsigned)p.Cin * 2u;            // bytes per output channel
+    const unsigned w_per_cls = (unsigned)p.Cout * w_per_n;                   // SUB: bytes per parity class of the pre-summed weights
     const char* gX = (const char*)p.x;
     const char* gWt = (const char*)p.w;
 
@@ -707,7 +722,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     unsigned rd_h0[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
-        rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
+        rd_h0[kx] = UPS == 1 ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
+    // SUB: tap (a, b) of parity class (py, px) reads patch pixel (row + py + a, col + px + b): per tile, the two column bases with the
+    // class's row offset folded in (a multiple of 128 bytes: the swizzle bits are untouched)
+    unsigned rd_hs[2] = {0u, 0u};
+    auto set_class = [&](int cls) {
+        const unsigned rowoff = (unsigned)((cls >> 1) * (PW * 128));
+        rd_hs[0] = ((cls & 1) ? rd_h0[1] : rd_h0[0]) + rowoff;
+        rd_hs[1] = ((cls & 1) ? rd_h0[2] : rd_h0[1]) + rowoff;
+    };
 
     f32x16 acc[RPW][2];
     // accumulators start from the bias of the tile's output channels (as in conv3x3_halo_kernel)
@@ -726,14 +749,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     // one tap: four k-steps on two fragment sets in ping-pong (the reads of k-step ks + 1 are issued ahead of the MFMAs of k-step
     // ks, held there by opaque accumulators as in conv3x3_halo_kernel; with one set every k-step waited out its own LDS round trip)
     auto compute = [&](int hbuf, int wbuf, int ky, int kx, rq_u128* rhp, int pit) {      // pit >= 0: patch piece normalised under this tap
-        const unsigned ha = rd_h0[kx] + (unsigned)(hbuf * PK_PSTRIDE);
+        const unsigned ha = (SUB ? rd_hs[kx] : rd_h0[kx]) + (unsigned)(hbuf * PK_PSTRIDE);          // (SUB: ky, kx = the tap's (a, b) in 0..1)
         const unsigned wa = rd_w0 + (unsigned)(wbuf * HW_BYTES);
         bf16x8 af[2][RPW], bfr[2][2];
         auto load_frags = [&](int ks, bf16x8* a, bf16x8* b) {
             const char* hb = sH + (ha ^ (unsigned)(ks << 5));
             const char* wb = sW + (wa ^ (unsigned)(ks << 5));
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) a[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
+            for (int i = 0; i < RPW; ++i) a[i] = as_bf16x8(ld128(hb + (UPS == 1 ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[j] = as_bf16x8(ld128(wb + j * (32 * 128)));
         };
@@ -779,17 +802,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     HaloTile cur = decode(slot), nxt = cur;
     bool has_next = slot_ok(slot + wpx);
     if (has_next) nxt = decode(slot + wpx);
-    unsigned wn_cur = (unsigned)cur.n0 * w_per_n, wn_nxt = (unsigned)nxt.n0 * w_per_n;
+    unsigned wn_cur = (unsigned)cur.n0 * w_per_n + (unsigned)cur.cls * w_per_cls, wn_nxt = (unsigned)nxt.n0 * w_per_n + (unsigned)nxt.cls * w_per_cls;
     set_staging(cur);
+    if (SUB) set_class(cur.cls);
     acc_from_bias(cur.n0);
     load_halo(0, rh);
     // weight units run on across tiles: unit (c, tap) of the tile, then (0, 0..) of the next one; always set tap % 3
     auto load_unit = [&](int c, int tap, rq_u128* r) {
         unsigned nb = wn_cur;
-        if (tap >= 9) { tap -= 9; ++c; }
+        if (tap >= TAPS) { tap -= TAPS; ++c; }
         if (c > last_c) {
             if (has_next) { c = 0; nb = wn_nxt; }
-            else { c = last_c; tap = 8; }           // past the end of this workgroup's work: harmless reload
+            else { c = last_c; tap = TAPS - 1; }    // past the end of this workgroup's work: harmless reload
         }
         load_w(nb, c, tap, r);
     };
@@ -804,7 +828,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
 
     int tid_o = tid;                               // opaque per-tile copy of the thread index (see the tile loop)
     unsigned io_off0 = 0;                          // byte offset of this thread's piece 0 of the current tile's residual / output
-    const unsigned io_step = (unsigned)p.W * (unsigned)p.Cout * 2u;
+    const unsigned io_step = (unsigned)p.W * (unsigned)p.Cout * (SUB ? 4u : 2u);      // (SUB: consecutive tile rows are two output rows apart)
 #ifdef RQ_CONV_TRACE
     int trace_tile = 0;
 #define RQ_CTP(slot) do { if (blockIdx.x == (RQ_CONV_TRACE & 255) && trace_tile == 2 && lane == 0 && (slot) < 64) g_conv_trace[wave * 64 + (slot)] = __builtin_readcyclecounter(); } while (0)
@@ -822,28 +846,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 for (int it = 0; it < H_IT; ++it) hd[it] = 0u;
             }
         }
-        constexpr int PPT = (H_IT + 7) / 8, NPT = (H_IT + PPT - 1) / PPT, FIRST = 9 - NPT;
-        static_assert(R_IT <= 8, "one residual piece per tap");
+        // patch pieces of the next chunk: PPT per tap in the chunk's last NPT taps (9 taps: one per tap; SUB, 4 taps: two per tap)
+        constexpr int PPT = (H_IT + TAPS - 2) / (TAPS - 1), NPT = (H_IT + PPT - 1) / PPT, FIRST = TAPS - NPT;
+        static_assert(R_IT <= 8 && FIRST >= 0, "one residual piece per tap; the pieces fit the chunk's taps");
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = SUB ? tap >> 1 : tap / 3, kx = SUB ? tap & 1 : tap - ky * 3;
             // loads spread over the taps as in conv3x3_halo_kernel: weight tile three units ahead, patch piece `it` three taps
             // before the tap that normalises and stores it, one residual piece per tap of the last chunk
             load_unit(c, tap + W_SETS, rw[tap % W_SETS]);
             if (tap == 0) load_gs(LAST ? 0 : c + 1);
 #pragma unroll
             for (int it = 0; it < H_IT; ++it) {
-                const int t_use = FIRST + it / PPT, t_load = t_use >= 3 ? t_use - 3 : 0;
+                constexpr int AHEAD = SUB ? 2 : 3;            // taps between a piece's request and its store
+                const int t_use = FIRST + it / PPT, t_load = t_use >= AHEAD ? t_use - AHEAD : 0;
                 if (t_load == tap) load_halo_piece(LAST ? 0 : c + 1, rh, it);
             }
             if (LAST && RES && tap >= 1) rr[tap - 1] = ld128((const char*)p.resid + (io_off0 + (unsigned)(tap - 1) * io_step));
             rq_sched_barrier();
             const bool ptap = tap >= FIRST;
-            static_assert(PPT == 1, "one patch piece per tap");
+            static_assert(PPT == 1 || !FUSE_GN, "the fused form normalises one patch piece per tap");
             if (FUSE_GN) {
                 compute(hbuf, wbuf, ky, kx, rh, ptap && tap - FIRST < H_IT ? tap - FIRST : -1);
             } else {
-                if (ptap && tap - FIRST < H_IT) rh[tap - FIRST] = halo_piece_value(rh, tap - FIRST);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int it = (tap - FIRST) * PPT + k;
+                    if (ptap && it < H_IT) rh[it] = halo_piece_value(rh, it);
+                }
                 compute(hbuf, wbuf, ky, kx, rh, -1);
             }
             store_w(wbuf ^ 1, rw[(tap + 1) % W_SETS]);
@@ -867,7 +897,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         rq_opaque(tid_o);
         // piece k of a thread = 16-byte chunk (tid & 15) of pixel (tid >> 4) of tile row k, residual and output alike
         static_assert(CPR == 16 && NTH / CPR == HT_W && R_IT == TH, "piece k = tile row k");
-        io_off0 = (unsigned)((((long)cur.img * p.H + cur.ty0) * p.W + cur.tx0 + (tid_o >> 4)) * p.Cout + cur.n0 + (tid_o & 15) * 8) * 2u;
+        if (SUB)      // output pixel (2 (ty0 + k) + py, 2 (tx0 + column) + px) of the class's lattice
+            io_off0 = (unsigned)((((long)cur.img * p.H + 2 * cur.ty0 + (cur.cls >> 1)) * p.W + 2 * (cur.tx0 + (tid_o >> 4)) + (cur.cls & 1)) * p.Cout + cur.n0 + (tid_o & 15) * 8) * 2u;
+        else
+            io_off0 = (unsigned)((((long)cur.img * p.H + cur.ty0) * p.W + cur.tx0 + (tid_o >> 4)) * p.Cout + cur.n0 + (tid_o & 15) * 8) * 2u;
         RQ_CTP(1);
         for (int c = 0; c + 1 < NC; ++c) run_chunk(c, std::false_type{});
         run_chunk(NC - 1, std::true_type{});
@@ -949,7 +982,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 const bool writer = gsz == 4 ? true : (gsz == 8 ? pair == 0 : (pair == 0 && (chunk & 1) == 0));
                 if (writer && lane_o < 32) {
                     const int g = (cur.n0 + chunk * 8 + pair * 4) / gsz;
-                    const int tiles = tiles_x * tiles_y;
+                    const int tiles = tiles_x * tiles_y * NCLS;
                     float* o = p.stats + (((long)cur.img * tiles + cur.trem) * 32 + g) * 2;
                     o[0] = a;
                     o[1] = q;
@@ -968,12 +1001,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         // first tap it would also cover that tap's fresh prefetches (6400 instead of 1650 cycles for the tap,
         // profiles/r02_conv_halo_barrier_timeline.txt).
         rq_use(rw[1][0].x, rw[1][1].x, rw[2][0].x, rw[2][1].x);
+        if (SUB) rq_use(rw[W_SETS - 1][0].x, rw[W_SETS - 1][1].x, rw[W_SETS - 1][0].y, rw[W_SETS - 1][1].y);
         rq_use(acc[0][0][0], acc[RPW - 1][1][15]);
         slot += wpx;
         cur = nxt;
         wn_cur = wn_nxt;
+        if (SUB) set_class(cur.cls);
         has_next = slot_ok(slot + wpx);
-        if (has_next) { nxt = decode(slot + wpx); wn_nxt = (unsigned)nxt.n0 * w_per_n; }
+        if (has_next) { nxt = decode(slot + wpx); wn_nxt = (unsigned)nxt.n0 * w_per_n + (unsigned)nxt.cls * w_per_cls; }
     }
 }
 
@@ -1358,6 +1393,36 @@ __global__ __launch_bounds__(256) void gn_params_kernel(const float* part, const
     }
 }
 
+// Pre-summed weights of the sub-pixel form (conv3x3_halo_pk_kernel<0, 2, 0>): w [Cout][3][3][Cin] bf16 -> wsub [4][Cout][2][2][Cin] bf16,
+// wsub[py * 2 + px][co][a][b][ci] = sum of w[co][ky][kx][ci] over the taps (ky, kx) that read source pixel (y + py - 1 + a, x + px - 1 + b)
+// from output pixel (2y + py, 2x + px): ky in {0} | {1, 2} for py = 0, {0, 1} | {2} for py = 1, likewise kx.  Summed in fp32, rounded once.
+__global__ void ups_subpixel_weights_kernel(const bf16_t* w, bf16_t* wsub, int Cout, int Cin) {
+    const long n = (long)4 * Cout * 4 * Cin;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const int ci = (int)(gid % Cin);
+    long r = gid / Cin;
+    const int tap = (int)(r & 3); r >>= 2;
+    const int co = (int)(r % Cout);
+    const int cls = (int)(r / Cout);
+    const int py = cls >> 1, px = cls & 1, a = tap >> 1, b = tap & 1;
+    const int ky_lo = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky_hi = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int kx_lo = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx_hi = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int ky = ky_lo; ky <= ky_hi; ++ky)
+        for (int kx = kx_lo; kx <= kx_hi; ++kx) acc += bf16_to_f32(w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci]);
+    wsub[gid] = f32_to_bf16(acc);
+}
+int rq_launch_ups_subpixel_weights(const bf16_t* w, bf16_t* wsub, int Cout, int Cin, hipStream_t s) {
+    const long n = (long)16 * Cout * Cin;
+    RQ_LAUNCH(ups_subpixel_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wsub, Cout, Cin);
+    return rq_check_launch("ups_subpixel_weights_kernel");
+}
+// the sub-pixel form needs whole 8 x 32 tiles of the SOURCE image
+bool rq_conv_halo_subpixel_supported(int H, int W, int Cin, int Cout) {
+    return rq_conv_halo_supported(H, W, Cin, Cout) && (H >> 1) % HT_H == 0 && (W >> 1) % HT_W == 0;
+}
+
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout) {
     return H % HT_H == 0 && W % HT_W == 0 && Cin % 64 == 0 && Cout % H_BN == 0 && H >= 32 && H * W <= 65536;      // (whether it pays below 64^2: engine_vae.hip)
 }
@@ -1392,6 +1457,25 @@ static int launch_conv_halo_th(const ConvHaloArgs& a, int ups, hipStream_t s) {
     // (the persistent forms of the plain / fused convs are not compiled: 0 ... -3 % in round 2; again in round 3 with the GroupNorm
     // words dealt out under the MFMAs -- bit-identical, +2 % (GN) ... +9 % (GN + residual) slower, 256 registers with spills in
     // its prologue / epilogue: profiles/r03_conv_halo_persist_fused_ab.txt)
+    if (ups == 2) {
+        // sub-pixel form of the upsample conv (a.w = the pre-summed weights): persistent, tiles = source tiles x 4 parity classes
+        static RqDeviceOnce sub_once;
+        static int cus_per_xcd_s[16];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (sub_once.first()) {
+            (void)hipFuncSetAttribute((const void*)conv3x3_halo_pk_kernel<0, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PK_SMEM);
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+            cus_per_xcd_s[dev & 15] = cus / 8;
+        }
+        const int n_sub = a.B * ((a.H >> 1) / TH) * ((a.W >> 1) / HT_W) * 4;
+        const int slots = ((n_sub + 7) / 8) * NT;
+        int wpx = g_conv_halo_dbg_wpx > 0 ? g_conv_halo_dbg_wpx : cus_per_xcd_s[dev & 15];
+        if (wpx > slots) wpx = slots;
+        RQ_LAUNCH((conv3x3_halo_pk_kernel<0, 2, 0>), dim3(8 * wpx), dim3(512), PK_SMEM, s, a, wpx);
+        return rq_check_launch("conv3x3_halo_pk_kernel<subpixel>");
+    }
     if (ups && halo_persistent(ups)) {
         // persistent form: one workgroup per CU, each walking every wpx-th slot of its XCD's band
         static RqDeviceOnce pk_once;
@@ -1423,6 +1507,7 @@ int rq_launch_conv_halo(const bf16_t* x, const bf16_t* w, const float* bias, con
     if (stats && Cout != 128 && Cout != 256 && Cout != 512) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: fused statistics need Cout 128/256/512");
     if (!rq_conv_halo_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: shape %dx%d %d->%d", H, W, Cin, Cout);
     if (ups && (gn || resid)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: the upsample conv takes no GroupNorm / residual");
+    if (ups == 2 && !rq_conv_halo_subpixel_supported(H, W, Cin, Cout)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: sub-pixel form at %dx%d", H, W);
     if (2.0 * B * H * W * (Cin > Cout ? Cin : Cout) >= 4294967296.0) return rq_fail(RQAMD_ERR_UNSUPPORTED, "conv_halo: tensor larger than 4 GiB");
     ConvHaloArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.gn = gn; a.resid = resid; a.out = out; a.stats = stats; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -1444,11 +1529,17 @@ extern "C" int rqamd_dbg_conv_halo_bf16(const void* x, const void* w, const floa
     if (!x || !w || !bias || !out) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_halo: null argument");
     g_conv_halo_dbg_pk = (ups & 16) ? 1 : (ups & 32) ? -1 : 0;                    // bits 4 / 5: persistent / per-tile form of the 8-row kernel
     g_conv_halo_dbg_wpx = (ups >> 8) & 0xff;                                      // bits 8..15: workgroups per XCD (0 = one per CU)
+    // bit 6: the sub-pixel form of the upsample conv (`w` = the pre-summed weights of rqamd_dbg_ups_subpixel_weights)
     const int rc = rq_launch_conv_halo((const bf16_t*)x, (const bf16_t*)w, bias, gn, (const bf16_t*)resid, (bf16_t*)out, stats, B, H, W,
-                                       Cin, Cout, ups & 1, (hipStream_t)stream);
+                                       Cin, Cout, (ups & 64) ? 2 : (ups & 1), (hipStream_t)stream);
     g_conv_halo_dbg_pk = 0;
     g_conv_halo_dbg_wpx = 0;
     return rc;
+}
+
+extern "C" int rqamd_dbg_ups_subpixel_weights(const void* w, int Cout, int Cin, void* wsub, void* stream) {
+    if (!w || !wsub) return rq_fail(RQAMD_ERR_INVALID, "dbg_ups_subpixel_weights: null argument");
+    return rq_launch_ups_subpixel_weights((const bf16_t*)w, (bf16_t*)wsub, Cout, Cin, (hipStream_t)stream);
 }
 
 extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const float* bias, const float* gn, int B, int H, int W,

@@ -29,7 +29,7 @@ struct rqamd_vae {
     size_t cap_elems = 0;
     int chunk = 0;
     int chunk_max = 128;
-    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false, no_splitk = false;
+    bool no_halo = false, no_fuse_gn = false, no_fuse_stats = false, no_halo_ups = false, no_splitk = false, no_ups_subpixel = false;
     bool halo_lowres = true;       // 32^2 layers take the halo kernel like the >= 64^2 ones (RQAMD_HALO_LOWRES=0: implicit GEMM there)
     static constexpr int SPLIT_MAX_B = 8;      // calls of at most this many images divide the K loop of low-resolution convs over workgroups
     std::string missing;
@@ -66,6 +66,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_fuse_gn = getenv("RQAMD_NO_FUSE_GN") != nullptr;
     h->no_fuse_stats = getenv("RQAMD_NO_FUSE_STATS") != nullptr;
     h->no_halo_ups = getenv("RQAMD_NO_HALO_UPS") != nullptr;
+    h->no_ups_subpixel = getenv("RQAMD_NO_UPS_SUBPIXEL") != nullptr;      // A/B switch: the 9-tap folded-upsample form everywhere
     h->no_splitk = getenv("RQAMD_VAE_NO_SPLITK") != nullptr;
     if (const char* e = getenv("RQAMD_HALO_LOWRES")) h->halo_lowres = atoi(e) != 0;
     if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
@@ -114,7 +115,17 @@ extern "C" int rqamd_vae_set_param(rqamd_vae* h, const char* name, const float* 
         }
         DevBuf* d = vae_slot(h, s, n * 2);
         if (!d) return RQAMD_ERR_HIP;
-        return rq_launch_repack_conv(src, d->p, O, I, kh, kw, 0, st);
+        RQ_TRY(rq_launch_repack_conv(src, d->p, O, I, kh, kw, 0, st));
+        // Upsample.conv (layers.py:20-35): also the pre-summed weights of its sub-pixel form (four 2 x 2 convs over the source image,
+        // conv_halo.hip), kept next to the 3 x 3 ones -- which form runs is decided per layer shape in VaeRun::conv
+        static const char* up_leaf = ".upsample.conv.weight";
+        const size_t ul = strlen(up_leaf);
+        if (kh == 3 && kw == 3 && s.size() > ul && s.compare(s.size() - ul, ul, up_leaf) == 0) {
+            DevBuf* ds = vae_slot(h, s + ".subpixel", (size_t)16 * O * I * 2);
+            if (!ds) return RQAMD_ERR_HIP;
+            RQ_TRY(rq_launch_ups_subpixel_weights(d->as<bf16_t>(), ds->as<bf16_t>(), O, I, st));
+        }
+        return RQAMD_OK;
     }
     if (ndim == 1) {
         const size_t n = (size_t)shape[0];
@@ -189,8 +200,15 @@ struct VaeRun {
         if (ks == 3 && stride == 1 && (!ups || (epi == EPI_BF16 && !h->no_halo_ups)) && (epi == EPI_BF16 || epi == EPI_BF16_RESID) &&
             halo_here(Hin, Win, Cin, Cout)) {
             const bool st_ok = !h->no_fuse_stats && (Cout == 128 || Cout == 256 || Cout == 512) && stat_fits(Hin, Win);
+            // the upsample conv as four 2 x 2 convs over the source image (round 5: 4 taps per output pixel instead of 9) wherever the
+            // source image has whole 8 x 32 tiles -- a function of the layer, like every other kernel choice here
+            int form = ups;
+            if (ups && !h->no_ups_subpixel && rq_conv_halo_subpixel_supported(Hin, Win, Cin, Cout)) {
+                auto it = h->params.find(name + ".weight.subpixel");
+                if (it != h->params.end() && it->second && it->second->p) { w = it->second->as<bf16_t>(); form = 2; }
+            }
             err = rq_launch_conv_halo(src, w, b, nullptr, epi == EPI_BF16_RESID ? resid : nullptr, (bf16_t*)dst,
-                                      st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, ups, st);
+                                      st_ok ? h->part.as<float>() : nullptr, B, Hin, Win, Cin, Cout, form, st);
             stats_of = st_ok ? (const bf16_t*)dst : nullptr;
             stats_n = st_ok ? rq_conv_halo_stat_tiles(Hin, Win) : 0;
             return;

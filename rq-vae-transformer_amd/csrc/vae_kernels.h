@@ -16,6 +16,8 @@ int rq_launch_repack_conv(const float* src, void* dst, int O, int I, int kh, int
 int rq_launch_gn_stats(const bf16_t* x, float* part, int B, int HW, int C, int* nchunk_out, hipStream_t s);
 // conv_halo.hip: halo-reuse 3x3 conv with optional fused GroupNorm+SiLU on the input
 bool rq_conv_halo_supported(int H, int W, int Cin, int Cout);
+bool rq_conv_halo_subpixel_supported(int H, int W, int Cin, int Cout);      // the upsample conv as four 2 x 2 convs over the source (ups = 2)
+int rq_launch_ups_subpixel_weights(const bf16_t* w, bf16_t* wsub, int Cout, int Cin, hipStream_t s);
 // stats != null: the epilogue also writes the GroupNorm partials of `out` ([B][rq_conv_halo_stat_tiles][32][2]);
 // ups != 0: x is [B][H/2][W/2][Cin] and is read through a nearest 2x upsample (gn and resid must be null)
 int rq_conv_halo_stat_tiles(int H, int W);

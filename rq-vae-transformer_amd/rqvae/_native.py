@@ -85,6 +85,7 @@ _SIGS = {
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_set_row_scale': (C.c_int, [C.c_int]),
     'rqamd_dbg_conv_in_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'rqamd_dbg_ups_subpixel_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_conv_out_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p]),
 }
@@ -331,7 +332,15 @@ def dbg_conv(x, w, bias=None, resid=None, ksize=3, stride=1, ups=0, bm=0, bn=0, 
     return out
 
 
-def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=False, persistent=None, wpx=0):
+def dbg_ups_subpixel_weights(w):
+    """diagnostics: (Cout,3,3,Cin) bf16 conv weights -> (4,Cout,2,2,Cin) bf16 pre-summed weights of the sub-pixel form of Upsample.conv."""
+    Cout, _, _, Cin = w.shape
+    wsub = torch.empty((4, Cout, 2, 2, Cin), dtype=torch.bfloat16, device=w.device)
+    check(lib().rqamd_dbg_ups_subpixel_weights(ptr(w, torch.bfloat16), Cout, Cin, ptr(wsub), stream_of(w)))
+    return wsub
+
+
+def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=False, persistent=None, wpx=0, subpixel=False):
     """diagnostics: halo-reuse 3x3 conv; x (B,H,W,Cin) bf16 (or (B,H/2,W/2,Cin) with ups), w (Cout,3,3,Cin) bf16, gn
     (B,Cin,2) fp32 or None; stats (B, (H/8)*(W/32), 32, 2) fp32 receives the per-tile GroupNorm partial sums.
     persistent True / False forces the persistent / per-tile form of the kernel (None: the default), wpx the persistent form's
@@ -342,9 +351,13 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
     Cout = w.shape[0]
     if out is None:
         out = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=x.device)
+    if subpixel:          # the upsample conv as four 2 x 2 convs over the source image (conv_halo.hip, UPS = 2)
+        assert ups
+        w = dbg_ups_subpixel_weights(w)
     check(lib().rqamd_dbg_conv_halo_bf16(ptr(x, torch.bfloat16), ptr(w, torch.bfloat16), ptr(bias, torch.float32), ptr(gn), ptr(resid),
                                          B, H, W, Cin, Cout,
-                                         (1 if ups else 0) | (0 if persistent is None else 16 if persistent else 32) | ((int(wpx) & 0xff) << 8),
+                                         (1 if ups else 0) | (0 if persistent is None else 16 if persistent else 32) | ((int(wpx) & 0xff) << 8)
+                                         | (64 if subpixel else 0),
                                          ptr(out), ptr(stats), stream_of(x)))
     return out
 

@@ -321,8 +321,8 @@ def test_emu_rqt_long_prefix(nat):
 def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
     """Opt-in 8-bit key cache of the body stack (RQAMD_KV=int8k, read when an engine is created): cached keys as
     64 bytes + one fp32 absmax / 127 scale per (token, head), this token's own key and all values bf16 as before.  Through every
-    attention kernel that has the variant -- <= 8 keys (attn_small), register blocks with one / two heads per wavefront (the
-    diagnostics row factor), the DYN long-context form behind a 69-token prefix, the quantising prefill -- against the
+    attention kernel that has the variant -- <= 8 keys (attn_small), register blocks, the DYN long-context form behind a 69-token
+    prefix, the quantising prefill -- against the
     reference's logits with the bound of the bf16 cache, and close to the bf16-cache engine; sampling stays inside the support of
     its own teacher-forced logits; an unknown format name is refused."""
     g = golden('rqt_tiny.npz')
@@ -340,12 +340,7 @@ def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
           % (err.max(), err.mean(), np.abs(logits - base).max(), np.abs(logits - base).mean()))
     assert err.max() < 0.06 and err.mean() < 0.01
     assert 0 < np.abs(logits - base).max() < 0.02            # the cache format is really in use, and costs little
-    nat.dbg_set_row_scale(4096)                              # two heads per wavefront, large-batch GEMM tiles
-    try:
-        big = eng.logits(codes, cond, [T(cb)] * 4).numpy()
-    finally:
-        nat.dbg_set_row_scale(1)
-    assert np.abs(big - g['logits']).max() < 0.06 and np.abs(big - logits).max() < 0.02
+    # (two heads per wavefront -- the large-batch form -- runs on the GPU: tests/test_gpu_parity_big.py::test_rqt_in1400m_int8k_key_cache)
     # sampling on it
     partial = torch.zeros((2, 4, 4, 4), dtype=torch.int64)
     out = eng.sample(partial, cond[:2].contiguous(), [T(cb)] * 4, (0, 0), 1.0, [5] * 4, [0.9] * 4, seed=11, offset=0, use_graph=False)
@@ -923,6 +918,56 @@ def test_emu_conv_halo_persistent(nat):
         for wpx in (1, 0):
             b = nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=True, wpx=wpx)
             assert torch.equal(a, b), (Cin, Cout, wpx)
+
+
+def test_emu_conv_halo_upsample_subpixel(nat):
+    """Round 5: Upsample.conv (layers.py:20-35) by sub-pixel decomposition -- for each output parity a 2 x 2 conv over the SOURCE image
+    with the taps that share a source pixel summed (conv3x3_halo_pk_kernel<0, 2, 0>: 4 taps per output pixel instead of 9).  The
+    pre-summed weights against a numpy sum of the taps; the conv against the oracle's conv2d of the nearest-upsampled input (image
+    borders, two channel chunks, two cout tiles, several tiles per workgroup, one workgroup per XCD) and close to the 9-tap folded
+    form; the epilogue statistics against sums over the output's 8 x 32-pixel lattices."""
+    from oracle.vae import conv2d
+    rng = np.random.default_rng(24)
+
+    def bf(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+    for (B, Hs, Ws, Cin, Cout) in ((1, 16, 32, 64, 128), (2, 16, 32, 128, 256)):
+        xs = bf(rng.standard_normal((B, Hs, Ws, Cin)).astype(np.float32))
+        w = bf((0.05 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+        bias = T(rng.standard_normal(Cout).astype(np.float32))
+        wf = w.float().numpy()
+        # weights: class (py, px), tap (a, b) = the 3 x 3 taps that read source pixel (y + py - 1 + a, x + px - 1 + b)
+        wsub = nat.dbg_ups_subpixel_weights(w).float().numpy()
+        sets = {0: ([0], [1, 2]), 1: ([0, 1], [2])}
+        for py in (0, 1):
+            for px in (0, 1):
+                for a in (0, 1):
+                    for b in (0, 1):
+                        want = sum(wf[:, ky, kx, :] for ky in sets[py][a] for kx in sets[px][b])
+                        got = wsub[py * 2 + px, :, a, b, :]
+                        assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(want).max() + 1e-6, (py, px, a, b)      # one bf16 rounding
+        xu = np.repeat(np.repeat(xs.float().numpy(), 2, axis=1), 2, axis=2)
+        ref = conv2d(xu, np.transpose(wf, (0, 3, 1, 2)), bias.numpy())
+        H, W = 2 * Hs, 2 * Ws
+        stats = torch.zeros((B, (H // 8) * (W // 32), 32, 2), dtype=torch.float32)
+        out = nat.dbg_conv_halo(xs, w, bias, ups=True, subpixel=True, stats=stats)
+        o = out.float().numpy()
+        assert o.shape == (B, H, W, Cout)
+        err = np.abs(o - ref).max() / np.abs(ref).max()
+        folded = nat.dbg_conv_halo(xs, w, bias, ups=True).float().numpy()
+        print(f'emu sub-pixel upsample conv {Cin}->{Cout} @ {Hs}x{Ws}: max err {err:.4f} of max vs fp32; vs the 9-tap folded form {np.abs(o - folded).max() / np.abs(ref).max():.4f}')
+        assert err < 0.02
+        assert np.abs(o - folded).max() < 0.02 * np.abs(ref).max()
+        assert torch.equal(out, nat.dbg_conv_halo(xs, w, bias, ups=True, subpixel=True, wpx=1))          # one workgroup per XCD walks every tile
+        # statistics: one partial per (source tile, parity class) = per 8 x 32 lattice of output pixels; their sum over an image is the
+        # image's sum (what gn_params_kernel forms), and every partial is the sum over its own lattice
+        tot = stats.numpy().astype(np.float64).sum(1)                                    # (B, 32, 2)
+        t = o.reshape(B, H * W, 32, Cout // 32).astype(np.float64)
+        want = np.stack([t.sum((1, 3)), (t * t).sum((1, 3))], -1)
+        assert np.abs(tot - want).max() < 1e-3 * np.abs(want).max()
+        lat = o[:, 0:16:2, 1:64:2].reshape(B, -1, 32, Cout // 32).astype(np.float64)     # source tile 0, class (py 0, px 1) = partial 1
+        want1 = np.stack([lat.sum((1, 3)), (lat * lat).sum((1, 3))], -1)
+        assert np.abs(stats.numpy()[:, 1] - want1).max() < 1e-3 * np.abs(want1).max()
 
 
 def test_emu_conv_in_mfma(nat):
