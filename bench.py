@@ -320,9 +320,11 @@ def rqt_flops_per_image(cfg):
     return 2.0 * (H * W * cfg['body']['n_layer'] * 12 * E * E + H * W * D * (cfg['head']['n_layer'] * 12 * E * E + E * V))
 
 
-def decoder_flops_per_image(dd, embed_dim):
+def decoder_flops_per_image(dd, embed_dim, executed=False):
     """Convolution + attention-GEMM FLOPs of Decoder.forward + post_quant_conv for one image (modules.py:171-202), from the
-    ddconfig alone: 249.5 GFLOP for the released 256x256 shapes."""
+    ddconfig alone: 249.5 GFLOP for the released 256x256 shapes.  executed=True: what the engine's kernels multiply --
+    the upsample convs whose source image has whole 8 x 32 tiles (output >= 64^2) run as four 2 x 2 convs over the source image,
+    4/9 of the taps (round 5, conv_halo.hip): 225.3 GFLOP."""
     ch, mult, nrb = dd['ch'], list(dd['ch_mult']), dd['num_res_blocks']
     res = dd['resolution'] >> (len(mult) - 1)
     fl = 0.0
@@ -349,7 +351,8 @@ def decoder_flops_per_image(dd, embed_dim):
                 fl += attn(block_in, res)
         if lvl != 0:
             res *= 2
-            fl += conv(block_in, block_in, 3, res)
+            sub = executed and res >= 64 and (res // 2) % 32 == 0 and not os.environ.get('RQAMD_NO_UPS_SUBPIXEL')
+            fl += conv(block_in, block_in, 3, res) * (4.0 / 9.0 if sub else 1.0)
     return fl + conv(block_in, dd['out_ch'], 3, res)
 
 
@@ -900,10 +903,14 @@ def main(argv=None):
         roofline_decode = step_frac = None
         dfl = decoder_flops_per_image(vcfg['ddconfig'], vcfg['hparams']['embed_dim'])
         if not args.overlap and t_dec > 0:
-            tf = dfl * B * args.steps / (t_dec * 1e-3) / 1e12
+            # MFMA utilisation is priced on the FLOPs the kernels execute (the sub-pixel upsample convs multiply 4/9 of the reference's taps);
+            # the reference's own count is reported next to it
+            dfx = decoder_flops_per_image(vcfg['ddconfig'], vcfg['hparams']['embed_dim'], executed=True)
+            tf = dfx * B * args.steps / (t_dec * 1e-3) / 1e12
             roofline_decode = {'bound': 'mfma', 'achieved': tf, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / MFMA_BF16_PEAK_TFLOPS,
                                'traffic': None,
-                               'algorithmic_GFLOP_per_image': dfl / 1e9, 'ms_per_image': t_dec / (args.steps * B),
+                               'executed_GFLOP_per_image': dfx / 1e9, 'algorithmic_GFLOP_per_image': dfl / 1e9,
+                               'algorithmic_TFLOPs': dfl * B * args.steps / (t_dec * 1e-3) / 1e12, 'ms_per_image': t_dec / (args.steps * B),
                                'what': 'RQ-VAE decode_code + clamp of the timed region: conv / attention-GEMM FLOPs of Decoder.forward '
                                        '(modules.py:171-202) over its device time (events around the decode half of every step)'}
         step_frac = {'achieved_TFLOPs': (dfl + rqt_flops_per_image(cfg)) * value / world / 1e12,
