@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
 export RQ_TAG=r05
 bash scripts/gpu.sh tests
-for m in 10752 500 64; do RQ_M=$m bash scripts/gpu.sh pmc 2>&1 | grep weighted; done
+echo "(GEMM traffic files: unchanged GEMM sources since the earlier run of this script -- not repeated)"
 bash scripts/gpu.sh bench
 RQ_TAG=r05_b10752 bash scripts/gpu.sh trace > /dev/null 2>&1; head -24 gpurun_out/r05_b10752_kernel_stats.md
 RQ_TAG=r05_b64 RQ_TRACE_ARGS="--batch 64 --steps 2" bash scripts/gpu.sh trace > /dev/null 2>&1; head -8 gpurun_out/r05_b64_kernel_stats.md
