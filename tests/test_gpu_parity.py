@@ -905,6 +905,18 @@ def test_conv_kernels_vs_torch(nat):
         for wpx in (0, 1):
             assert torch.equal(nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=False),
                                nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=True, wpx=wpx)), wpx
+        # round 5: the sub-pixel form of the same layer (four 2 x 2 convs over the source image with pre-summed taps) where the source has
+        # whole 8 x 32 tiles: vs torch, the epilogue statistics per output lattice, one workgroup per XCD == one per CU, repeated launches
+        if (H // 2) % 8 == 0 and (W // 2) % 32 == 0:
+            st2 = torch.zeros((B, (H // th) * (W // 32), 32, 2), device=DEV)
+            sub = nat.dbg_conv_halo(xs, w, bias, ups=True, subpixel=True, stats=st2)
+            assert float((sub.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
+            t2 = sub.double().reshape(B, H * W, 32, Cout // 32)
+            want2 = torch.stack([t2.sum((1, 3)), (t2 * t2).sum((1, 3))], -1)
+            assert float((st2.double().sum(1) - want2).abs().max()) < 1e-3 * float(want2.abs().max())
+            assert torch.equal(sub, nat.dbg_conv_halo(xs, w, bias, ups=True, subpixel=True, wpx=1))
+            for _ in range(4):
+                assert torch.equal(sub, nat.dbg_conv_halo(xs, w, bias, ups=True, subpixel=True))
     # MFMA Encoder.conv_in: NCHW fp32 image -> NHWC bf16
     x = rn(2, 3, 256, 256).clamp(-1, 1)
     w = rn(128, 3, 3, 3, scale=0.2)
