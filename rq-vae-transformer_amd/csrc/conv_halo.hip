@@ -55,7 +55,30 @@ constexpr int HT_H = 8, HT_W = 32;                 // output tile
 constexpr int HP_W = HT_W + 2;                     // halo patch of the plain conv: 34 x 10 = 340 pixels
 constexpr int H_BN = 128;
 constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows x 64 k
-constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + 3 * HW_BYTES;     // two patch buffers + three weight slots = 135 KB (every variant)
+// RQ_HALO_WDMA (A/B switch, default 1; round 5): the per-tile kernel's weight units go from global memory straight into a ring of FOUR LDS
+// slots by LDS-DMA -- no staging registers, no ds_write -- instead of through three register sets into three slots.
+#ifndef RQ_HALO_WDMA
+#define RQ_HALO_WDMA 1
+#endif
+// RQ_HALO_PMID / RQ_HALO_RMID (A/B switches of the DMA form): the next chunk's patch pieces / the residual pieces are requested behind the
+// tap's weight request (1) or at the top of the tap (0)
+#ifndef RQ_HALO_PMID
+#define RQ_HALO_PMID 0
+#endif
+#ifndef RQ_HALO_RMID
+#define RQ_HALO_RMID 1
+#endif
+constexpr int H_WSLOTS = RQ_HALO_WDMA ? 4 : 3;
+constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + H_WSLOTS * HW_BYTES;     // two patch buffers + the weight slots = 133 / 149 KB (every variant)
+// counted wait of the DMA form: at most nd LDS-DMAs and no ordinary loads of the wavefront stay in flight (both constants once the tap loop is unrolled)
+static __device__ __forceinline__ void halo_wait_dma(int nd, int no) {
+#define RQ_HC(ND, K) case K: rq_wait_vmcnt_mixed<ND, K>(); break;
+#define RQ_HW(ND) switch (no) { RQ_HC(ND, 0) RQ_HC(ND, 1) RQ_HC(ND, 2) RQ_HC(ND, 3) RQ_HC(ND, 4) RQ_HC(ND, 5) RQ_HC(ND, 6) RQ_HC(ND, 7) RQ_HC(ND, 8) \
+    RQ_HC(ND, 9) RQ_HC(ND, 10) RQ_HC(ND, 11) RQ_HC(ND, 12) default: rq_wait_vmcnt_mixed<ND, 0>(); break; }      /* (default: a stronger wait) */
+    if (nd >= 2) { RQ_HW(2) } else { RQ_HW(0) }
+#undef RQ_HW
+#undef RQ_HC
+}
 
 // LDS byte offset of 16-byte chunk c8 of patch pixel (hy, hx).  The XOR swizzle depends on the patch COLUMN
 // only, so a tap's row shift (and the fragment row i, and the double-buffer index) are plain multiples of 128
@@ -94,7 +117,8 @@ __device__ unsigned long long g_conv_trace[8 * 64];
 #endif
 template <int FUSE_GN, int UPS, int RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
-    constexpr int TH = HT_H, NTH = 512, RPW = 2, NJ = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3, W_SLOTS = 3;
+    constexpr bool WDMA = RQ_HALO_WDMA != 0;
+    constexpr int TH = HT_H, NTH = 512, RPW = 2, NJ = 2, W_IT = 2, TPX = TH * HT_W, W_SETS = 3, W_SLOTS = H_WSLOTS;
     static_assert(!(FUSE_GN && UPS), "the upsample conv has no Normalize in front of it");
     constexpr int PW = UPS ? HT_W / 2 + 2 : HP_W, PH = UPS ? TH / 2 + 2 : TH + 2;
     constexpr int HP_N = PW * PH;                  // patch pixels: 340, or 108 through the upsample
@@ -140,12 +164,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         for (int i = 0; i < W_IT; ++i) rw[i] = ld128(gWt + (w_goff[i] + kb));
     };
     rq_u128 rh[H_IT], rw[W_SETS][W_IT], r01[2][W_IT];
-    // weight units 0..4 of the tile (0, 1 go to LDS before the first barrier; 2, 3, 4 wait in register sets 2, 0, 1)
-    load_w(0, 0, r01[0]);
-    load_w(0, 1, r01[1]);
-    load_w(0, 2, rw[2]);
-    load_w(0, 3, rw[0]);
-    load_w(0, 4, rw[1]);
+    // DMA form: a unit's 16 KB are sixteen 1-KB wave-instructions, two per wavefront: wavefront w fills rows 16 w .. 16 w + 15 of the
+    // slot; LDS position (l & 7) of row r holds chunk (l & 7) ^ ((r >> 1) & 7) (the swizzle of w_loff below), so lane l FETCHES that
+    // chunk.  Source = wave-uniform base (tap, chunk) + a loop-invariant per-lane offset: no VALU work per unit.
+    unsigned w_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 16 + i * 8 + (lane >> 3);
+        w_voff[i] = (unsigned)(((long)(n0 + r) * 9 * p.Cin + ((lane & 7) ^ ((r >> 1) & 7)) * 8) * 2);
+    }
+    const rq_lds_t sW_dma = rq_lds_addr(sW) + (rq_lds_t)rq_uniform(wave) * 2048u;
+    // unit (c, tap) into the slot at byte offset woff of the ring; tap may run into the next chunk
+    auto dma_w = [&](int c, int tap, unsigned woff) {
+        if (tap >= 9) { tap -= 9; ++c; }
+        rq_glds16_s2(sW_dma + woff, gWt + (unsigned)rq_uniform((tap * p.Cin + c * 64) * 2), w_voff[0], w_voff[1]);    // (wave-uniform: the asm wants it in SGPRs)
+    };
+    if (WDMA) {
+        // units 0, 1, 2 of the tile into slots 0, 1, 2
+        dma_w(0, 0, 0u);
+        dma_w(0, 1, (unsigned)HW_BYTES);
+        dma_w(0, 2, 2u * HW_BYTES);
+    } else {
+        // weight units 0..4 of the tile (0, 1 go to LDS before the first barrier; 2, 3, 4 wait in register sets 2, 0, 1)
+        load_w(0, 0, r01[0]);
+        load_w(0, 1, r01[1]);
+        load_w(0, 2, rw[2]);
+        load_w(0, 3, rw[0]);
+        load_w(0, 4, rw[1]);
+    }
     rq_sched_barrier();
 
     // ---- halo staging bookkeeping (loop-invariant), ONE packed register per piece: source pixel index inside the image
@@ -172,11 +218,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     }
     const float* gn = FUSE_GN ? p.gn + (long)img * p.Cin * 2 : nullptr;
     // (scale, shift) of this thread's 8 channels of the chunk: the same for all of its pieces (c8 = tid & 7)
+    // (fetched raw and scaled by log2 e one tap later, scale_gs: multiplied on arrival, the loads' round trip stood at the head of
+    // every chunk's first tap, in front of the MFMAs of both wavefronts of the SIMD)
     f32x4 gs[4];
     auto load_gs = [&](int c) {
         if (FUSE_GN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2) * RQ_LOG2E;
+            for (int e = 0; e < 4; ++e) gs[e] = *(const f32x4*)(gn + (c * 64 + (tid & 7) * 8 + e * 2) * 2);
+        }
+    };
+    auto scale_gs = [&]() {
+        if (FUSE_GN) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { rq_opaque_f4(gs[e]); gs[e] = gs[e] * RQ_LOG2E; }
         }
     };
     load_gs(0);
@@ -271,9 +325,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     for (int kx = 0; kx < 3; ++kx)
         rd_h0[kx] = UPS ? halo_lds_off<PW>(wm * (RPW / 2), (ftx + kx + 1) >> 1, fk) : halo_lds_off<PW>(wm * RPW, ftx + kx, fk);
 
-    auto load_frags = [&](int hbuf, int wslot, int ky, int kx, int ks, bf16x8* af, bf16x8* bfr) {
+    auto load_frags = [&](int hbuf, unsigned woff, int ky, int kx, int ks, bf16x8* af, bf16x8* bfr) {
         const char* hb = sH + ((rd_h0[kx] + (unsigned)(hbuf * HALO_BYTES)) ^ (unsigned)(ks << 5));
-        const char* wb = sW + ((rd_w0 + (unsigned)(wslot * HW_BYTES)) ^ (unsigned)(ks << 5));
+        const char* wb = sW + ((rd_w0 ^ (unsigned)(ks << 5)) + woff);        // (woff is a multiple of 16 KB: the k-step XOR of bits 5..6 commutes with it)
 #pragma unroll
         for (int i = 0; i < RPW; ++i) af[i] = as_bf16x8(ld128(hb + (UPS ? (i + ky + 1) >> 1 : i + ky) * (PW * 128)));
 #pragma unroll
@@ -311,16 +365,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // prologue: patch of chunk 0 and weight units 0, 1 (requested at the top of the kernel) go to LDS
     {
         RQ_CT(0);
+        scale_gs();
 #pragma unroll
         for (int it = 0; it < H_IT; ++it)
             if (h_in(it)) st128(sH + h_loff(it), halo_piece_value(rh, it));
-        store_w(0, r01[0]);
-        store_w(1, r01[1]);
+        if (WDMA) rq_wait_vmcnt_mixed<0, 0>();     // units 0, 1, 2 have landed
+        else {
+            store_w(0, r01[0]);
+            store_w(1, r01[1]);
+        }
     }
     rq_syncthreads();
     RQ_CT(1);
 #pragma unroll
-    for (int g = 0; g < FD; ++g) load_frags(0, 0, 0, 0, g, fa[g], fb[g]);           // k-steps 0 .. FD - 1 of tap 0
+    for (int g = 0; g < FD; ++g) load_frags(0, 0u, 0, 0, g, fa[g], fb[g]);           // k-steps 0 .. FD - 1 of tap 0
     // residual tile (epilogue operand): its 8 pieces per thread are fetched one per tap during the LAST chunk, where the
     // patch registers are idle, so the epilogue starts with the data in hand
     constexpr int CPR = H_BN / 8;
@@ -339,6 +397,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     auto run_chunk = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int hbuf = c & 1;
+        // DMA form: unit u = 9 c + tap lives in slot u & 3 = (c + tap) & 3 -- a run-time rotation (9 taps per chunk, four slots), so the
+        // slot offset is a scalar that the fragment addresses add; unit u is requested at the start of tap u - 3 (its slot was read in
+        // tap u - 4), must have landed in every wavefront before the barrier that ends tap u - 2, and is first read at the end of tap u - 1
+        const unsigned cph = (unsigned)c & 3u;
+        auto slot_off = [&](int tap) { return WDMA ? ((cph + (unsigned)tap) & 3u) * (unsigned)HW_BYTES : (unsigned)((tap % 3) * HW_BYTES); };
         // next chunk's patch: one piece per tap, normalised and stored in taps FIRST.. (6 pieces: taps 2..7; through the
         // upsample 2 pieces: taps 6, 7), fetched three taps earlier where the chunk is long enough
         constexpr int NPT = H_IT, FIRST = 8 - NPT;
@@ -347,32 +410,56 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
             // ---- stage: weight unit (c, tap + 2) from its registers into the slot tap t-1 just left
-            const bool have_w2 = !(LAST && tap + 2 >= 9);
+            const bool have_w2 = !(LAST && tap + 2 >= 9), have_w3 = !(LAST && tap + 3 >= 9);
 #ifndef RQ_CONV_ABLATE_STAGE        // diagnostics build: no weight staging stores (results are wrong)
-            if (have_w2) store_w((tap + 2) % W_SLOTS, rw[(tap + 2) % W_SETS]);
+            if (!WDMA && have_w2) store_w((tap + 2) % 3, rw[(tap + 2) % W_SETS]);
 #endif
             // ---- global prefetches, spread over the taps (every workgroup of a launch is in the same phase: eight residual or
             // six patch pieces per thread issued in ONE tap are a 16-MB chip-wide request burst that stalled the issuing
             // wavefronts for ~1800 cycles): weight unit tap + 5 into the registers just stored; patch piece `it` of the next
             // chunk three taps before the tap that normalises it; one residual piece per tap of the last chunk
-            if (have_w2) (void)load_unit(c, tap + 5, rw[(tap + 2) % W_SETS]);
-            if (!LAST) {
-                if (tap == 0) load_gs(c + 1);
+            if (!WDMA && have_w2) (void)load_unit(c, tap + 5, rw[(tap + 2) % W_SETS]);
+            // the ordinary loads of tap t: the next chunk's GroupNorm words and patch pieces / the residual pieces; n_* = how many
+            auto n_patch = [&](int t) {
+                int n = 0;
+                if (!LAST && t >= 0) {
+                    if (t == 0 && FUSE_GN) n += 4;
 #pragma unroll
-                for (int it = 0; it < H_IT; ++it) {
-                    const int t_use = FIRST + it, t_load = t_use >= 3 ? t_use - 3 : 0;
-                    if (t_load == tap) load_halo_piece(c + 1, rh, it);
+                    for (int it = 0; it < H_IT; ++it) n += ((FIRST + it >= 3 ? FIRST + it - 3 : 0) == t) ? 1 : 0;
                 }
-            }
-            if (LAST && RES && tap < R_IT / 2) {           // (a template parameter, not `if (p.resid)`: behind a run-time branch the
+                return n;
+            };
+            auto n_resid = [&](int t) { return LAST && RES && t >= 0 && t < R_IT / 2 ? 2 : 0; };
+            auto patch_loads = [&]() {
+                if (!LAST) {
+                    if (tap == 0) load_gs(c + 1);
+#pragma unroll
+                    for (int it = 0; it < H_IT; ++it) {
+                        const int t_use = FIRST + it, t_load = t_use >= 3 ? t_use - 3 : 0;
+                        if (t_load == tap) load_halo_piece(c + 1, rh, it);
+                    }
+                }
+            };
+            auto resid_loads = [&]() {
+                if (LAST && RES && tap < R_IT / 2) {       // (a template parameter, not `if (p.resid)`: behind a run-time branch the
                                                            // compiler's vmcnt for this tap's store_w assumed no residual loads in
                                                            // flight and so also waited for the weight tile fetched two taps ago)
-                // two pieces per tap in the FIRST four taps: the tile is an old activation (HBM, not the L2), and a piece fetched
-                // in tap 8 was still on its way when the epilogue wanted it (~1200 cycles of the epilogue, barrier timeline in
-                // profiles/r03_conv_halo_barrier_timeline.txt)
-                rr[2 * tap] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap) * io_step));
-                rr[2 * tap + 1] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap + 1) * io_step));
-            }
+                    // two pieces per tap in the FIRST four taps: the tile is an old activation (HBM, not the L2), and a piece fetched
+                    // in tap 8 was still on its way when the epilogue wanted it (~1200 cycles of the epilogue, barrier timeline in
+                    // profiles/r03_conv_halo_barrier_timeline.txt)
+                    rr[2 * tap] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap) * io_step));
+                    rr[2 * tap + 1] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap + 1) * io_step));
+                }
+            };
+            // DMA form: where the tap's ordinary loads stand relative to its weight request (which follows the first k-step).  The
+            // vector-memory counter retires in issue order, so the wait for LAST tap's weight request at the end of this tap also
+            // waits for every ordinary load issued before that request: loads that come from HBM (the residual tile) go BEHIND it.
+            constexpr bool PMID = WDMA && RQ_HALO_PMID, RMID = WDMA && RQ_HALO_RMID;
+            if (!PMID) patch_loads();
+            if (!RMID) resid_loads();
+            // ordinary loads younger than last tap's weight request at the end of this tap
+            const int n_vis = n_patch(tap) + n_resid(tap) + (PMID ? n_patch(tap - 1) : 0) + (RMID ? n_resid(tap - 1) : 0);
+            if (!LAST && tap == 1) scale_gs();              // (the next chunk's GroupNorm words, fetched a tap ago, first used in tap FIRST >= 2)
             rq_sched_barrier();
             // ---- four k-step regions: reads of the next k-step (the last one: of the coming tap's first k-step -- its slot and
             // patch were published one barrier ago), four MFMAs, and a quarter of the fused GroupNorm+SiLU arithmetic of the tap's
@@ -398,8 +485,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                     // read k-step g + FD: this tap's, the next tap's (its weight slot and the patch were published one barrier ago), or
                     // the next chunk's first (other patch buffer, complete since the barrier that ended tap 7)
                     const int g = tap * 4 + ks + FD, t2 = g >> 2, k2 = g & 3, set2 = g % NSET;
-                    if (t2 < 9) load_frags(hbuf, t2 % W_SLOTS, t2 / 3, t2 % 3, k2, fa[set2], fb[set2]);
-                    else if (!LAST) load_frags(hbuf ^ 1, (t2 - 9) % W_SLOTS, (t2 - 9) / 3, (t2 - 9) % 3, k2, fa[set2], fb[set2]);
+                    if (t2 < 9) load_frags(hbuf, slot_off(t2), t2 / 3, t2 % 3, k2, fa[set2], fb[set2]);
+                    else if (!LAST) load_frags(hbuf ^ 1, slot_off(t2), (t2 - 9) / 3, (t2 - 9) % 3, k2, fa[set2], fb[set2]);
                 }
                 mfma_step((tap * 4 + ks) % NSET);
                 // The word's arithmetic is pinned INSIDE this region by making its input opaque here and its result opaque before
@@ -419,8 +506,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                     if (FUSE_GN && ptap) { rq_sched_group(0x002, 3); rq_sched_group(0x400, 1); }
                 }
                 rq_sched_barrier();
+                // DMA form: unit tap + 3 into the slot tap - 1 just left.  Requested BEHIND the tap's first k-step: the compiler's own
+                // wait for the patch piece this tap normalises (vmcnt(k), k = the ordinary loads issued since) stands in that k-step and
+                // would otherwise also wait for this request, which is younger than every one of them.
+                if (WDMA && ks == 0) {
+                    if (have_w3) dma_w(c, tap + 3, slot_off(tap + 3));
+                    if (PMID) patch_loads();
+                    if (RMID) resid_loads();
+                    rq_sched_barrier();
+                }
             }
             if (ptap) { if (h_in(pi)) st128(sH + (hbuf ^ 1) * HALO_BYTES + h_loff(pi), rh[pi]); }
+            // DMA form: unit tap + 2 (requested one tap ago) has landed before the barrier publishes it; this tap's own requests stay in flight
+            if (WDMA && have_w2) halo_wait_dma(have_w3 ? 2 : 0, n_vis);
             RQ_CT(2 + (c * 9 + tap) * 2);
             rq_syncthreads();
             RQ_CT(3 + (c * 9 + tap) * 2);

@@ -113,6 +113,10 @@ static __device__ __forceinline__ void rq_glds16_s2(unsigned lds_base, const voi
 #undef RQ_GLDS2
 }
 template <int N> static __device__ __forceinline__ void rq_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// counted wait in a kernel that also has ordinary global loads in flight: at most ND of the wavefront's LDS-DMAs and NO of its other
+// (younger) vector-memory loads stay outstanding.  The hardware has one counter for both (they retire in issue order); the host
+// emulator, whose ordinary loads are synchronous, counts the DMAs alone.
+template <int ND, int NO> static __device__ __forceinline__ void rq_wait_vmcnt_mixed() { rq_wait_vmcnt<ND + NO>(); }
 template <int N> static __device__ __forceinline__ void rq_wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory"); }
 static __device__ __forceinline__ void rq_barrier_raw() { __builtin_amdgcn_s_barrier(); }
 // lockstep point of one wavefront (no instruction: a wavefront IS in lockstep; the host emulator, whose lanes are fibers, meets here)
@@ -154,6 +158,7 @@ static __device__ __forceinline__ void rq_opaque(int& x) { asm volatile("" : "+v
 // statement is ordered against sched_barriers and other asm statements, register arithmetic is ordered only through operands)
 static __device__ __forceinline__ void rq_opaque_u(uint32_t& x) { asm volatile("" : "+v"(x)); }
 static __device__ __forceinline__ void rq_opaque_acc(f32x16& x) { asm volatile("" : "+v"(x)); }
+static __device__ __forceinline__ void rq_opaque_f4(f32x4& x) { asm volatile("" : "+v"(x)); }
 // "these values are needed now": makes the compiler place its wait for the loads that produce them here
 static __device__ __forceinline__ void rq_use(unsigned a, unsigned b, unsigned c, unsigned d) { asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d)); }
 static __device__ __forceinline__ void rq_use(float a, float b) { asm volatile("" :: "v"(a), "v"(b)); }

@@ -165,6 +165,7 @@ static inline void rq_glds16_s2(uintptr_t lds_base, const void* sbase, unsigned 
 // counted wait: the issuing lane's DMAs land, oldest first, until at most N are outstanding (hardware also counts the lane's other
 // global loads there; the kernels that use counted waits issue none between their DMAs)
 template <int N> static inline void rq_wait_vmcnt() { if (rqemu::g_dma_late) rqemu::dma_land_until(*rqemu::g_cur, (size_t)N); }
+template <int ND, int NO> static inline void rq_wait_vmcnt_mixed() { rq_wait_vmcnt<ND>(); }   // (ordinary loads are synchronous here)
 template <int N> static inline void rq_wait_lgkmcnt() {}
 // A wavefront executes in lockstep: past any point of the program every lane has issued everything before it.  The emulator runs
 // lanes as fibers, so kernels whose lanes hand data to each other through LDS WITHOUT a workgroup barrier (gemm_stream_kernel's
@@ -193,6 +194,7 @@ static inline float rq_dot2_bf16(uint32_t a, uint32_t b, float acc) {
     return acc + (al.f * bl.f + ah.f * bh.f);
 }
 static inline void rq_opaque_acc(f32x16_emu&) {}
+static inline void rq_opaque_f4(f32x4_emu&) {}
 static inline void rq_use(unsigned, unsigned, unsigned, unsigned) {}
 static inline void rq_use(float, float) {}
 static inline void rq_trap() { abort(); }

@@ -887,6 +887,16 @@ def test_emu_conv_halo(nat):
     t3 = out.reshape(2, 4, 8, 1, 32, 32, Cout // 32).astype(np.float64)
     want3 = np.stack([t3.sum((2, 4, 6)), (t3 * t3).sum((2, 4, 6))], -1).reshape(2, -1, 32, 2)
     assert np.abs(st3.numpy() - want3).max() < 1e-3 * np.abs(want3).max()
+    # four channel chunks, fused GroupNorm + residual: the four-slot LDS-DMA weight ring of the per-tile kernel turns by 9 units per
+    # chunk, so every chunk starts in a different slot (unit u in slot u & 3), and the last chunk's requests stop three taps early
+    x4 = bf(rng.standard_normal((1, 32, 32, 256)).astype(np.float32))
+    w4 = bf((0.05 * rng.standard_normal((128, 3, 3, 256))).astype(np.float32))
+    r4 = bf(rng.standard_normal((1, 32, 32, 128)).astype(np.float32))
+    gn4 = T(np.stack([1.0 + 0.2 * rng.standard_normal((1, 256)), 0.3 * rng.standard_normal((1, 256))], -1).astype(np.float32))
+    xn4 = bf(silu(x4.float().numpy() * gn4.numpy()[:, None, None, :, 0] + gn4.numpy()[:, None, None, :, 1]).astype(np.float32)).float().numpy()
+    ref4 = conv2d(xn4, np.transpose(w4.float().numpy(), (0, 3, 1, 2)), bias.numpy()) + r4.float().numpy()
+    out = nat.dbg_conv_halo(x4, w4, bias, gn=gn4, resid=r4).float().numpy()
+    assert np.abs(out - ref4).max() < 0.02 * np.abs(ref4).max()
     xs3 = bf(rng.standard_normal((1, 16, 16, Cin)).astype(np.float32))
     ref_up3 = conv2d(np.repeat(np.repeat(xs3.float().numpy(), 2, axis=1), 2, axis=2), wf, bias.numpy())
     out = nat.dbg_conv_halo(xs3, w, bias, ups=True).float().numpy()
@@ -899,6 +909,14 @@ def test_emu_conv_halo(nat):
         out = nat.dbg_conv_halo(xs, w, bias, ups=True, persistent=pers).float().numpy()
         assert out.shape == (B, H, W, Cout)
         assert np.abs(out - ref_up).max() < 0.02 * np.abs(ref_up).max(), pers
+
+
+def test_emu_conv_halo_weight_dma_lands_late(nat, monkeypatch):
+    """The per-tile halo conv's weight ring is filled by LDS-DMA (round 5): the same cases with every DMA landing at the LATEST moment its
+    wavefront's counted wait allows (RQ_EMU_DMA=late; the default run lands them at issue, the worst case for a slot that is still being
+    read).  A weight fragment read that is not behind the covering wait + barrier returns the slot's previous unit."""
+    monkeypatch.setenv('RQ_EMU_DMA', 'late')
+    test_emu_conv_halo(nat)
 
 
 def test_emu_conv_halo_persistent(nat):
