@@ -250,6 +250,12 @@ int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, in
  * that the large-batch variants run on test-sized inputs (results must not change); 1 restores normal behaviour. */
 int rqamd_dbg_set_row_scale(int factor);
 
+/* The dense bf16 MFMA rate the board sustains, measured: `launches` launches of one 512-thread workgroup per CU, every wavefront issuing
+ * n_per_wave v_mfma_f32_32x32x16_bf16 from registers alone.  mode 0: constant operands (the data-sheet instruction rate); mode 1: operands
+ * that change with every instruction (~N(0,1) bf16), which the board's power limit lets through at a lower clock.  scratch: >= 4 device
+ * bytes; *flop_out = the FLOPs issued (the caller times the stream).  bench.py reports the mode-1 rate beside `roofline.peak`. */
+int rqamd_dbg_mfma_rate(int mode, int n_per_wave, int launches, float* scratch, double* flop_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

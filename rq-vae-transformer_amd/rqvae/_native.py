@@ -84,6 +84,7 @@ _SIGS = {
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_set_row_scale': (C.c_int, [C.c_int]),
+    'rqamd_dbg_mfma_rate': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     'rqamd_dbg_conv_in_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_ups_subpixel_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_conv_out_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -360,6 +361,31 @@ def dbg_conv_halo(x, w, bias, gn=None, resid=None, out=None, stats=None, ups=Fal
                                          | (64 if subpixel else 0),
                                          ptr(out), ptr(stats), stream_of(x)))
     return out
+
+
+def dbg_mfma_rate(mode=1, n_per_wave=1 << 15, launches=64, secs=1.5, device='cuda'):
+    """diagnostics: the dense bf16 MFMA rate (TFLOP/s) the board sustains with MFMAs alone -- mode 0 constant operands (the instruction
+    rate), mode 1 operands that change every instruction (~N(0,1) bf16).  Runs for about `secs` seconds so that the clock settles under the
+    power limit, and times the last batch of launches with events."""
+    scratch = torch.zeros(16, dtype=torch.float32, device=device)
+    flop = C.c_double(0.0)
+    st = torch.cuda.current_stream(scratch.device)
+
+    def batch():
+        check(lib().rqamd_dbg_mfma_rate(int(mode), int(n_per_wave), int(launches), ptr(scratch), C.byref(flop), stream_of(scratch)))
+    batch()
+    torch.cuda.synchronize()
+    import time
+    t0, rate = time.time(), 0.0
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        batch()
+        e1.record(st)
+        e1.synchronize()
+        rate = flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        if time.time() - t0 >= secs:
+            return rate
 
 
 def dbg_set_row_scale(factor):

@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
     ap.add_argument('--rev', default=None)
+    ap.add_argument('--csrc', default=None, help='a patched copy of csrc/ (scratch experiments that should not touch the tree)')
     ap.add_argument('--flags', default='')
     ap.add_argument('--file-flags', action='append', default=[], help='file.hip=-flag[,-flag]')
     a = ap.parse_args()
@@ -32,7 +33,7 @@ def main():
             subprocess.check_call(f'git -C {ROOT} archive {a.rev} rq-vae-transformer_amd/csrc include | tar -x -C {tmp}', shell=True)
             csrc, inc = os.path.join(tmp, 'rq-vae-transformer_amd', 'csrc'), os.path.join(tmp, 'include')
         else:
-            csrc, inc = rqbuild.CSRC, os.path.join(ROOT, 'include')
+            csrc, inc = (a.csrc or rqbuild.CSRC), os.path.join(ROOT, 'include')
         per_file = dict((kv.split('=', 1)[0], kv.split('=', 1)[1].split(',')) for kv in a.file_flags)
         objs, procs = [], []
         for s in rqbuild.SOURCES:
