@@ -68,6 +68,9 @@ constexpr int HW_BYTES = H_BN * 128;               // one weight tile: 128 rows 
 #ifndef RQ_HALO_RMID
 #define RQ_HALO_RMID 1
 #endif
+#ifndef RQ_HALO_RES_F32
+#define RQ_HALO_RES_F32 1
+#endif
 constexpr int H_WSLOTS = RQ_HALO_WDMA ? 4 : 3;
 constexpr int H_SMEM_BYTES = 2 * (HT_H + 2) * HP_W * 128 + H_WSLOTS * HW_BYTES;     // two patch buffers + the weight slots = 133 / 149 KB (every variant)
 // counted wait of the DMA form: at most nd LDS-DMAs and no ordinary loads of the wavefront stay in flight (both constants once the tap loop is unrolled)
@@ -532,7 +535,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     static_assert(TPX * LDR + 4096 <= 160 * 1024, "epilogue tile must fit the CU's LDS (the launcher allocates max(staging, epilogue))");
     char* sT = (char*)smem;
     // (the loop ended with a barrier: all waves are done with the operand buffers)
-    if (RES) {
+    // RQ_HALO_RES_F32 (A/B switch, default 1; round 5): with a residual the accumulators cross the LDS as fp32 and meet the residual piece
+    // -- which the streaming thread already holds in registers -- on the way out: 16 ds_write_b128 + 16 ds_read_b128 per lane and one
+    // barrier, instead of the residual's round trip through the bf16 tile (8 ds_write_b128, a barrier, 16 + 16 eight-byte accesses, a
+    // barrier, 8 ds_read_b128).  Same fp32 sum, same single rounding: bit-identical.  Row = 32 sixteen-byte units (4 channels each);
+    // unit u sits in slot (u >> 1) + 16 (u & 1), so that the two units of a thread's 8-channel piece are 256 bytes apart and each
+    // ds_read_b128 of 16 lanes covers 256 contiguous bytes.
+    constexpr bool RF32 = RES && RQ_HALO_RES_F32;
+    constexpr int LDF = H_BN * 4 + 16;
+    static_assert(!RF32 || TPX * LDF <= H_SMEM_BYTES, "the fp32 tile overlays the operand buffers");
+    if (RF32) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int ml = (wm * RPW + i) * HT_W + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int u = wn * (NJ * 8) + j * 8 + 2 * q + (lane >> 5);            // 4-channel unit of the row
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                    *(f32x4*)(sT + ml * LDF + ((u >> 1) + 16 * (u & 1)) * 16) = v;
+                }
+        }
+    }
+    if (RES && !RF32) {
         // the residual tile (fetched as row-contiguous 16-byte pieces during the last taps) waits in the LDS tile, where
         // the lane that owns an 8-byte slot adds it in fp32 before the single rounding and overwrites it in place (the
         // per-lane 8-byte global reads of the first version touched 32 cache lines per wavefront load: +46 us on 173)
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     // overwritten in place, and the compiler will not move a later read above an earlier write to the same tile -- slot by slot
     // that was 32 serialised LDS round trips (~2 800 cycles of a fused + residual tile's epilogue)
     uint32_t rres[RPW][NJ][4][2];
-    if (RES) {
+    if (RES && !RF32) {
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
@@ -559,6 +587,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 }
         rq_sched_barrier();
     }
+    if (!RF32)
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         const int ty = wm * RPW + i, tx = lane & 31;
@@ -571,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (RES) {
+                if (RES && !RF32) {
                     const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
                     v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
                     v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
@@ -594,7 +623,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     for (int e = 0; e < 4; ++e) { gs_[e] = 0.f; gq_[e] = 0.f; }
 #pragma unroll
     for (int k = 0; k < R_IT; ++k) {
-        const rq_u128 u = ld128(sT + ((tid >> 4) + HT_W * k) * LDR + (tid & 15) * 16);
+        rq_u128 u;
+        if (RF32) {
+            const char* src = sT + ((tid >> 4) + HT_W * k) * LDF + (tid & 15) * 16;
+            f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 256);
+            const rq_u128 r = rr[k];
+            a[0] += __uint_as_float(r.x << 16); a[1] += __uint_as_float(r.x & 0xffff0000u);
+            a[2] += __uint_as_float(r.y << 16); a[3] += __uint_as_float(r.y & 0xffff0000u);
+            b[0] += __uint_as_float(r.z << 16); b[1] += __uint_as_float(r.z & 0xffff0000u);
+            b[2] += __uint_as_float(r.w << 16); b[3] += __uint_as_float(r.w & 0xffff0000u);
+            u.x = pack_bf16x2(a[0], a[1]); u.y = pack_bf16x2(a[2], a[3]);
+            u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
+        } else {
+            u = ld128(sT + ((tid >> 4) + HT_W * k) * LDR + (tid & 15) * 16);
+        }
         st128((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
         if (p.stats) rq_stats_piece(u, gs_, gq_);
     }
