@@ -34,8 +34,8 @@ __global__ __launch_bounds__(512, 1) void mfma_rate_kernel(float* out, int n, in
     for (int k = 0; k < 8; ++k)
         for (int e = 0; e < 8; ++e) {
             const float a = rq_mfma_rate_rnd(s), b = rq_mfma_rate_rnd(s);
-            x[k][e] = (__bf16)(mode == 0 ? 1.0f : a);
-            y[k][e] = (__bf16)(mode == 0 ? 0.5f : b);
+            x[k][e] = (short)(__float_as_uint(mode == 0 ? 1.0f : a) >> 16);         // (bf16x8 holds raw bf16 bits)
+            y[k][e] = (short)(__float_as_uint(mode == 0 ? 0.5f : b) >> 16);
         }
     f32x16 acc[8];
     for (int a = 0; a < 8; ++a)
