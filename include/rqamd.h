@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 5
+#define RQAMD_ABI_VERSION 6
 
 typedef enum {
     RQAMD_OK = 0,

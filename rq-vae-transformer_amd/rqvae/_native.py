@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class RqamdError(RuntimeError):

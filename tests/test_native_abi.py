@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib_path):
     from rqvae import _native
     assert declared == set(_native.EXPORTS)
     lib.rqamd_abi_version.restype = ctypes.c_int
-    assert lib.rqamd_abi_version() == _native.ABI_VERSION == 5
+    assert lib.rqamd_abi_version() == _native.ABI_VERSION == 6
 
 
 def test_status_codes_without_gpu(lib_path):
