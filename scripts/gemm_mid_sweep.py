@@ -32,6 +32,8 @@ TILES = [(128, 64, 128, (3, 6)), (128, 128, 128, (3, 5)), (129, 64, 128, (3, 6))
 if os.environ.get('RQ_TILES'):          # e.g. RQ_TILES=129x128,132x128,136x128: only these tile codes
     keep = set(os.environ['RQ_TILES'].split(','))
     TILES = [t for t in TILES if f'{t[0]}x{t[1]}' in keep]
+if os.environ.get('RQ_STAGES'):         # e.g. RQ_STAGES=3,4: these ring depths for every tile
+    TILES = [(c, bn, bm, tuple(int(x) for x in os.environ['RQ_STAGES'].split(','))) for c, bn, bm, _ in TILES]
 REG = [(64, 64), (128, 64), (64, 128), (128, 128)]
 if os.environ.get('RQ_TILES'):
     REG = [t for t in REG if f'{t[0]}x{t[1]}r' in os.environ['RQ_TILES'].split(',')]
@@ -90,7 +92,7 @@ for M in [int(x) for x in os.environ.get('RQ_MS', '200,500').split(',')]:
                     got = out.float().sum(0) if epi == 4 else out.float()
                     err = ((got - ref).abs().max() / scale).item()
                     t = graph_time(lambda i: _native.dbg_gemm(a, ws[i % nrot], b, ecode, bm, bn, sk, out=out))
-            except RuntimeError as ex:
+            except (RuntimeError, ValueError) as ex:
                 print(f'   {tag}: {str(ex)[:90]}', flush=True)
                 return None
             if err > 2e-2:
