@@ -69,7 +69,7 @@ for M in [int(x) for x in os.environ.get('RQ_MS', '200,500').split(',')]:
     for name, N, K, epi in SHAPES:
         if only and name not in only.split(','):
             continue
-        nrot = max(4, int(420e6 / (N * K * 2)) + 1)
+        nrot = int(os.environ['RQ_NROT']) if os.environ.get('RQ_NROT') else max(4, int(420e6 / (N * K * 2)) + 1)     # RQ_NROT=1: the same (cache-warm) weights every launch
         a = torch.randn((M, K), device=dev).to(torch.bfloat16)
         ws = [(torch.randn((N, K), device=dev) * 0.05).to(torch.bfloat16) for _ in range(nrot)]
         bias = torch.randn((N,), device=dev)

@@ -145,5 +145,46 @@ int main() {
             }
         }
     }
+    // ---- cold operands: every workgroup streams its OWN 128-row panel ONCE (one pass over K, like a weight tile of a decode-step GEMM), from memory
+    // nothing has touched since it left every cache (a 2-GB buffer, each launch on the next region).  Row-strided (the panel is 128 rows of a
+    // K-contiguous matrix: a unit = 128 x 128 bytes, rows `ld` bytes apart) against the same bytes laid out unit by unit (16 KB contiguous).
+    {
+        char* big;
+        const size_t big_bytes = (size_t)2048 << 20;
+        if (hipMalloc(&big, big_bytes + (1u << 20)) != hipSuccess) { printf("cold test: no memory\n"); return 0; }
+        hipMemset(big, 1, big_bytes);
+        hipDeviceSynchronize();
+        for (int ld : {3072, 12288}) {
+          for (int share : {1, 4}) {                                     // 4: every panel is streamed by four workgroups of one XCD at once (the four m-tiles of a 500-row GEMM)
+            for (int blocks : {144, 256}) {
+                const int win = 128 * ld, units = ld / 128;
+                const size_t per_launch = (size_t)blocks / share * win;  // windows, xcd-major
+                const int launches = (int)(big_bytes / per_launch) < 24 ? (int)(big_bytes / per_launch) : 24;
+                double tbs[2][2];
+                for (int strided = 0; strided < 2; ++strided)
+                    for (int mode = 0; mode < 2; ++mode) {
+                        hipEvent_t e0, e1;
+                        hipEventCreate(&e0); hipEventCreate(&e1);
+                        // flush: touch another 512 MB so that the MALL holds none of the region (the buffer is 8 x the MALL anyway)
+                        hipEventRecord(e0);
+                        for (int l = 0; l < launches; ++l) {
+                            const char* base = big + (size_t)l * per_launch;
+                            if (mode == 0) hipLaunchKernelGGL((k_intake<0, 4>), dim3(blocks), dim3(512), 8 * UNIT, 0, base, win, share, units, 1, sink, strided ? ld : 0);
+                            else if (strided) hipLaunchKernelGGL((k_intake<0, 6>), dim3(blocks), dim3(512), 8 * UNIT, 0, base, win, share, units, 1, sink, ld);   // (column 'reg' of the strided half: dma with 5 units in flight)
+                            else hipLaunchKernelGGL((k_intake<0, 2>), dim3(blocks), dim3(512), 8 * UNIT, 0, base, win, share, units, 1, sink, 0);                  // (column 'reg' of the contiguous half: dma with 1 unit in flight)
+                        }
+                        hipEventRecord(e1);
+                        hipEventSynchronize(e1);
+                        float ms = 0;
+                        hipEventElapsedTime(&ms, e0, e1);
+                        tbs[strided][mode] = ms * 1e3 / launches;
+                    }
+                printf("== cold, %3d workgroups, %d per %d-KB panel (%d units), %.0f MB unique per launch: us per launch  contiguous units: dma D=4 %6.1f D=2 %6.1f | row-strided (ld %d): dma D=4 %6.1f D=6 %6.1f\n",
+                       blocks, share, win >> 10, units, per_launch / 1048576.0, tbs[0][0], tbs[0][1], ld, tbs[1][0], tbs[1][1]);
+                fflush(stdout);
+            }
+          }
+        }
+    }
     return 0;
 }
