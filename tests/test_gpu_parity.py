@@ -982,3 +982,14 @@ def test_create_model_and_state_dict_roundtrip(nat):
     assert torch.allclose(b, a + 1.0, atol=1e-5)
     m.load_state_dict(sd)
     assert torch.equal(m.decode_code(codes), a)
+
+
+@pytest.mark.gpu
+def test_sustained_mfma_rate_probe(nat):
+    """rqamd_dbg_mfma_rate (what bench.py reports as roofline.sustained_mfma_peak): MFMAs alone on constant operands run near the data-sheet
+    rate, on operands that change every instruction measurably below it (the board's power limit), and both are sane numbers."""
+    const = nat.dbg_mfma_rate(mode=0, secs=0.5)
+    chg = nat.dbg_mfma_rate(mode=1, secs=1.0)
+    print(f'MFMAs alone: constant operands {const:.0f} TFLOP/s, changing operands {chg:.0f} TFLOP/s')
+    assert 1500.0 < const < 2600.0, const
+    assert 800.0 < chg < const * 1.02, (chg, const)
