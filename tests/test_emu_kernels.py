@@ -897,6 +897,13 @@ def test_emu_conv_halo(nat):
     ref4 = conv2d(xn4, np.transpose(w4.float().numpy(), (0, 3, 1, 2)), bias.numpy()) + r4.float().numpy()
     out = nat.dbg_conv_halo(x4, w4, bias, gn=gn4, resid=r4).float().numpy()
     assert np.abs(out - ref4).max() < 0.02 * np.abs(ref4).max()
+    # eight channel chunks (the ring turns through its four slots 18 times per tile), plain + residual
+    x8 = bf(rng.standard_normal((1, 32, 32, 512)).astype(np.float32))
+    w8 = bf((0.03 * rng.standard_normal((128, 3, 3, 512))).astype(np.float32))
+    r8 = bf(rng.standard_normal((1, 32, 32, 128)).astype(np.float32))
+    ref8 = conv2d(x8.float().numpy(), np.transpose(w8.float().numpy(), (0, 3, 1, 2)), bias.numpy()) + r8.float().numpy()
+    out = nat.dbg_conv_halo(x8, w8, bias, resid=r8).float().numpy()
+    assert np.abs(out - ref8).max() < 0.02 * np.abs(ref8).max()
     xs3 = bf(rng.standard_normal((1, 16, 16, Cin)).astype(np.float32))
     ref_up3 = conv2d(np.repeat(np.repeat(xs3.float().numpy(), 2, axis=1), 2, axis=2), wf, bias.numpy())
     out = nat.dbg_conv_halo(xs3, w, bias, ups=True).float().numpy()
