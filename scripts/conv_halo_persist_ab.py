@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'rq-vae-transformer_amd'))
 import torch
 from rqvae import _native
+if os.environ.get('RQ_LIB'):          # a differently-built kernel library (scripts/build_variant.py; diagnostics only)
+    _native.LIB_PATH = os.environ['RQ_LIB']
 
 dev = 'cuda'
 
