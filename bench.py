@@ -959,6 +959,30 @@ def main(argv=None):
             'roofline': roofline, 'roofline_attn': roofline_attn, 'roofline_decode': roofline_decode,
             'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'kv_cache_formats': kv_formats, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
+        # ---- flat scalars: the driver's record keeps the scalar members of `roofline` / `cpu_baseline` / `config` and only the
+        # NAMES of other top-level keys, so everything this repo claims from the line is repeated as plain numbers -- at the top level and inside `roofline`
+        flat = {}
+        for e in sweep:
+            flat[f"b{e['batch_per_gpu']}_images_per_sec"] = e.get('images_per_sec')
+            flat[f"b{e['batch_per_gpu']}_ar_ms_per_batch"] = e.get('ar_ms_per_batch')
+        for key, r in (('roofline_decode_frac', roofline_decode), ('roofline_attn_frac', roofline_attn), ('roofline_rq_frac', rqr),
+                       ('roofline_encode_frac', (enc or {}).get('roofline_encode'))):
+            flat[key] = (r or {}).get('frac')
+        if enc:
+            flat['encode_images_per_sec'] = enc.get('images_per_sec')
+            flat['encode_codes_per_sec'] = enc.get('codes_per_sec')
+        smp = (roofline or {}).get('sustained_mfma_peak') or {}
+        flat['sustained_mfma_peak_TFLOPs'] = smp.get('value')
+        flat['gemm_frac_of_sustained'] = smp.get('frac_of_it')
+        flat['gemm_in_graph_frac'] = ((roofline or {}).get('in_graph') or {}).get('frac')
+        flat['ar_ms_per_image'] = out['ar_ms_per_image']
+        flat['decode_ms_per_image'] = out['decode_ms_per_image']
+        for a in also:
+            if 'model' in a:
+                flat[f"{a['model']}_b{a['batch_per_gpu']}_images_per_sec"] = a.get('images_per_sec')
+        out.update(flat)
+        if roofline is not None:
+            roofline.update({k: v for k, v in flat.items() if k not in roofline})
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -728,6 +728,32 @@ extern "C" int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64
     return run_all(h, c, codes, cond, 0, false, nullptr, (hipStream_t)stream);
 }
 
+// ---- lanes (round 6): a second handle that runs on the SAME parameter arena as `src` -- its own workspace, KV caches, graphs and
+// stepping state, no weights of its own.  Two handles fed half a batch each on two streams run two independent decode chains
+// over one copy of the weights (L2 / MALL hits for whichever chain reaches a layer second).
+extern "C" int rqamd_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src) {
+    if (!dst || !src) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: null argument");
+    if (memcmp(&dst->cfg, &src->cfg, sizeof(dst->cfg)) != 0) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: configurations differ");
+    if (src->seen.size() - src->n_ccls_seen < src->n_required || src->tables_dirty)
+        return rq_fail(RQAMD_ERR_STATE, "rqt_share_params: the source handle has not run yet (parameters incomplete or tables not derived)");
+    auto cp = [](std::vector<RqtLayer>& d, const std::vector<RqtLayer>& s) {
+        for (size_t i = 0; i < d.size(); ++i) {
+            RqtLayer keep = d[i];
+            d[i] = s[i];
+            d[i].kc = keep.kc; d[i].vc = keep.vc; d[i].ksc = keep.ksc;
+        }
+    };
+    cp(dst->body, src->body); cp(dst->head, src->head);
+    dst->w_in = src->w_in; dst->w_headin = src->w_headin; dst->w_cls = src->w_cls;
+    dst->b_in = src->b_in; dst->b_headin = src->b_headin; dst->b_cls = src->b_cls; dst->cls_lnw = src->cls_lnw; dst->cls_lnb = src->cls_lnb;
+    dst->w_ccls = src->w_ccls; dst->b_ccls = src->b_ccls; dst->ccls_lnw = src->ccls_lnw; dst->ccls_lnb = src->ccls_lnb; dst->n_ccls_seen = src->n_ccls_seen;
+    dst->cond_emb = src->cond_emb; dst->pos_cond = src->pos_cond; dst->pos_hw = src->pos_hw; dst->pos_d = src->pos_d; dst->tok_emb = src->tok_emb;
+    dst->body_in_bias = src->body_in_bias; dst->head_in_bias = src->head_in_bias;
+    dst->seen = src->seen; dst->tables_dirty = false; dst->gvalid = false;
+    dst->arena.release();
+    return RQAMD_OK;
+}
+
 // ---- stepping form: the caller draws the samples (include/rqamd.h)
 extern "C" int rqamd_rqt_step_begin(rqamd_rqt* h, const int64_t* partial, const int64_t* cond, int batch, const float* const* codebooks, void* stream) {
     if (!h || !partial || !codebooks) return rq_fail(RQAMD_ERR_INVALID, "rqt_step_begin: null argument");

@@ -70,6 +70,7 @@ struct DevBuf {
         return RQAMD_OK;
     }
     template <typename T> T* as() const { return (T*)p; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
     ~DevBuf() { if (p) (void)hipFree(p); }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
