@@ -30,6 +30,12 @@
 #ifndef RQ_GEMM_VARIANT
 #define RQ_GEMM_VARIANT 0
 #endif
+#ifndef RQ_GEMM_PF           // fragment reads one K-tile ahead of the MFMAs in the LDS-DMA tiles (A/B switch; measured, off: see the loop)
+#define RQ_GEMM_PF 0
+#endif
+#ifndef RQ_GEMM_PF_MINW      // ... from this many wavefronts per tile
+#define RQ_GEMM_PF_MINW 8
+#endif
 
 enum GemmEpi {
     EPI_BF16 = 0,         // out bf16 = acc + bias
@@ -749,6 +755,82 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
         // diagnostics (scripts only): dbg bit1 = no staging at all (MFMAs + fragment reads + barriers on whatever the LDS holds),
         // bit2 = staging, waits and barriers only (no fragment reads, no MFMAs): which side of the loop a tile shape is bound by
         const bool no_dma = p.dbg & 2, no_mma = p.dbg & 4;
+        // Round 6: fragment reads one K-tile AHEAD of the MFMAs (eight / sixteen-wavefront tiles, >= 3 stages, where two fragment sets
+        // fit the register budget).  The loop below this one reads tile t's fragments right after the barrier that publishes tile t and
+        // only then multiplies: with every wavefront of the tile leaving that barrier together, the matrix pipes sit idle for one LDS
+        // round trip per K-tile and then compete with the reads for the LDS (a 128 x 128 tile on sixteen wavefronts reads 128 KB per
+        // K-tile = 512 LDS cycles for 512 MFMA cycles per SIMD: 14.8 us of 'MFMA side' for 5.9 us of pipe time,
+        // profiles/r05_gemm_mid_probes.txt).  Here the barrier at the top of tile t publishes tile t + 1; its fragments are requested
+        // into the second register set and travel while the MFMAs of tile t run on the first.  Tile k lives in stage k % GL; the stage
+        // of tile t is free once every wavefront has its fragments in registers (lgkmcnt(0) before the barrier) and is refilled with
+        // tile t + GL right after it.  Same MFMA order per accumulator as the plain loop: bit-identical results.
+        // MEASURED (profiles/r06_gemm_pf_ab.txt, MI355X, 500 rows, in-graph, cold weights): no gain on the shipped tiles -- 128 x 128 on
+        // sixteen wavefronts 18.5 -> 18.9 us (MFMA side alone 14.9 -> 15.6), eight wavefronts 19.0 -> 19.3; the four-wavefront forms gain
+        // (2 x 2: 25.8 -> 21.1 us) and still lose to sixteen.  The launch is bound by its cold weight stream (staging alone 18.0-18.5 us),
+        // not by the order of reads and MFMAs.  Off by default (-DRQ_GEMM_PF=1 -DRQ_GEMM_PF_MINW=4 builds it).
+        constexpr bool PF = RQ_GEMM_PF && GL >= 3 && NW >= RQ_GEMM_PF_MINW && ((MI + NI) * 32 + MI * NI * 16 + 40 <= 2048 / NW);
+        if constexpr (PF) {
+            bf16x8 fa[2][4][MI], fb[2][4][NI];
+            auto read_frags = [&](int stg, int set) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) fa[set][ks][i] = as_bf16x8(ld128(rd_a[ks] + stg * A_STRIDE + i * (32 * 64 * 2)));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) fb[set][ks][j] = as_bf16x8(ld128(rd_b[ks] + stg * B_STRIDE + j * (32 * 64 * 2)));
+                }
+            };
+            auto mma = [&](int set) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = TR ? rq_mfma_32x32x16_bf16(fb[set][ks][j], fa[set][ks][i], acc[i][j])
+                                           : rq_mfma_32x32x16_bf16(fa[set][ks][i], fb[set][ks][j], acc[i][j]);
+            };
+            // own DMAs of tile `need` have landed: at most min(GL - 2, last issued - need) newer tiles stay in flight
+            auto wait_tile = [&](int newer) {
+                if (GL >= 6 && newer >= 4) rq_wait_vmcnt<(GL >= 6 ? 4 : 0) * PER>();
+                else if (GL >= 5 && newer >= 3) rq_wait_vmcnt<(GL >= 5 ? 3 : 0) * PER>();
+                else if (GL >= 4 && newer >= 2) rq_wait_vmcnt<(GL >= 4 ? 2 : 0) * PER>();
+                else if (newer >= 1) rq_wait_vmcnt<PER>();
+                else rq_wait_vmcnt<0>();
+            };
+            if (nk > 0) {
+#pragma unroll
+                for (int s0 = 0; s0 < GL - 1; ++s0)
+                    if (s0 < nk && !no_dma) issue(kt0 + s0, s0);
+                wait_tile(nk - 1 < GL - 2 ? nk - 1 : GL - 2);
+                rq_barrier_raw();                                      // publishes tile 0
+                if (GL - 1 < nk && !no_dma) issue(kt0 + GL - 1, GL - 1);
+                if (!no_mma) read_frags(0, 0);
+                int st = 0;
+                // one step: tile t multiplied from register set SET while tile t + 1 is read into the other
+                auto step = [&](int t, auto set_c) {
+                    constexpr int SET = decltype(set_c)::value;
+                    const int nx = st + 1 == GL ? 0 : st + 1;
+                    if (t + 1 < nk) {
+                        const int issued_last = t + GL - 1 < nk - 1 ? t + GL - 1 : nk - 1;
+                        wait_tile(issued_last - (t + 1));
+                        rq_wait_lgkmcnt<0>();                          // tile t's fragments are in registers: its stage may be refilled
+                        rq_barrier_raw();                              // publishes tile t + 1
+                        if (t + GL < nk && !no_dma) issue(kt0 + t + GL, st);
+                        if (!no_mma) read_frags(nx, SET ^ 1);
+                        rq_sched_barrier();
+                    }
+                    if (!no_mma) mma(SET);
+                    st = nx;
+                };
+                int t = 0;
+                for (; t + 1 < nk; t += 2) {
+                    step(t, std::integral_constant<int, 0>{});
+                    step(t + 1, std::integral_constant<int, 1>{});
+                }
+                if (t < nk) step(t, std::integral_constant<int, 0>{});
+            }
+        } else
         if (nk > 0) {
 #pragma unroll
             for (int s0 = 0; s0 < GL - 1; ++s0)

@@ -45,6 +45,10 @@ constexpr int QT_M = 64;     // vectors per workgroup
 constexpr int QT_N = 128;    // codes per tile (4 code groups x 32)
 constexpr int QT_K = 64;     // dims per staged chunk
 constexpr int QT_NTH = 512;  // 8 wavefronts: 2 vector halves x 4 code groups, one 32 x 32 accumulator each
+constexpr int QT_NST = 4;    // ring stages of [128 codes][64 dims] fp32 (32 KB each), filled by LDS-DMA
+constexpr int QT_PER = 5;    // LDS-DMA instructions per wavefront and step: 4 x (4 code rows x 256 B) + this code group's 32 norms
+constexpr int QT_STAGE_BYTES = QT_N * QT_K * 4;
+constexpr size_t QT_SMEM = (size_t)QT_NST * QT_STAGE_BYTES + (size_t)QT_NST * 4 * 1024 + (QT_M + 4 * QT_M) * sizeof(float) + (4 * QT_M + QT_M) * sizeof(int);
 
 __global__ void rq_code_norm_kernel(const float* cb, int K, int dim, float* cn) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,59 +64,100 @@ __global__ void rq_code_norm_kernel(const float* cb, int K, int dim, float* cn) 
     cn[k] = (s0 + s1) + (s2 + s3);
 }
 
-// ||r||^2 of one vector, accumulated by the 8 threads that share it (thread `useg` takes float4s useg, useg + 8, ...): the ONE
-// summation order used wherever a residual norm is formed (load phase, update phase, split-mode combine), so that the fused
-// and the split path produce bit-identical distances.
-static __device__ __forceinline__ float rq_norm8(float ss) {
-    ss += rq_shfl_xor(ss, 1);
-    ss += rq_shfl_xor(ss, 2);
-    ss += rq_shfl_xor(ss, 4);
-    return ss;
+// SPLIT = 0: all depths in one launch.  SPLIT = 1: depth p.dep only, codes of tiles [blockIdx.y * tiles_per_split, ...) only; the
+// per-vector partial minimum goes to part_v / part_i and rq_split_combine_kernel finishes the depth.  NCH = dim / 64.
+//
+// Round 6 structure (rounds 1-5: residual in LDS, codebook chunks staged global -> registers -> ds_write into two LDS buffers, one
+// barrier per 64 dims behind a vmcnt(0): 0.57-0.61 of the fp32 MFMA rate with 38.5 % of the wave-cycles parked, profiles/r05_rq_sqpmc.txt):
+//  * the RESIDUAL LIVES IN REGISTERS: lane (i = l & 31, half = l >> 5) of a wavefront of vector half vh holds
+//    r[32 vh + i][64 c + 8 q + 4 half + m] in ra[(8 c + q) * 4 + m] -- exactly the A operand of MFMA m of group q of chunk c, so the
+//    main loop reads no A fragment at all (half of the LDS read traffic gone, 66 KB of LDS freed); the four code-group wavefronts
+//    of a vector half hold the same 32 vectors.  The residual update gathers c[code] in the same layout and subtracts in registers.
+//  * the CODEBOOK goes from global memory straight into a ring of four 32-KB LDS stages by LDS-DMA (global_load_lds_dwordx4: no
+//    staging registers, no ds_write); a 16-byte chunk of a row lands in slot (chunk ^ (row & 15)) of its 256-byte LDS row (the
+//    swizzle is applied to the per-lane SOURCE address, the DMA writes lane-linear), which makes the ds_read_b128 of 32 rows x
+//    one chunk conflict-free.  The ||c||^2 of the tile ride along as a fifth DMA per wavefront and step (128 bytes, into a 1-KB
+//    slot per stage and code group).  Counted waits: the DMAs of step s were issued three steps earlier; before the barrier that
+//    publishes step s a wavefront waits until at most 2 x 5 of its DMAs (steps s + 1, s + 2) are in flight.
+//  * one barrier per step as before, but nothing else stands at it: no vmcnt(0), no ds_write pass.
+// Arithmetic unchanged: the same MFMA sequence per accumulator, the same ||r||^2 summation order (rq_norm_regs reproduces the
+// eight-threads-per-vector order of rounds 1-5 bit for bit), the same distance expression and tie-breaks.
+template <int NCH>
+static __device__ __forceinline__ float rq_norm_regs(const float (&ra)[NCH * 32]) {
+    // partial sums as the 8 threads of a vector formed them: thread useg = 2 u + half took float4s useg, useg + 8, ... of the row,
+    // i.e. (chunk c ascending; q = u, then q = u + 4), an fmaf chain over its elements; then the xor-1 / 2 / 4 shuffle tree
+    float s[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float v = ra[(8 * c + u + 4 * hi) * 4 + m];
+                    ss = fmaf(v, v, ss);
+                }
+        s[u] = ss;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += rq_shfl_xor(s[u], 32);      // useg ^ 1: the other half
+    return (s[0] + s[1]) + (s[2] + s[3]);                          // useg ^ 2, useg ^ 4
 }
 
-// SPLIT = 0: all depths in one launch (residual in LDS).  SPLIT = 1: depth p.dep only, codes of tiles
-// [blockIdx.y * tiles_per_split, ...) only; the per-vector partial minimum goes to part_v / part_i and
-// rq_split_combine_kernel finishes the depth.  Eight wavefronts (round 1 had four with two accumulators each: one wavefront per
-// SIMD, so every LDS / barrier latency was exposed -- 58 % of the fp32 MFMA peak); two per SIMD cover each other.
-template <int SPLIT>
+template <int SPLIT, int NCH>
 __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
     RQ_DYN_SMEM(smem);
-    const int D = p.dim;
-    const int RS = D + 4;                 // residual row stride (floats): odd multiple of 16 B
-    constexpr int CS = QT_K + 4;          // chunk row stride
-    float* sR = (float*)smem;                         // [64][RS]
-    float* sC = sR + QT_M * RS;                       // [2][128][CS]
-    float* sXn = sC + 2 * QT_N * CS;                  // [64]
-    float* sRedV = sXn + QT_M;                        // [4][64]
-    int* sRedI = (int*)(sRedV + 4 * QT_M);            // [4][64]
-    int* sCode = sRedI + 4 * QT_M;                    // [64]
+    constexpr int D = NCH * 64;
+    float* sC = (float*)smem;                                          // [NST][128][64] swizzled
+    float* sCn = sC + QT_NST * QT_N * QT_K;                            // [NST][4][256] (the first 32 floats of a slot are used)
+    float* sXn = sCn + QT_NST * 4 * 256;                               // [64]
+    float* sRedV = sXn + QT_M;                                         // [4][64]
+    int* sRedI = (int*)(sRedV + 4 * QT_M);                             // [4][64]
+    int* sCode = sRedI + 4 * QT_M;                                     // [64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = rq_uniform(tid >> 6);
     const int vh = wave >> 2, cw = wave & 3;          // vector half (32 rows), code group (32 columns of the tile)
     const long v0 = (long)blockIdx.x * QT_M;
-    const int urow = tid >> 3, useg = tid & 7;        // load / update mapping: 8 threads per vector
-    const long uvec = v0 + urow;
-    const bool uok = uvec < p.n_vec;
-    const int nf4 = D / 32;                           // float4s per thread
-
-    // ---- load the vectors into the LDS residual, ||x||^2
-    {
-        float ss = 0.f;
-        for (int i = 0; i < nf4; ++i) {
-            int f = useg + 8 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (uok) v = *(const f32x4*)(p.x + uvec * D + f * 4);
-            *(f32x4*)(sR + urow * RS + f * 4) = v;
-            ss = fmaf(v[0], v[0], ss); ss = fmaf(v[1], v[1], ss); ss = fmaf(v[2], v[2], ss); ss = fmaf(v[3], v[3], ss);
-        }
-        ss = rq_norm8(ss);
-        if (useg == 0) sXn[urow] = ss;
-    }
-    rq_syncthreads();
-
     const int fi = lane & 31, fh = lane >> 5;
-    const int nchunk = D / QT_K;
-    const int srow = tid >> 4, sf4 = tid & 15;        // staging: 16 threads x float4 per 64-dim row, rows srow + 32 i
+    const long myvec = v0 + vh * 32 + fi;
+    const bool vok = myvec < p.n_vec;
+
+    // ---- this lane's slice of its vector: 32 float4s per chunk pair ... (8 NCH float4s), ||x||^2
+    float ra[NCH * 32];
+    {
+        const float* src = p.x + myvec * D + 4 * fh;
+#pragma unroll
+        for (int g = 0; g < NCH * 8; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (vok) v = *(const f32x4*)(src + 8 * g);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ra[g * 4 + m] = v[m];
+        }
+    }
+    rq_sched_barrier();
+    float xn_mine = rq_norm_regs<NCH>(ra);
+    if (cw == 0 && fh == 0) sXn[vh * 32 + fi] = xn_mine;
+
+    // ---- LDS-DMA addressing.  Instruction i of this wavefront fills tile rows 4 g .. 4 g + 3, g = 4 wave + i: lane l -> row
+    // 4 g + (l >> 4), LDS slot l & 15, source chunk (l & 15) ^ (row & 15).
+    const rq_lds_t lds0 = rq_lds_addr(smem);
+    const rq_lds_t ldsCn = lds0 + (rq_lds_t)(QT_NST * QT_STAGE_BYTES);
+    int drow[4];
+    unsigned dchunk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        drow[i] = (4 * wave + i) * 4 + (lane >> 4);
+        dchunk[i] = (unsigned)(((lane & 15) ^ (drow[i] & 15)) << 4);
+    }
+    // B fragment of group q: row 32 cw + fi, chunk 2 q + half -> slot (2 q) ^ (half ^ (row & 15))
+    unsigned brd[8];
+    {
+        const int row = cw * 32 + fi;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) brd[q] = (unsigned)(row * 256 + (((2 * q) ^ (fh ^ (row & 15))) << 4));
+    }
 
     const int dep_lo = SPLIT ? p.dep : 0, dep_hi = SPLIT ? p.dep + 1 : p.depth;
     for (int dep = dep_lo; dep < dep_hi; ++dep) {
@@ -123,73 +168,97 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
         const int tile_lo = SPLIT ? blockIdx.y * p.tiles_per_split : 0;
         int tile_hi = SPLIT ? tile_lo + p.tiles_per_split : ntile_all;
         tile_hi = tile_hi < ntile_all ? tile_hi : ntile_all;
-        const int nstep = (tile_hi - tile_lo) * nchunk;
+        const int ntile = tile_hi > tile_lo ? tile_hi - tile_lo : 0;
+        const int nstep = ntile * NCH;
 
         float bestv[16];
         int besti[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { bestv[r] = __int_as_float(0x7f800000); besti[r] = 0x7fffffff; }
 
-        f32x4 stage[4];
-        auto load_chunk = [&](int step) {
-            int tile = tile_lo + step / nchunk, c = step - (step / nchunk) * nchunk;
+        // DMA of step (tile, c) into stage st: the tile's rows beyond the codebook re-read its last row (never selected: `valid`)
+        auto issue = [&](int tile, int c, int st) {
+            const int row_max = K - 1 - tile * QT_N;                   // >= 0
+            const char* base = (const char*)(cb + (long)tile * QT_N * D + c * QT_K);
+            const rq_lds_t dst = lds0 + (rq_lds_t)(st * QT_STAGE_BYTES + wave * 4096);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                int code = tile * QT_N + srow + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (code < K) v = *(const f32x4*)(cb + (long)code * D + c * QT_K + sf4 * 4);
-                stage[i] = v;
+                const int r = drow[i] < row_max ? drow[i] : row_max;
+                rq_glds16_s(dst + (rq_lds_t)(i * 1024), base, (unsigned)r * (unsigned)(D * 4) + dchunk[i]);
             }
+            // the 32 norms of this code group: lanes 0 .. 7 carry them (16 bytes each), the others repeat them into the rest of the slot;
+            // a ragged last tile clamps the chunk inside the array (its misplaced values belong to codes >= K or are re-read below)
+            int e = tile * QT_N + cw * 32 + 4 * (lane & 7);
+            e = e <= K - 4 ? e : (K >= 4 ? K - 4 : 0);
+            rq_glds16_s(ldsCn + (rq_lds_t)(st * 4096 + cw * 1024), K >= 4 ? (const char*)cn : (const char*)cb, (unsigned)e * 4u);      // (K < 4: any 16 readable bytes)
         };
-        auto store_chunk = [&](int buf) {
-            float* dst = sC + buf * QT_N * CS;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(f32x4*)(dst + (srow + 32 * i) * CS + sf4 * 4) = stage[i];
+        // steps are numbered s = (tile - tile_lo) * NCH + c and live in stage s % NST
+        auto issue_step = [&](int s, int st) {
+            const int t = s / NCH;
+            issue(tile_lo + t, s - t * NCH, st);
         };
 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        rq_syncthreads();                                              // sXn of this depth is complete; the ring is free
 
-        if (nstep > 0) {
-            load_chunk(0);
-            store_chunk(0);
-        }
-        rq_syncthreads();
-        for (int step = 0; step < nstep; ++step) {
-            const int buf = step & 1;
-            const int tile = tile_lo + step / nchunk, c = step - (step / nchunk) * nchunk;
-            const bool more = step + 1 < nstep;
-            if (more) load_chunk(step + 1);
-            const float* cT = sC + buf * QT_N * CS + (cw * 32 + fi) * CS + 4 * fh;
-            const float* r0 = sR + (vh * 32 + fi) * RS + c * QT_K + 4 * fh;
 #pragma unroll
-            for (int q = 0; q < QT_K / 8; ++q) {
-                f32x4 b = *(const f32x4*)(cT + 8 * q);
-                f32x4 a0 = *(const f32x4*)(r0 + 8 * q);
+        for (int s0 = 0; s0 < QT_NST - 1; ++s0)
+            if (s0 < nstep) issue_step(s0, s0);
+        int st = 0;
+        for (int t = 0; t < ntile; ++t) {
+            const int tile = tile_lo + t;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) acc = rq_mfma_32x32x2_f32(a0[m], b[m], acc);
-            }
-            if (c == nchunk - 1) {
-                // distances of this lane's code column against its 16 rows
-                const int code = tile * QT_N + cw * 32 + fi;
-                const bool valid = code < K;
-                const float cnv = valid ? cn[code] : 0.f;
+            for (int c = 0; c < NCH; ++c) {
+                const int s = t * NCH + c;
+                // step s has landed once at most the steps issued after it are outstanding: min(NST - 2, nstep - 1 - s) of them
+                const int newer = nstep - 1 - s;
+                if (newer >= 2) rq_wait_vmcnt<2 * QT_PER>();
+                else if (newer == 1) rq_wait_vmcnt<QT_PER>();
+                else rq_wait_vmcnt<0>();
+                rq_barrier_raw();                                      // publishes stage st; stage st - 1 is free for step s + NST - 1
+                if (s + QT_NST - 1 < nstep) issue_step(s + QT_NST - 1, st == 0 ? QT_NST - 1 : st - 1);
+                const char* cT = (const char*)sC + st * QT_STAGE_BYTES;
+                // the B fragment of group q + 1 is requested before the four MFMAs of group q issue
+                f32x4 b = *(const f32x4*)(cT + brd[0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
-                    float d0 = fmaf(-2.0f, acc[r], sXn[row] + cnv);
-                    if (valid && d0 < bestv[r]) { bestv[r] = d0; besti[r] = code; }
-                    if (SPLIT && p.logit_out && valid && v0 + row < p.n_vec)       // soft codes: softmax(-d / temp) logits
-                        p.logit_out[(v0 + row) * K + code] = -d0 * p.inv_temp;
-                    acc[r] = 0.f;
+                for (int q = 0; q < 8; ++q) {
+                    f32x4 bn = b;
+                    if (q < 7) bn = *(const f32x4*)(cT + brd[q + 1]);
+                    rq_sched_barrier();
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc = rq_mfma_32x32x2_f32(ra[(8 * c + q) * 4 + m], b[m], acc);
+                    rq_sched_barrier();
+                    b = bn;
                 }
+                if (c == NCH - 1) {
+                    // distances of this lane's code column against its 16 rows
+                    const int code = tile * QT_N + cw * 32 + fi;
+                    const bool valid = code < K;
+                    float cnv = sCn[st * 1024 + cw * 256 + fi];
+                    if (tile * QT_N + QT_N > K) cnv = valid ? cn[code] : 0.f;      // ragged last tile (the DMA chunk may be clamped)
+                    // ||r||^2 of the 16 rows this lane scores: rows (r & 3) + 8 (r >> 2) + 4 half + 32 vh
+                    f32x4 xn4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xn4[j] = *(const f32x4*)(sXn + vh * 32 + 8 * j + 4 * fh);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
+                        float d0 = fmaf(-2.0f, acc[r], xn4[r >> 2][r & 3] + cnv);
+                        if (valid && d0 < bestv[r]) { bestv[r] = d0; besti[r] = code; }
+                        if (SPLIT && p.logit_out && valid && v0 + row < p.n_vec)       // soft codes: softmax(-d / temp) logits
+                            p.logit_out[(v0 + row) * K + code] = -d0 * p.inv_temp;
+                        acc[r] = 0.f;
+                    }
+                }
+                st = st + 1 == QT_NST ? 0 : st + 1;
             }
-            if (more) store_chunk(buf ^ 1);
-            rq_syncthreads();
         }
 
         // ---- wavefront (value, index) min-reduction over the 32 code columns, lowest index on ties
+        int rbase = cw * QT_M + 4 * fh + 32 * vh;      // row (r & 3) + 8 (r >> 2) + 4 half + 32 vh of code group cw
+        rq_opaque(rbase);                              // (formed here: hoisted out of the depth loop, the 32 addresses below were spilled)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = bestv[r];
@@ -201,9 +270,8 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
                 if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
             }
             if (fi == 0) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * fh + 32 * vh;
-                sRedV[cw * QT_M + row] = v;
-                sRedI[cw * QT_M + row] = ix;
+                sRedV[rbase + (r & 3) + 8 * (r >> 2)] = v;
+                sRedI[rbase + (r & 3) + 8 * (r >> 2)] = ix;
             }
         }
         rq_syncthreads();
@@ -235,27 +303,27 @@ __global__ __launch_bounds__(QT_NTH) void rq_quantize_kernel(RqQuantArgs p) {
         if (SPLIT) return;
         rq_syncthreads();
 
-        // ---- residual -= c[code]; aggregated += c[code]; new ||r||^2   (quantizations.py:264-267)
+        // ---- residual -= c[code]; aggregated += c[code]; new ||r||^2   (quantizations.py:264-267).  Every wavefront updates its own
+        // copy of the residual (the four code groups of a vector half compute identical values); the aggregated output -- read-modify-
+        // write of the previous depth's row -- is divided between them: code group cw takes groups q = 2 cw, 2 cw + 1 of every chunk.
         {
-            const float* q = cb + (long)sCode[urow] * D;
-            float ss = 0.f;
-            for (int i = 0; i < nf4; ++i) {
-                int f = useg + 8 * i;
-                f32x4 qv = *(const f32x4*)(q + f * 4);
-                f32x4 rv = *(f32x4*)(sR + urow * RS + f * 4);
-                rv = rv - qv;
-                *(f32x4*)(sR + urow * RS + f * 4) = rv;
-                ss = fmaf(rv[0], rv[0], ss); ss = fmaf(rv[1], rv[1], ss); ss = fmaf(rv[2], rv[2], ss); ss = fmaf(rv[3], rv[3], ss);
-                if (p.quant_cum && uok) {
+            const float* qrow = cb + (long)sCode[vh * 32 + fi] * D + 4 * fh;
+#pragma unroll
+            for (int g = 0; g < NCH * 8; ++g) {
+                const f32x4 qv = *(const f32x4*)(qrow + 8 * g);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ra[g * 4 + m] -= qv[m];
+                if (p.quant_cum && vok && ((g & 7) >> 1) == cw) {
                     f32x4 agg = qv;
-                    if (dep > 0) agg = *(const f32x4*)(p.quant_cum + ((long)(dep - 1) * p.n_vec + uvec) * D + f * 4) + qv;
-                    *(f32x4*)(p.quant_cum + ((long)dep * p.n_vec + uvec) * D + f * 4) = agg;
+                    if (dep > 0) agg = *(const f32x4*)(p.quant_cum + ((long)(dep - 1) * p.n_vec + myvec) * D + 8 * g + 4 * fh) + qv;
+                    *(f32x4*)(p.quant_cum + ((long)dep * p.n_vec + myvec) * D + 8 * g + 4 * fh) = agg;
                 }
+                if ((g & 7) == 7) rq_sched_barrier();              // eight row pieces in flight at a time (the residual holds 32 NCH registers)
             }
-            ss = rq_norm8(ss);
-            if (useg == 0) sXn[urow] = ss;
+            xn_mine = rq_norm_regs<NCH>(ra);
+            if (cw == 0 && fh == 0) sXn[vh * 32 + fi] = xn_mine;
         }
-        rq_syncthreads();
+        // (the barrier at the top of the next depth publishes sXn and frees the ring)
     }
 }
 
@@ -333,6 +401,27 @@ __global__ void rq_embed_kernel(RqEmbedArgs p) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// one launch of the quantiser kernel for a.dim = 64 NCH
+template <int SPLIT, int NCH>
+static int rq_launch_quant_n(const RqQuantArgs& a, dim3 grid, hipStream_t st) {
+    static RqDeviceOnce attr_once;      // kernel attributes are per device
+    if (attr_once.first())
+        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<SPLIT, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)QT_SMEM);
+    RQ_LAUNCH((rq_quantize_kernel<SPLIT, NCH>), grid, dim3(QT_NTH), QT_SMEM, st, a);
+    return rq_check_launch(SPLIT ? "rq_quantize_kernel<split>" : "rq_quantize_kernel");
+}
+template <int SPLIT>
+static int rq_launch_quant(const RqQuantArgs& a, dim3 grid, hipStream_t st) {
+    switch (a.dim) {
+        case 64: return rq_launch_quant_n<SPLIT, 1>(a, grid, st);
+        case 128: return rq_launch_quant_n<SPLIT, 2>(a, grid, st);
+        case 192: return rq_launch_quant_n<SPLIT, 3>(a, grid, st);
+        case 256: return rq_launch_quant_n<SPLIT, 4>(a, grid, st);
+        default: return rq_fail(RQAMD_ERR_UNSUPPORTED, "rq_quantize: dim %d must be 64, 128, 192 or 256", a.dim);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // ||c||^2 of every code of one codebook (the ||e||^2 term of VQEmbedding.compute_distances, quantizations.py:51-52), computed
 // ONCE per codebook version by the caller and passed to every rqamd_rq_quantize on it (it used to be recomputed per call into a
 // process-global scratch buffer, which was neither stream- nor thread-safe).
@@ -363,13 +452,6 @@ extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, 
         kmin = n_embed[d] < kmin ? n_embed[d] : kmin;
     }
     a.x = x; a.depth = depth; a.dim = dim; a.n_vec = n_vec; a.codes = codes; a.quant_cum = quant_cum;
-    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float)
-                        + (4 * QT_M + QT_M) * sizeof(int);
-    static RqDeviceOnce attr_once;      // kernel attributes are per device
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     const long ntiles = (n_vec + QT_M - 1) / QT_M;
     // Few vectors (the per-image rFID / get_codes calls: 64 vectors = ONE workgroup scanning a 16.8 MB codebook four times):
     // divide the codebook over blockIdx.y, one launch pair per depth.  Needs the caller's workspace (residual + partials).
@@ -391,8 +473,7 @@ extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, 
                     a.tiles_per_split = (tk + S - 1) / S;
                     a.n_split = (tk + a.tiles_per_split - 1) / a.tiles_per_split;
                     a.x = d == 0 ? x : a.resid;
-                    RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, st, a);
-                    RQ_TRY(rq_check_launch("rq_quantize_kernel<split>"));
+                    RQ_TRY(rq_launch_quant<1>(a, dim3((unsigned)ntiles, (unsigned)a.n_split), st));
                     RQ_LAUNCH(rq_split_combine_kernel, dim3((unsigned)ntiles), dim3(512), 0, st, a);
                     RQ_TRY(rq_check_launch("rq_split_combine_kernel"));
                 }
@@ -400,8 +481,7 @@ extern "C" int rqamd_rq_quantize(const float* x, const float* const* codebooks, 
             }
         }
     }
-    RQ_LAUNCH(rq_quantize_kernel<0>, dim3((unsigned)ntiles), dim3(QT_NTH), smem, st, a);
-    return rq_check_launch("rq_quantize_kernel");
+    return rq_launch_quant<0>(a, dim3((unsigned)ntiles), st);
 }
 
 
@@ -461,14 +541,10 @@ extern "C" int rqamd_rq_soft_codes(const float* x, const float* const* codebooks
     a.use_codes = stochastic ? 1 : 0;
     a.tiles_per_split = (tiles_k + S - 1) / S;
     a.n_split = (tiles_k + a.tiles_per_split - 1) / a.tiles_per_split;
-    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float) + (4 * QT_M + QT_M) * sizeof(int);
-    static RqDeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int d = 0; d < depth; ++d) {
         a.dep = d;
         a.x = d == 0 ? x : a.resid;
-        RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, st, a);
-        RQ_TRY(rq_check_launch("rq_quantize_kernel<split>"));
+        RQ_TRY(rq_launch_quant<1>(a, dim3((unsigned)ntiles, (unsigned)a.n_split), st));
         if (stochastic)      // torch.multinomial(soft_code, 1) (quantizations.py:388-390): one draw per vector from softmax(logits)
             RQ_TRY(rq_launch_sample_rows(a.logit_out, (int)n_vec, K, seed, offset + 4ull * d, codes + d, depth, st));
         RQ_LAUNCH(rq_split_combine_kernel, dim3((unsigned)ntiles), dim3(512), 0, st, a);
@@ -503,11 +579,7 @@ extern "C" int rqamd_rq_distances(const float* x, const float* codebook, const f
     a.inv_temp = -1.0f;
     a.tiles_per_split = (tiles_k + S - 1) / S;
     a.n_split = (tiles_k + a.tiles_per_split - 1) / a.tiles_per_split;
-    const size_t smem = ((size_t)QT_M * (dim + 4) + 2 * QT_N * (QT_K + 4) + QT_M + 4 * QT_M) * sizeof(float) + (4 * QT_M + QT_M) * sizeof(int);
-    static RqDeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute((const void*)rq_quantize_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    RQ_LAUNCH(rq_quantize_kernel<1>, dim3((unsigned)ntiles, (unsigned)a.n_split), dim3(QT_NTH), smem, (hipStream_t)stream, a);
-    return rq_check_launch("rq_quantize_kernel<split>");
+    return rq_launch_quant<1>(a, dim3((unsigned)ntiles, (unsigned)a.n_split), (hipStream_t)stream);
 }
 
 extern "C" int rqamd_rq_embed(const int64_t* codes, const float* const* codebooks, const int* n_embed, int depth,

@@ -103,6 +103,39 @@ def test_emu_rq_quantize_non_finite_rows(nat):
         assert np.array_equal(codes[keep], good.numpy()[keep])
 
 
+@pytest.mark.parametrize('which', ['golden', 'ragged', 'split'])
+def test_emu_rq_quantize_codebook_dma_lands_late(nat, golden, monkeypatch, which):
+    """Round 6: the quantiser's codebook ring (four 32-KB stages + the tile's norms, filled by LDS-DMA) with RQ_EMU_DMA=late -- every
+    DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it, so a fragment (or norm) read that is not behind the
+    covering wait and the barrier returns stale bytes.  The default mode lands a DMA at issue (the worst case for a stage refilled while
+    some wavefront still reads it); the three tests above run in that mode.  Depths 1, 2 and 4 chunks per tile, ragged K, the split form."""
+    monkeypatch.setenv('RQ_EMU_DMA', 'late')
+    if which == 'golden':
+        test_emu_rq_quantize_and_embed(nat, golden)
+    elif which == 'ragged':
+        test_emu_rq_quantize_ragged(nat)
+    else:
+        test_emu_rq_quantize_codebook_split(nat)
+
+
+def test_emu_rq_quantize_dims_and_tiny_codebooks(nat):
+    """dim 192 / 256 (three / four chunks per tile: the released RQ-VAEs are 256) and codebooks smaller than one DMA chunk of norms
+    (K = 2, 3, 5; K = 1: every code is 0), vs the oracle."""
+    rng = np.random.default_rng(77)
+    for dim, ks, n in ((192, (200, 129), 70), (256, (300, 128, 64), 130), (64, (2, 3, 5), 9)):
+        cbs = [rng.standard_normal((k, dim), dtype=np.float32) for k in ks]
+        x = rng.standard_normal((1, 1, n, dim), dtype=np.float32)
+        codes, quants = nat.rq_quantize(T(x.reshape(-1, dim)), [T(c) for c in cbs])
+        oq, oc = oracle.rq_quantize(x, cbs)
+        gaps, _ = oracle.rq_quantize_margins(x, cbs)
+        ok = gaps.reshape(n, len(ks)).min(1) > 1e-3
+        assert ok.mean() > 0.9
+        assert np.array_equal(codes.numpy().reshape(n, -1)[ok], oc.reshape(n, -1)[ok])
+    one = rng.standard_normal((1, 64), dtype=np.float32)
+    codes, quants = nat.rq_quantize(T(rng.standard_normal((5, 64), dtype=np.float32)), [T(one)] * 2)
+    assert (codes.numpy() == 0).all() and np.array_equal(quants.numpy()[1], np.tile(one + one, (5, 1)))
+
+
 def test_emu_rq_ema_update(nat, golden, fake_torch_rng):
     """Train-mode quantiser: the product's EMA codebook update + dead-code restart (csrc/quantize.hip: rq_ema_* kernels behind
     VQEmbedding.forward / RQBottleneck.quantize in train mode, quantizations.py:80-142,237-271) against the REFERENCE's outputs
