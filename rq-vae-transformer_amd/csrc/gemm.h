@@ -128,6 +128,13 @@ static __device__ __forceinline__ int swz_off(int row, int chunk) {   // element
 // Epilogue shared by the GEMM kernels: bias / GELU / residual / bf16 packing / fp32 and split-K slab stores from the
 // accumulators of a WGM x WGN wavefront grid over a BM x BN tile.  `smem` is the workgroup's dynamic LDS segment of
 // SMEM_BYTES bytes (the operand buffers, free once every wave has passed the barrier inside); TR as in the kernels.
+#ifdef RQ_GL_TRACE
+// Diagnostics build only (scripts/gl_trace.py): shader-clock stamps of workgroup RQ_GL_TRACE of the LDS-DMA tiled kernel (plain loop)
+__device__ unsigned long long g_gl_trace[16 * 32];
+#define RQ_GLT(slot) do { if (blockIdx.x == RQ_GL_TRACE && blockIdx.z == 0 && (threadIdx.x & 63) == 0) g_gl_trace[(threadIdx.x >> 6) * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RQ_GLT(slot) do { } while (0)
+#endif
 #ifdef RQ_GEMM_TRACE
 // Diagnostics build only (scripts/gemm_trace.sh): shader-clock stamps of one workgroup's epilogue phases.
 __device__ unsigned long long g_gemm_trace[8 * 16];
@@ -832,9 +839,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
             }
         } else
         if (nk > 0) {
+            RQ_GLT(0);
 #pragma unroll
             for (int s0 = 0; s0 < GL - 1; ++s0)
                 if (s0 < nk && !no_dma) issue(kt0 + s0, s0);
+            RQ_GLT(1);
             int st = 0;
             for (int t = 0; t < nk; ++t) {
                 // tile t has landed once at most (tiles issued after it: up to GL - 2) * PER loads are outstanding
@@ -844,11 +853,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
                 else if (GL >= 4 && newer >= 2) rq_wait_vmcnt<(GL >= 4 ? 2 : 0) * PER>();
                 else if (GL >= 3 && newer >= 1) rq_wait_vmcnt<PER>();
                 else rq_wait_vmcnt<0>();
+                if (t < 6) RQ_GLT(2 + 4 * t);
                 rq_barrier_raw();            // publishes stage st; every wave is past its reads of stage st-1 (refilled next)
+                if (t < 6) RQ_GLT(3 + 4 * t);
                 if (t + GL - 1 < nk && !no_dma) issue(kt0 + t + GL - 1, st == 0 ? GL - 1 : st - 1);
+                if (t < 6) RQ_GLT(4 + 4 * t);
                 if (!no_mma) compute(st);
+                if (t < 6) RQ_GLT(5 + 4 * t);
                 st = st + 1 == GL ? 0 : st + 1;
             }
+            RQ_GLT(26);
         }
     } else {
     rq_u128 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
@@ -936,6 +950,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     }   // GL == 0
 
     rq_gemm_epilogue<BM, BN, TR, WGM, WGN, (GL ? GL : 2) * (BM + BN) * 64 * 2>(p, acc, smem, m0, n0);
+    if (GL > 0) RQ_GLT(27);
 }
 
 // -------------------------------------------------------------------------------------------------

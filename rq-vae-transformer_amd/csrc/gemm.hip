@@ -522,6 +522,13 @@ extern "C" int rqamd_dbg_stream_trace(unsigned long long* out_host, int clear) {
     return RQAMD_OK;
 }
 #endif
+#ifdef RQ_GL_TRACE
+// diagnostics build only (scripts/gl_trace.py)
+extern "C" int rqamd_dbg_gl_trace(unsigned long long* out_host) {
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_gl_trace), sizeof(g_gl_trace)) != hipSuccess) return rq_fail(RQAMD_ERR_HIP, "gl_trace: copy failed");
+    return RQAMD_OK;
+}
+#endif
 #ifdef RQ_GEMM_TRACE
 // diagnostics build only (scripts/gemm_trace.sh)
 extern "C" int rqamd_dbg_gemm_trace(unsigned long long* out_host) {
