@@ -25,6 +25,8 @@ struct rqamd_vae {
     std::map<std::string, std::unique_ptr<DevBuf>> params;
     DevBuf slab;               // fp32 split-K partial slabs (calls of <= SPLIT_MAX_B images; reserved on the first such call)
     DevBuf ws, part, gnp;      // gnp: [chunk][C][2] GroupNorm (scale, shift) for the fused norm->swish->conv
+    DevBuf stage;              // two-phase calls: the <= 16^2 activation of a super-chunk of images between the two phases
+    bool no_two_phase = false; // RQAMD_VAE_TWO_PHASE=0 (A/B switch)
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
@@ -70,6 +72,7 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     h->no_splitk = getenv("RQAMD_VAE_NO_SPLITK") != nullptr;
     if (const char* e = getenv("RQAMD_HALO_LOWRES")) h->halo_lowres = atoi(e) != 0;
     if (const char* e = getenv("RQAMD_VAE_GRAPH")) h->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("RQAMD_VAE_TWO_PHASE")) h->no_two_phase = atoi(e) == 0;
     *out = h;
     return RQAMD_OK;
 }
@@ -352,28 +355,66 @@ static int vae_prepare_slab(rqamd_vae* h, int B) {
     return RQAMD_OK;
 }
 
-static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipStream_t st) {
+// Two-phase calls (round 6).  The layers at <= 16^2 (implicit-GEMM convs over a few hundred rows per image, single-head attention,
+// GroupNorm passes) run at 0.18-0.32 of the MFMA peak on the 128 images of a chunk and 1.8 x faster on 256 and more
+// (scripts/conv_lowres_tiles.py); the chunk itself cannot grow, it is what bounds the 256^2 tensors.  So a call of more than one chunk
+// runs these layers ONCE over a super-chunk of up to eight chunks (their tensors are 1/64 of the 256^2 ones: the same five buffers
+// hold them) and the >= 32^2 layers chunk by chunk, the 16^2 activation of the super-chunk parked in `stage` in between.  The cut
+// sits where the producing conv is an implicit GEMM (no GroupNorm statistics travel across it); every kernel on either side
+// computes an image's values independently of the others in its launch (section 3a of DESIGN.md), so the pixels / latents are
+// bit-identical to the single-phase path.  phase 0: everything; 1: the first half, ends with the copy into `stage`; 2: the second
+// half, starts from `stage`.
+// first level (counted from the full resolution) whose side is <= 16; two phases need a level on either side of it
+static int vae_lo_level(const rqamd_vae_config& c) {
+    for (int l = 0; l < c.n_levels; ++l)
+        if (vae_level_res(c, l) <= 16) return l;
+    return c.n_levels;
+}
+static bool vae_two_phase(const rqamd_vae* h) {
+    const int l = vae_lo_level(h->cfg);
+    return !h->no_two_phase && l >= 1 && l <= h->cfg.n_levels - 1;
+}
+
+static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipStream_t st, int phase = 0, bf16_t* stage = nullptr) {
     const rqamd_vae_config& c = h->cfg;
     VaeRun r{h, st, B};
     r.X = h->buf[0]; r.Y = h->buf[1]; r.T1 = h->buf[2]; r.T2 = h->buf[3]; r.T3 = h->buf[4];
     const int nl = c.n_levels;
+    const int l_lo = vae_lo_level(c);
     int res = vae_level_res(c, nl - 1);
     int block_in = c.ch * c.ch_mult[nl - 1];
-    // z_q NHWC fp32 -> bf16; post_quant_conv (1x1, rqvae.py:87); Decoder.conv_in
-    RQ_TRY(rq_launch_cvt_bf16(z_q, r.T1, (long)B * res * res * c.embed_dim, st));
-    r.conv("post_quant_conv", r.T1, r.X, res, res, c.embed_dim, c.z_channels, 1, 1, 0, EPI_BF16, nullptr);
-    r.conv("decoder.conv_in", r.X, r.Y, res, res, c.z_channels, block_in, 3, 1, 0, EPI_BF16, nullptr);
-    r.swap();
-    r.res("decoder.mid.block_1", res, res, block_in, block_in);
-    r.attn("decoder.mid.attn_1", res, res, block_in);
-    r.res("decoder.mid.block_2", res, res, block_in, block_in);
+    if (phase != 2) {
+        // z_q NHWC fp32 -> bf16; post_quant_conv (1x1, rqvae.py:87); Decoder.conv_in
+        RQ_TRY(rq_launch_cvt_bf16(z_q, r.T1, (long)B * res * res * c.embed_dim, st));
+        r.conv("post_quant_conv", r.T1, r.X, res, res, c.embed_dim, c.z_channels, 1, 1, 0, EPI_BF16, nullptr);
+        r.conv("decoder.conv_in", r.X, r.Y, res, res, c.z_channels, block_in, 3, 1, 0, EPI_BF16, nullptr);
+        r.swap();
+        r.res("decoder.mid.block_1", res, res, block_in, block_in);
+        r.attn("decoder.mid.attn_1", res, res, block_in);
+        r.res("decoder.mid.block_2", res, res, block_in, block_in);
+    }
     for (int l = nl - 1; l >= 0; --l) {
         const int block_out = c.ch * c.ch_mult[l];
         const std::string up = "decoder.up." + std::to_string(l);
-        for (int ib = 0; ib < c.num_res_blocks + 1; ++ib) {
-            r.res(up + ".block." + std::to_string(ib), res, res, block_in, block_out);
+        const bool skip = phase == 2 && l >= l_lo;             // done by phase 1
+        if (skip) {
+            res = vae_level_res(c, l);
             block_in = block_out;
-            if (vae_has_attn(c, res)) r.attn(up + ".attn." + std::to_string(ib), res, res, block_in);
+            if (l != l_lo) continue;                           // (its upsample conv ran in phase 1 as well)
+            if (r.err) return r.err;
+            RQ_HIP(hipMemcpyAsync(r.X, stage, (size_t)B * res * res * block_in * 2, hipMemcpyDeviceToDevice, st));
+        } else {
+            for (int ib = 0; ib < c.num_res_blocks + 1; ++ib) {
+                r.res(up + ".block." + std::to_string(ib), res, res, block_in, block_out);
+                block_in = block_out;
+                if (vae_has_attn(c, res)) r.attn(up + ".attn." + std::to_string(ib), res, res, block_in);
+            }
+            if (phase == 1 && l == l_lo) {
+                if (r.err) return r.err;
+                if (r.stats_of == r.X) return rq_fail(RQAMD_ERR_STATE, "vae: two-phase cut behind a conv that leaves GroupNorm statistics");
+                RQ_HIP(hipMemcpyAsync(stage, r.X, (size_t)B * res * res * block_in * 2, hipMemcpyDeviceToDevice, st));
+                return RQAMD_OK;
+            }
         }
         if (l != 0) {
             res *= 2;   // nearest x2 folded into the conv gather (layers.py:31-35)
@@ -398,13 +439,14 @@ static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipSt
     return rq_launch_conv_out3(r.T1, w, b, out, B, res, res, block_in, c.out_ch, st);
 }
 
-static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStream_t st) {
+static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStream_t st, int phase = 0, bf16_t* stage = nullptr) {
     const rqamd_vae_config& c = h->cfg;
     VaeRun r{h, st, B};
     r.X = h->buf[0]; r.Y = h->buf[1]; r.T1 = h->buf[2]; r.T2 = h->buf[3]; r.T3 = h->buf[4];
     const int nl = c.n_levels;
+    const int l_lo = vae_lo_level(c);
     int res = c.resolution;
-    {
+    if (phase != 2) {
         const float* w = (const float*)r.P("encoder.conv_in.weight");
         const float* b = (const float*)r.P("encoder.conv_in.bias");
         if (r.err) return r.err;
@@ -415,6 +457,12 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
     for (int l = 0; l < nl; ++l) {
         const int block_out = c.ch * c.ch_mult[l];
         const std::string dn = "encoder.down." + std::to_string(l);
+        if (phase == 2 && l < l_lo) {                          // done by phase 1 (its last conv is the downsample out of level l_lo - 1)
+            block_in = block_out;
+            res = vae_level_res(c, l + 1);
+            if (l == l_lo - 1) RQ_HIP(hipMemcpyAsync(r.X, stage, (size_t)B * res * res * block_in * 2, hipMemcpyDeviceToDevice, st));
+            continue;
+        }
         for (int ib = 0; ib < c.num_res_blocks; ++ib) {
             r.res(dn + ".block." + std::to_string(ib), res, res, block_in, block_out);
             block_in = block_out;
@@ -424,6 +472,12 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
             r.conv(dn + ".downsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 2, 0, EPI_BF16, nullptr);
             r.swap();
             res /= 2;
+        }
+        if (phase == 1 && l == l_lo - 1) {
+            if (r.err) return r.err;
+            if (r.stats_of == r.X) return rq_fail(RQAMD_ERR_STATE, "vae: two-phase cut behind a conv that leaves GroupNorm statistics");
+            RQ_HIP(hipMemcpyAsync(stage, r.X, (size_t)B * res * res * block_in * 2, hipMemcpyDeviceToDevice, st));
+            return RQAMD_OK;
         }
     }
     r.res("encoder.mid.block_1", res, res, block_in, block_in);
@@ -437,8 +491,26 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
     return r.err;
 }
 
-static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipStream_t st);
-static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStream_t st);
+// images of a two-phase super-chunk: up to eight chunks, bounded by what the five activation buffers (sized for `chunk` images of the
+// largest layer) hold of the <= 16^2 tensors -- the widest of them with the attention's 3 C -- and returns the bytes per image of the
+// parked activation (decode: level l_lo's output; encode: the downsample into level l_lo)
+static int vae_super_chunk(const rqamd_vae* h, int batch, bool dec, size_t* stage_per_img) {
+    const rqamd_vae_config& c = h->cfg;
+    const int l_lo = vae_lo_level(c);
+    size_t per_img = 0, cmax = c.z_channels > c.embed_dim ? c.z_channels : c.embed_dim;
+    for (int l = l_lo > 0 ? l_lo - 1 : 0; l < c.n_levels; ++l) if ((size_t)c.ch * c.ch_mult[l] > cmax) cmax = (size_t)c.ch * c.ch_mult[l];
+    for (int l = l_lo; l < c.n_levels; ++l) {
+        const size_t hw = (size_t)vae_level_res(c, l) * vae_level_res(c, l);
+        if (hw * cmax * 3 > per_img) per_img = hw * cmax * 3;
+    }
+    const int r_lo = vae_level_res(c, l_lo);
+    *stage_per_img = (size_t)r_lo * r_lo * (dec ? (size_t)c.ch * c.ch_mult[l_lo] : (size_t)c.ch * c.ch_mult[l_lo - 1]) * 2;
+    size_t n = per_img ? h->cap_elems / per_img : 0;
+    if (n > (size_t)8 * h->chunk) n = (size_t)8 * h->chunk;
+    if (n > (size_t)batch) n = batch;
+    return (int)n;
+}
+
 
 // returns RQAMD_OK when the call was served by a graph replay, 1 when the caller should run the eager path
 static int vae_graph_run(rqamd_vae* h, bool dec, const float* in, int B, float* out, hipStream_t st) {
@@ -500,6 +572,23 @@ extern "C" int rqamd_vae_decode(rqamd_vae* h, const float* z_q, int batch, float
     // chunks of <= SPLIT_MAX_B images divide K over workgroups and need the slab: the FULL chunks when RQAMD_VAE_CHUNK is that small
     // (they are the larger ones), otherwise only a tail chunk
     RQ_TRY(vae_prepare_slab(h, chunk <= rqamd_vae::SPLIT_MAX_B ? chunk : (batch % chunk ? batch % chunk : chunk)));
+    if (batch > chunk && vae_two_phase(h)) {
+        size_t spi = 0;
+        const int ns = vae_super_chunk(h, batch, true, &spi);
+        if (ns > chunk) {
+            RQ_TRY(h->stage.reserve((size_t)ns * spi));
+            for (int s0 = 0; s0 < batch; s0 += ns) {
+                const int m = (batch - s0 < ns) ? batch - s0 : ns;
+                RQ_TRY(decode_chunk(h, z_q + (size_t)s0 * lowres * lowres * c.embed_dim, m, nullptr, (hipStream_t)stream, 1, h->stage.as<bf16_t>()));
+                for (int b0 = 0; b0 < m; b0 += chunk) {
+                    const int n = (m - b0 < chunk) ? m - b0 : chunk;
+                    RQ_TRY(decode_chunk(h, nullptr, n, out + (size_t)(s0 + b0) * c.out_ch * c.resolution * c.resolution, (hipStream_t)stream, 2,
+                                        (bf16_t*)((char*)h->stage.p + (size_t)b0 * spi)));
+                }
+            }
+            return RQAMD_OK;
+        }
+    }
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(decode_chunk(h, z_q + (size_t)b0 * lowres * lowres * c.embed_dim, n,
@@ -521,6 +610,23 @@ extern "C" int rqamd_vae_encode(rqamd_vae* h, const float* x, int batch, float* 
     }
     RQ_TRY(vae_prepare(h, chunk));
     RQ_TRY(vae_prepare_slab(h, chunk <= rqamd_vae::SPLIT_MAX_B ? chunk : (batch % chunk ? batch % chunk : chunk)));
+    if (batch > chunk && vae_two_phase(h)) {
+        size_t spi = 0;
+        const int ns = vae_super_chunk(h, batch, false, &spi);
+        if (ns > chunk) {
+            RQ_TRY(h->stage.reserve((size_t)ns * spi));
+            for (int s0 = 0; s0 < batch; s0 += ns) {
+                const int m = (batch - s0 < ns) ? batch - s0 : ns;
+                for (int b0 = 0; b0 < m; b0 += chunk) {
+                    const int n = (m - b0 < chunk) ? m - b0 : chunk;
+                    RQ_TRY(encode_chunk(h, x + (size_t)(s0 + b0) * c.in_channels * c.resolution * c.resolution, n, nullptr, (hipStream_t)stream, 1,
+                                        (bf16_t*)((char*)h->stage.p + (size_t)b0 * spi)));
+                }
+                RQ_TRY(encode_chunk(h, nullptr, m, z_e + (size_t)s0 * lowres * lowres * c.embed_dim, (hipStream_t)stream, 2, h->stage.as<bf16_t>()));
+            }
+            return RQAMD_OK;
+        }
+    }
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int n = (batch - b0 < chunk) ? batch - b0 : chunk;
         RQ_TRY(encode_chunk(h, x + (size_t)b0 * c.in_channels * c.resolution * c.resolution, n,

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One RQVAE.decode_code at the benchmark's decode sub-batch, for an ordered kernel timeline.
+"""One RQVAE.decode_code (or, RQ_WHAT=encode, RQVAE.get_codes) at the benchmark's decode sub-batch, for an ordered kernel timeline.
 
     python scripts/decode_timeline.py run            # the workload (under rocprofv3 --kernel-trace --output-format csv)
     python scripts/decode_timeline.py report <dir>   # ordered list of the LAST decode's dispatches: kernel, grid, duration, gap
@@ -14,10 +14,16 @@ if sys.argv[1] == 'run':
     vae, ar, cfg = presets.build('huge', device=dev, seed=0)
     del ar
     B = int(os.environ.get('RQ_B', 128))
-    codes = torch.randint(0, 16384, (B, 8, 8, 4), device=dev)
-    for _ in range(3):
-        vae.decode_code(codes)
-        torch.cuda.synchronize()
+    if os.environ.get('RQ_WHAT', 'decode') == 'encode':      # RQ_WHAT=encode: RQVAE.get_codes (encoder + residual quantiser) instead
+        x = torch.randn((B, 3, 256, 256), device=dev).clamp(-1, 1)
+        for _ in range(3):
+            vae.get_codes(x)
+            torch.cuda.synchronize()
+    else:
+        codes = torch.randint(0, 16384, (B, 8, 8, 4), device=dev)
+        for _ in range(3):
+            vae.decode_code(codes)
+            torch.cuda.synchronize()
 else:
     f = glob.glob(sys.argv[2] + '/**/*kernel_trace.csv', recursive=True)[0]
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))

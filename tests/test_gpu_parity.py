@@ -791,6 +791,27 @@ def test_vae_small_chunk_reserves_its_split_k_slab(nat, golden, monkeypatch):
     assert torch.equal(vae1.encode(x), z0)
 
 
+def test_vae_two_phase_calls(nat, golden, monkeypatch):
+    """Round 6: a call of more than one chunk runs the <= 16^2 layers once over a super-chunk of up to eight chunks and the >= 32^2 layers
+    chunk by chunk (engine_vae.hip, "Two-phase calls").  Same bits as the single-phase path: 20 images through the default engine (one
+    chunk: single phase) == chunks of 6 in two phases (super-chunks of 20) == chunks of 2 (super-chunks of 16 + 4) == chunks of 6
+    with RQAMD_VAE_TWO_PHASE=0."""
+    g = golden('vae_imagenet.npz')
+    rng = np.random.default_rng(14)
+    codes = G(rng.integers(0, 16384, (20, 8, 8, 4)), torch.long)
+    x = G(np.clip(rng.standard_normal((20, 3, 256, 256), dtype=np.float32), -1, 1))
+    vae0, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+    d0, z0 = vae0.decode_code(codes), vae0.encode(x)
+    for env in ({'RQAMD_VAE_CHUNK': '6'}, {"RQAMD_VAE_CHUNK": "2"}, {'RQAMD_VAE_CHUNK': '6', 'RQAMD_VAE_TWO_PHASE': '0'}):
+        for k in ('RQAMD_VAE_CHUNK', 'RQAMD_VAE_TWO_PHASE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                           # read when the engine is created
+        vae1, _, _, _ = _models(C.VAE_IMAGENET, None, int(g['seed']), 0)
+        assert torch.equal(vae1.decode_code(codes), d0), env
+        assert torch.equal(vae1.encode(x), z0), env
+
+
 def test_vae_decode_code_read_ahead(nat, golden):
     """The reference drivers decode ONE image per call out of the batch they sampled (measure_throughput/__main__.py:297-299:
     torch.cat([decode_code(chunk) for chunk in codes.chunk(B)]); main_sampling_fid.py:223: decode_code(pixels[i:i+1])).  Those
