@@ -13,6 +13,14 @@
  *  - return 0 on success, negative rqamd_status otherwise; rqamd_last_error() gives the message
  *    (thread-local).  Nothing is thrown across the ABI.
  *  - tensors are dense, row-major, in the layouts the reference methods use.
+ *
+ * Two builds of the RQ-Transformer engine (round 6).  librqamd.so stores weights, GEMM operands and the KV cache as bfloat16
+ * (BASELINE.json's compute dtype; the default everywhere).  librqamd_f16.so is the SAME source compiled with -DRQ_F16=1
+ * (csrc/rq_hip.h): IEEE fp16 storage instead, fp32 accumulation / residual stream / LayerNorm / softmax / logits as before --
+ * what the reference's `amp=True` (fp16 autocast, rqvae/models/rqtransformer/transformers.py:21,206; main_sampling_fid.py:216)
+ * computes in.  It exports the rqamd_rqt_* entry points below with identical signatures and meaning, plus rqamd_abi_version /
+ * rqamd_last_error / rqamd_dbg_set_row_scale; the RQ-VAE engine and the quantiser exist in librqamd.so only.  Values beyond
+ * 65504 become inf in fp16 storage, as in torch.float16.
  */
 #ifndef RQAMD_H
 #define RQAMD_H

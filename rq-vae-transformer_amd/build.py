@@ -11,6 +11,11 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'librqamd.so')
 SOURCES = ['api.hip', 'gemm.hip', 'quantize.hip', 'rqt_kernels.hip', 'engine_rqt.hip', 'vae_kernels.hip', 'conv_halo.hip', 'engine_vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-I', CSRC]
+# librqamd_f16.so: the RQ-Transformer engine once more with IEEE fp16 as the 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1) -- what
+# RQTransformer.sample(amp=True) / forward(amp=True) run on, as the reference's fp16 autocast does (transformers.py:21,206).  Same C ABI
+# (the rqamd_rqt_* entry points, rqamd_abi_version, rqamd_last_error); the RQ-VAE engine and the quantiser are not in it.
+OUT_F16 = os.path.join(HERE, 'librqamd_f16.so')
+SOURCES_F16 = ['api.hip', 'gemm.hip', 'rqt_kernels.hip', 'engine_rqt.hip']
 
 
 def _newer(a, b):
@@ -24,23 +29,24 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(HERE), 'include', 'rqamd.h'))
     newest_h = max(os.path.getmtime(h) for h in headers)
-    objs, procs = [], []
-    for s in SOURCES:
-        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + '.o')
-        objs.append(obj)
+    objs, objs16, procs = [], [], []
+    for s, f16 in [(s, False) for s in SOURCES] + [(s, True) for s in SOURCES_F16]:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s + ('.f16.o' if f16 else '.o'))
+        (objs16 if f16 else objs).append(obj)
         if force or _newer(src, obj) or newest_h > os.path.getmtime(obj):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + FLAGS + (['-DRQ_F16=1'] if f16 else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
+            procs.append((s, f16, subprocess.Popen(cmd)))
+    for s, f16, p in procs:
         if p.wait() != 0:
-            raise RuntimeError(f'hipcc failed on {s}')
-    if procs or not os.path.exists(OUT):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+            raise RuntimeError(f'hipcc failed on {s}' + (' (-DRQ_F16=1)' if f16 else ''))
+    for out, obs, mine in ((OUT, objs, any(not f for _, f, _ in procs)), (OUT_F16, objs16, any(f for _, f, _ in procs))):
+        if mine or not os.path.exists(out):
+            cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--no-undefined', '-o', out] + obs
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
     return OUT
 
 

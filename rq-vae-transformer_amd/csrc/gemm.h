@@ -254,16 +254,14 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                     if (res_vec) {
                         // residual added in fp32 BEFORE the single bf16 rounding (as the reference's x + h)
                         const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
-                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                        { float ra_, rb_; rq_unpack2(r0, ra_, rb_); v[0] += ra_; v[1] += rb_; rq_unpack2(r1, ra_, rb_); v[2] += ra_; v[3] += rb_; }
                     } else if (epi == EPI_BF16_RESID) {
                         const int m = m0 + ml;
                         if (m < p.M && n < p.N) {
                             const bf16_t* rp = p.resid + (long)m * p.ldr + n;
                             if ((p.ldr & 3) == 0 && n + 3 < p.N) {
                                 const uint32_t r0 = ((const uint32_t*)rp)[0], r1 = ((const uint32_t*)rp)[1];
-                                v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                                v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                                { float ra_, rb_; rq_unpack2(r0, ra_, rb_); v[0] += ra_; v[1] += rb_; rq_unpack2(r1, ra_, rb_); v[2] += ra_; v[3] += rb_; }
                             } else {
                                 for (int e = 0; e < 4 && n + e < p.N; ++e) v[e] += bf16_to_f32(rp[e]);
                             }
@@ -369,8 +367,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                         if (epi == EPI_BF16_RESID) {
                             const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
                             const uint32_t r0 = rp[0], r1 = rp[1];
-                            v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                            v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                            { float ra_, rb_; rq_unpack2(r0, ra_, rb_); v[0] += ra_; v[1] += rb_; rq_unpack2(r1, ra_, rb_); v[2] += ra_; v[3] += rb_; }
                         }
                         struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w;
                         w.a = pack_bf16x2(v[0], v[1]);
@@ -447,8 +444,7 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
                     if (epi == EPI_BF16_RESID) {
                         const uint32_t* rp = (const uint32_t*)(p.resid + (long)m * p.ldr + n);
                         const uint32_t r0 = rp[0], r1 = rp[1];
-                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                        { float ra_, rb_; rq_unpack2(r0, ra_, rb_); v[0] += ra_; v[1] += rb_; rq_unpack2(r1, ra_, rb_); v[2] += ra_; v[3] += rb_; }
                     }
                     uint32_t* op = (uint32_t*)o;
                     const uint32_t w0 = pack_bf16x2(v[0], v[1]), w1 = pack_bf16x2(v[2], v[3]);

@@ -24,6 +24,29 @@ typedef unsigned short bf16_t;                                // raw bf16 bits
 #define RQ_WAVE 64
 
 // ---------------------------------------------------------------------------------------------
+// The 16-bit storage type of activations / weights / KV cache.  Default: bfloat16 (what BASELINE.json asks for).  Compiled with
+// -DRQ_F16=1 (librqamd_f16.so: the RQ-Transformer engine behind sample(amp=True) / forward(amp=True)) the SAME sources store IEEE
+// fp16 instead -- what the reference's amp=True autocast computes in (transformers.py:21,206) -- through these few helpers: the
+// conversions, the packed-pair unpack, the two MFMA wrappers and the packed dot product.  `bf16_t` / `bf16x8` keep their names
+// (raw 16-bit words); accumulation, residual stream, LayerNorm, softmax and logits are fp32 either way.
+#ifndef RQ_F16
+#define RQ_F16 0
+#endif
+#if RQ_F16
+static inline __host__ __device__ float bf16_to_f32(bf16_t v) {
+    union { uint16_t u; _Float16 h; } c;
+    c.u = v;
+    return (float)c.h;
+}
+static inline __host__ __device__ bf16_t f32_to_bf16(float f) {      // round-to-nearest-even; beyond 65504 -> inf, as torch.float16 does
+    union { uint16_t u; _Float16 h; } c;
+    c.h = (_Float16)f;
+    return c.u;
+}
+static inline __host__ __device__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+#else
 // bf16 <-> f32 (round-to-nearest-even), usable on host and device
 static inline __host__ __device__ float bf16_to_f32(bf16_t v) {
     union { uint32_t u; float f; } c;
@@ -53,16 +76,40 @@ static inline __host__ __device__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 #endif
+#endif
+// the two 16-bit values of a packed word as floats (bf16: a shift and a mask)
+static inline __host__ __device__ void rq_unpack2(uint32_t w, float& lo, float& hi) {
+#if RQ_F16
+    lo = bf16_to_f32((bf16_t)(w & 0xffffu));
+    hi = bf16_to_f32((bf16_t)(w >> 16));
+#else
+    union { uint32_t u; float f; } a, b;
+    a.u = w << 16;
+    b.u = w & 0xffff0000u;
+    lo = a.f;
+    hi = b.f;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // wave-collective wrappers (one spelling for hipcc and the emulator)
 #ifndef RQ_EMU
+#if RQ_F16
+typedef _Float16 rq_f16x8 __attribute__((ext_vector_type(8)));
+static __device__ __forceinline__ f32x16 rq_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rq_f16x8, a), __builtin_bit_cast(rq_f16x8, b), c, 0, 0, 0);
+}
+static __device__ __forceinline__ f32x4 rq_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rq_f16x8, a), __builtin_bit_cast(rq_f16x8, b), c, 0, 0, 0);
+}
+#else
 static __device__ __forceinline__ f32x16 rq_mfma_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 static __device__ __forceinline__ f32x4 rq_mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+#endif
 static __device__ __forceinline__ f32x16 rq_mfma_32x32x2_f32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -164,8 +211,13 @@ static __device__ __forceinline__ void rq_use(unsigned a, unsigned b, unsigned c
 static __device__ __forceinline__ void rq_use(float a, float b) { asm volatile("" :: "v"(a), "v"(b)); }
 // acc + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs, fp32 accumulate (v_dot2c_f32_bf16)
 static __device__ __forceinline__ float rq_dot2_bf16(uint32_t a, uint32_t b, float acc) {
+#if RQ_F16
+    typedef _Float16 rq_f16x2_v __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(rq_f16x2_v, a), __builtin_bit_cast(rq_f16x2_v, b), acc, false);      // v_dot2_f32_f16
+#else
     typedef __bf16 rq_bf16x2_v __attribute__((ext_vector_type(2)));
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(rq_bf16x2_v, a), __builtin_bit_cast(rq_bf16x2_v, b), acc, false);
+#endif
 }
 // byte I (0..3) of a word as a float (the back end selects v_cvt_f32_ubyteI for this pattern: one instruction): the dequantisation
 // of the opt-in 8-bit key cache

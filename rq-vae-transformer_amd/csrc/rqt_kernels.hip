@@ -193,10 +193,10 @@ int rq_launch_resid_ln(const ResidLnArgs& a, hipStream_t s) {
 // KV-cache decode attention (attentions.py:60-105 of the reference, cached branch): one wavefront per (row, head),
 // head_dim 64, up to NB*64 keys
 static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    rq_unpack2(u.x, f[0], f[1]);
+    rq_unpack2(u.y, f[2], f[3]);
+    rq_unpack2(u.z, f[4], f[5]);
+    rq_unpack2(u.w, f[6], f[7]);
 }
 
 // ---- opt-in 8-bit key cache (RQAMD_KV=int8k; AttnDecodeArgs::ksc != null; body stack only).  A cached key is 64 bytes + one fp32

@@ -11,8 +11,12 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
+# the RQ-Transformer engine compiled once more with IEEE fp16 as its 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1; build.py): what
+# RQTransformer.sample(amp=True) / forward(amp=True) run on.  Same entry points, same ABI version; RqtEngine(half=True) binds to it.
+LIB16_PATH = os.path.join(_PKG, 'librqamd_f16.so')
 
 _lib = None
+_lib16 = None
 ABI_VERSION = 6
 
 
@@ -93,9 +97,14 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 
-def _bind(path):
+EXPORTS_F16 = tuple(n for n in _SIGS if n.startswith('rqamd_rqt_')) + ('rqamd_abi_version', 'rqamd_last_error', 'rqamd_dbg_set_row_scale')
+
+
+def _bind(path, names=None):
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
+        if names is not None and name not in names:
+            continue
         fn = getattr(lib, name)           # AttributeError if the symbol is missing
         fn.restype, fn.argtypes = res, args
     if lib.rqamd_abi_version() != ABI_VERSION:
@@ -114,6 +123,17 @@ def lib():
     return _lib
 
 
+def lib16():
+    """librqamd_f16.so (the fp16 build of the RQ-Transformer engine); raises when it has not been built."""
+    global _lib16
+    if _lib16 is None:
+        if not os.path.exists(LIB16_PATH):
+            raise RqamdError(f'{LIB16_PATH} not found: build it with `python rq-vae-transformer_amd/build.py` '
+                             '(hipcc --offload-arch=gfx950 -DRQ_F16=1). There is no CPU fallback.')
+        _lib16 = _bind(LIB16_PATH, EXPORTS_F16)
+    return _lib16
+
+
 def kernel_source_hash(files=('gemm.h', 'gemm.hip')):
     """sha256[:16] over kernel sources under csrc/: stamps measurements that were taken out of run (PMC traffic files under
     profiles/) with the kernels they were taken on, so that bench.py can refuse a stale one."""
@@ -125,9 +145,9 @@ def kernel_source_hash(files=('gemm.h', 'gemm.hip')):
     return h.hexdigest()[:16]
 
 
-def check(status):
+def check(status, L=None):
     if status != 0:
-        msg = lib().rqamd_last_error().decode(errors='replace')
+        msg = (L or lib()).rqamd_last_error().decode(errors='replace')
         if status == -1:
             raise ValueError(msg)
         if status == -2:
@@ -417,13 +437,15 @@ class _Engine:
     """Opaque native handle bound to ONE device: created, fed and run with that device current (on_device_of)."""
     _create = _destroy = _set = None
 
-    def __init__(self, cfg_struct, device):
+    def __init__(self, cfg_struct, device, half=False):
         self.device = torch.device(device)
         if self.device.type == 'cuda' and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self._h = C.c_void_p()
+        self.half = bool(half)
+        self._L = lib16() if half else lib()         # the library this handle belongs to (errors are per library, too)
         with on_device_of(self.device):
-            check(getattr(lib(), self._create)(C.byref(cfg_struct), C.byref(self._h)))
+            check(getattr(self._L, self._create)(C.byref(cfg_struct), C.byref(self._h)), self._L)
 
     def _on_my_device(self, *tensors):
         for t in tensors:
@@ -437,7 +459,7 @@ class _Engine:
             t = t.to(torch.float32).contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
         with on_device_of(self.device):
-            check(getattr(lib(), self._set)(self._h, name.encode(), ptr(t, torch.float32), shape, t.dim(), stream_of(t)))
+            check(getattr(self._L, self._set)(self._h, name.encode(), ptr(t, torch.float32), shape, t.dim(), stream_of(t)), self._L)
         if t.is_cuda:
             t.record_stream(torch.cuda.current_stream(t.device))
 
@@ -448,16 +470,16 @@ class _Engine:
         failed regrowth, and the library clears HIP's sticky last-error after the failed hipMalloc."""
         with on_device_of(self.device):
             try:
-                return check(fn())
+                return check(fn(), self._L)
             except RqamdOutOfMemory:
                 if self.device.type != 'cuda':
                     raise
                 torch.cuda.empty_cache()
-                return check(fn())
+                return check(fn(), self._L)
 
     def close(self):
-        if self._h is not None and self._h.value and _lib is not None:
-            getattr(_lib, self._destroy)(self._h)
+        if self._h is not None and self._h.value and self._L is not None:
+            getattr(self._L, self._destroy)(self._h)
         self._h = None
 
     def __del__(self):
@@ -517,7 +539,7 @@ class RqtEngine(_Engine):
 
     def __init__(self, *, embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
                  block_size_cond, block_size, gelu_v2=False, device='cuda', input_emb_vqvae=True, head_emb_vqvae=True,
-                 shared_tok_emb=True, shared_cls_emb=True, cumsum_depth_ctx=True, vocab_sizes=None):
+                 shared_tok_emb=True, shared_cls_emb=True, cumsum_depth_ctx=True, vocab_sizes=None, half=False):
         c = RqtConfig(embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
                       block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2), int(bool(input_emb_vqvae)),
                       int(bool(head_emb_vqvae)), int(bool(shared_tok_emb)), int(bool(shared_cls_emb)), int(bool(cumsum_depth_ctx)))
@@ -525,7 +547,7 @@ class RqtEngine(_Engine):
         for i, v in enumerate(vs[:8]):
             c.vocab_sizes[i] = int(v)
         self.cfg = c
-        super().__init__(c, device)
+        super().__init__(c, device, half=half)
 
     def _check(self, codes, cond, codebooks):
         c = self.cfg
@@ -547,7 +569,7 @@ class RqtEngine(_Engine):
         out = torch.empty_like(partial)
         D = self.cfg.D
         cbs, tk, tp = _ptr_array(codebooks[:D]), _int_array(top_k[:D]), (C.c_float * D)(*[float(p) for p in top_p[:D]])
-        self._run(lambda: lib().rqamd_rqt_sample(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), B, cbs,
+        self._run(lambda: self._L.rqamd_rqt_sample(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), B, cbs,
                                                  int(start_loc[0]), int(start_loc[1]), float(temperature), tk, tp,
                                                  int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), int(bool(use_graph)),
                                                  ptr(out), stream_of(partial)))
@@ -559,7 +581,7 @@ class RqtEngine(_Engine):
         c = self.cfg
         out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
         cbs = _ptr_array(codebooks[:c.D])
-        self._run(lambda: lib().rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
+        self._run(lambda: self._L.rqamd_rqt_logits(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
                                                  ptr(out), stream_of(codes)))
         return out
 
@@ -571,7 +593,7 @@ class RqtEngine(_Engine):
         out = torch.empty((B, c.H, c.W, c.D, c.vocab_size), dtype=torch.float32, device=codes.device)
         cl = torch.empty((B, c.block_size_cond - 1, max(c.vocab_size_cond, 1)), dtype=torch.float32, device=codes.device)
         cbs = _ptr_array(codebooks[:c.D])
-        self._run(lambda: lib().rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
+        self._run(lambda: self._L.rqamd_rqt_forward(self._h, ptr(codes, torch.int64), ptr(cond, torch.int64), B, cbs,
                                                   ptr(out), ptr(cl), stream_of(codes)))
         return out, cl
 
@@ -580,7 +602,7 @@ class RqtEngine(_Engine):
         self._check(partial, cond, codebooks)
         self._step = (partial.shape[0], partial.device, [cb for cb in codebooks[:self.cfg.D]])     # keeps the codebooks alive
         cbs = _ptr_array(self._step[2])
-        self._run(lambda: lib().rqamd_rqt_step_begin(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), partial.shape[0], cbs,
+        self._run(lambda: self._L.rqamd_rqt_step_begin(self._h, ptr(partial, torch.int64), ptr(cond, torch.int64), partial.shape[0], cbs,
                                                      stream_of(partial)))
 
     def step_logits(self, pos, d):
@@ -590,7 +612,7 @@ class RqtEngine(_Engine):
         out = C.c_void_p()
         with on_device_of(dev):
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else 0)
-            check(lib().rqamd_rqt_step_logits(self._h, int(pos), int(d), C.byref(out), st))
+            check(self._L.rqamd_rqt_step_logits(self._h, int(pos), int(d), C.byref(out), st), self._L)
         if d < 0:
             return None
         return _view_f32(out.value, (B, self.cfg.vocab_size), dev)
@@ -600,26 +622,26 @@ class RqtEngine(_Engine):
         if tuple(codes.shape) != (B,):
             raise ValueError(f'codes of shape {tuple(codes.shape)}; expected ({B},)')
         with on_device_of(dev):
-            check(lib().rqamd_rqt_step_set_code(self._h, int(pos), int(d), ptr(codes.contiguous(), torch.int64), stream_of(codes)))
+            check(self._L.rqamd_rqt_step_set_code(self._h, int(pos), int(d), ptr(codes.contiguous(), torch.int64), stream_of(codes)), self._L)
 
     def step_end(self):
         B, dev, _ = self._step
         c = self.cfg
         out = torch.empty((B, c.H, c.W, c.D), dtype=torch.int64, device=dev)
         with on_device_of(dev):
-            check(lib().rqamd_rqt_step_end(self._h, ptr(out), stream_of(out)))
+            check(self._L.rqamd_rqt_step_end(self._h, ptr(out), stream_of(out)), self._L)
         self._step = None
         return out
 
     def set_profile(self, mode):
         """0 / False: off; 1 / True: HIP events around every GEMM / attention launch (eager launches); 2: skip the GEMM launches (graphs
         stay on) -- a sampling pass timed with and without them gives the GEMMs' time inside the graphs."""
-        check(lib().rqamd_rqt_set_profile(self._h, int(mode)))
+        check(self._L.rqamd_rqt_set_profile(self._h, int(mode)), self._L)
 
     def get_profile(self):
         ms, n, by, fl = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-        check(lib().rqamd_rqt_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)))
+        check(self._L.rqamd_rqt_get_profile(self._h, C.byref(ms), C.byref(n), C.byref(by), C.byref(fl)), self._L)
         ams, an = C.c_double(), C.c_int64()
-        check(lib().rqamd_rqt_get_profile_attn(self._h, C.byref(ams), C.byref(an)))
+        check(self._L.rqamd_rqt_get_profile_attn(self._h, C.byref(ams), C.byref(an)), self._L)
         return dict(gemm_ms_total=ms.value, gemm_launches=n.value, gemm_bytes=by.value, gemm_flops=fl.value,
                     attn_ms_total=ams.value, attn_launches=an.value)

@@ -4,14 +4,15 @@
 cloned not mutated, rows before start_loc are kept, per-depth top-k/top-p lists, cond None -> zeros --
 but the 256-step loop runs inside librqamd's sampling engine (csrc/engine_rqt.hip): one C call enqueues
 the whole loop on a side stream, replaying one captured hipGraph per spatial position, with the
-sampler on the device (no host sync per step).  Weights are bf16, accumulation / residual stream /
-LayerNorm / softmax / logits fp32.  Arguments of ``sample`` that cannot mean here what they mean upstream
-are never ignored silently: ``amp=True`` (fp16 autocast upstream) warns once that bf16 is the only compute
-dtype; ``cached=False`` runs a real uncached loop (every step recomputes all logits; the reference's own
+sampler on the device (no host sync per step).  Weights, GEMM operands and the KV cache are bf16 by default
+(BASELINE.json's compute dtype) and IEEE fp16 under ``amp=True`` -- the reference's ``amp`` is fp16 autocast
+(transformers.py:21,206; main_sampling_fid.py:216 passes it) and the engine's fp16 build (librqamd_f16.so) is what
+serves it: three more mantissa bits than bf16, the same MFMA rate; accumulation / residual stream / LayerNorm /
+softmax / logits are fp32 either way.  Arguments of ``sample`` that cannot mean here what they mean upstream
+are never ignored silently: ``cached=False`` runs a real uncached loop (every step recomputes all logits; the reference's own
 cross-check of its cache, transformers.py:352-356); ``is_tqdm`` / ``desc`` have nothing to report on (the
 whole loop is one asynchronous C call) and ``fast`` is unused by the reference itself."""
 import os
-import warnings
 from collections import OrderedDict
 
 import torch
@@ -39,7 +40,6 @@ def _attr(d):
 
 
 class RQTransformer(Stage2Model):
-    _amp_warned = False
 
     def __init__(self, config):
         super().__init__()
@@ -91,34 +91,50 @@ class RQTransformer(Stage2Model):
                 ('linear', nn.Linear(E, cfg['vocab_size_cond'])),
             ]))
         self._cache = None
-        self._engine = None
-        self._engine_sig = None
+        self._engines = {}                               # amp (False: bf16 engine, True: fp16 engine) -> (engine, parameter signature)
         self._side = SideStream()
         self.use_graph = os.environ.get('RQAMD_GRAPH', '1') != '0'
         # 'philox' (default): on-device sampler inside the captured graphs; 'torch': host loop + torch.multinomial (see sample)
         self.sampler = os.environ.get('RQAMD_SAMPLER', 'philox')
 
     # ------------------------------------------------------------------ engine plumbing
-    def _eng(self):
+    @property
+    def _engine(self):
+        """the default (bf16) engine, or None before its first use (bench.py / scripts read its profile counters)"""
+        return self._engines.get(False, (None, None))[0]
+
+    @_engine.setter
+    def _engine(self, value):
+        if value is None:
+            self._engines.pop(False, None)
+        else:
+            self._engines[False] = (value, None)
+
+    def _eng(self, amp=False):
+        """The native engine for this precision: amp=False -> bf16 (librqamd.so), amp=True -> IEEE fp16 (librqamd_f16.so).  Each keeps its
+        own packed copy of the parameters (pushed again whenever the module's tensors change) and its own KV cache / graphs."""
+        amp = bool(amp)
         sig = signature(self)
-        if self._engine is not None and self._engine.device != self.pos_emb_hw.device:
-            self._engine.close()                        # the module moved (model.to(other device)): rebuild there
-            self._engine = None
-        if self._engine is None or sig != self._engine_sig:
-            if self._engine is None:
+        eng, esig = self._engines.get(amp, (None, None))
+        if eng is not None and eng.device != self.pos_emb_hw.device:
+            eng.close()                                 # the module moved (model.to(other device)): rebuild there
+            eng = None
+        if eng is None or sig != esig:
+            self._cf = None                             # (a cached_forward sequence does not survive an engine rebuild / parameter push)
+            if eng is None:
                 c = self.config
                 if c.body.block.gelu != c.head.block.gelu:
                     raise NotImplementedError('different GELU variants in body and head')
                 if c.body.block.n_head != c.head.block.n_head:
                     raise NotImplementedError('different head counts in body and head')
-                self._engine = _native.RqtEngine(
+                eng = _native.RqtEngine(
                     embed_dim=c.embed_dim, n_head=c.body.block.n_head, n_layer_body=c.body.n_layer, n_layer_head=c.head.n_layer,
                     vocab_size=max(self.vocab_size), input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
                     block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=c.body.block.gelu == 'v2',
                     device=self.pos_emb_hw.device, input_emb_vqvae=c.input_emb_vqvae, head_emb_vqvae=c.head_emb_vqvae,
                     shared_tok_emb=c.shared_tok_emb, shared_cls_emb=c.shared_cls_emb, cumsum_depth_ctx=c.cumsum_depth_ctx,
-                    vocab_sizes=self.vocab_size)
-            push_all(self, self._engine)
+                    vocab_sizes=self.vocab_size, half=amp)
+            push_all(self, eng)
             # bias-free layers (attn_bias / mlp_bias = False): the engine's epilogues always add a bias vector -- zeros here
             dev = self.pos_emb_hw.device
             for prefix, stack in (('body_transformer', self.body_transformer), ('head_transformer', self.head_transformer)):
@@ -126,9 +142,9 @@ class RQTransformer(Stage2Model):
                     for leaf, lin in (('attn.query', blk.attn.query), ('attn.key', blk.attn.key), ('attn.value', blk.attn.value),
                                       ('attn.proj', blk.attn.proj), ('mlp.0', blk.mlp[0]), ('mlp.2', blk.mlp[2])):
                         if lin.bias is None:
-                            self._engine.set_param(f'{prefix}.blocks.{i}.{leaf}.bias', torch.zeros(lin.out_features, device=dev))
-            self._engine_sig = sig
-        return self._engine
+                            eng.set_param(f'{prefix}.blocks.{i}.{leaf}.bias', torch.zeros(lin.out_features, device=dev))
+            self._engines[amp] = (eng, sig)
+        return eng
 
     @staticmethod
     def _codebooks(model_aux):
@@ -175,7 +191,10 @@ class RQTransformer(Stage2Model):
         the engine's stepping entry points (rqamd_rqt_step_begin / _step_logits / _step_set_code: the arithmetic of sample()).  As in
         the reference the calls of a sequence come in sampling order after init_cache(): a call with d == 0 that does not continue
         the previous call starts a sequence -- the codes of the positions before (h, w) are taken from `xs` and only feed the body
-        stack's KV cache (the start_loc > (0, 0) prefill, :235-239) -- and a call with d > 0 must follow (h, w, d - 1).  `xs` holds
+        stack's KV cache (the start_loc > (0, 0) prefill, :235-239; that restart costs `pos` body-only steps, and so does any call that
+        finds the engine rebuilt, the parameters pushed again or `amp` changed since the previous one) -- and a call with d > 0 must
+        follow (h, w, d - 1).  `model_aux` and `cond` are read when a sequence starts; only the code of the step before is re-read
+        from `xs` at a continuing call (the reference re-embeds all of `xs` every time).  `xs` holds
         the codes drawn so far, (B, h + 1 .. H, W, D) as sample() passes them (:349); the codes of the step before are read from it
         at every call, so a caller may write them in place like sample() does (:364).  The returned tensor is the caller's own."""
         (h, w, d) = (int(v) for v in sample_loc)
@@ -183,8 +202,10 @@ class RQTransformer(Stage2Model):
         (H, W_, D_) = self.block_size
         assert (W, D) == (W_, D_) and h < Hx <= H and 0 <= w < W and 0 <= d < D
         pos = h * W + w
-        eng = self._eng()
+        eng = self._eng(amp)
         st = getattr(self, '_cf', None)
+        if st is not None and st.get('eng') is not eng:
+            st = None                                   # another engine (precision) or a rebuilt one: the sequence restarts
         if st is None or st['next'] != (pos, d) or st['B'] != B:
             if d != 0:
                 raise RuntimeError(f'cached_forward(sample_loc={tuple(sample_loc)}): depth {d} must follow depth {d - 1} of the same position '
@@ -204,7 +225,7 @@ class RQTransformer(Stage2Model):
             hp, wp = divmod(pos - 1, W)
             eng.step_set_code(pos - 1, D - 1, xs[:, hp, wp, D - 1].to(torch.long).contiguous())
         logits = eng.step_logits(pos, d).clone()
-        self._cf = {'next': (pos, d + 1) if d + 1 < D else (pos + 1, 0), 'B': B}
+        self._cf = {'next': (pos, d + 1) if d + 1 < D else (pos + 1, 0), 'B': B, 'eng': eng}
         return logits
 
     def embed_with_model_aux(self, xs, model_aux):
@@ -222,22 +243,22 @@ class RQTransformer(Stage2Model):
             # (transformers.py:150-153,185-186); the engine takes them from the multi-token prefill of the prefix
             (B, H, W, D) = xs.shape
             assert torch.Size([H, W, D]) == self.block_size
-            eng = self._eng()
+            eng = self._eng(amp)
             cbs = self._checked_codebooks(model_aux)
             codes = xs.to(torch.long).contiguous()
             c = self._cond(cond, B, xs.device)
             if c is None:
                 c = torch.zeros((B, self.block_size_cond), dtype=torch.long, device=xs.device)
             return self._on_side_stream(xs.device, lambda: eng.forward(codes, c, cbs))
-        return self.teacher_forced_logits(xs, model_aux, cond)
+        return self.teacher_forced_logits(xs, model_aux, cond, amp=amp)
 
     @torch.no_grad()
-    def teacher_forced_logits(self, xs, model_aux=None, cond=None):
+    def teacher_forced_logits(self, xs, model_aux=None, cond=None, amp=False):
         """seq_logits of forward() (transformers.py:113-188) for any block_size_cond, via the engine's cached path."""
         (B, H, W, D) = xs.shape
         assert torch.Size([H, W, D]) == self.block_size
         self._cf = None
-        eng = self._eng()
+        eng = self._eng(amp)
         cbs = self._checked_codebooks(model_aux)
         codes = xs.to(torch.long).contiguous()
         c = self._cond(cond, B, xs.device)
@@ -268,13 +289,7 @@ class RQTransformer(Stage2Model):
             top_p_list = [min(top_p[i], 1.0) for i in range(D)]
         B = partial_sample.shape[0]
         device = partial_sample.device
-        if amp and not RQTransformer._amp_warned:
-            # the reference's amp=True is fp16 autocast (transformers.py:305,346); this engine has ONE compute dtype, bf16 GEMM
-            # operands with fp32 accumulation / residual stream / LayerNorm / softmax / logits (BASELINE.json), whatever amp says
-            warnings.warn('RQTransformer.sample(amp=True): librqamd computes in bf16 (fp32 accumulation) regardless of `amp`; '
-                          'there is no fp16 autocast path', stacklevel=2)
-            RQTransformer._amp_warned = True
-        eng = self._eng()
+        eng = self._eng(amp)                            # amp=True: the fp16 build of the engine (the reference's fp16 autocast)
         cbs = self._checked_codebooks(model_aux)
         xs = partial_sample.to(torch.long).contiguous()
         c = self._cond(cond, B, device)

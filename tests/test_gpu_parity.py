@@ -469,12 +469,10 @@ def test_rqt_sample_semantics(nat, golden):
     assert torch.equal(o1, o2)
 
 
-def test_rqt_sample_uncached_equals_cached_and_amp_warns(nat, golden):
+def test_rqt_sample_uncached_equals_cached(nat, golden):
     """sample(cached=False) (transformers.py:352-356, the reference's own cross-check of its KV cache): every step recomputes
     the logits of the whole code map from the codes so far; with the cached path's draw at each step the codes must come out
-    IDENTICAL -- i.e. the cache changes nothing, bit for bit.  amp=True warns once (bf16 is the only compute dtype)."""
-    import warnings
-    from rqvae.models.rqtransformer import RQTransformer
+    IDENTICAL -- i.e. the cache changes nothing, bit for bit."""
     g = golden('rqt_tiny.npz')
     vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
     cond = G(g['cond'], torch.long)[:2].contiguous()
@@ -492,12 +490,46 @@ def test_rqt_sample_uncached_equals_cached_and_amp_warns(nat, golden):
     torch.cuda.manual_seed_all(3)
     c2 = ar.sample(part2, vae, cond=cond, start_loc=(1, 0), top_k=5, cached=False)
     assert torch.equal(c1, c2) and torch.equal(c1[:, :1], a[:, :1])
-    RQTransformer._amp_warned = False
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter('always')
-        ar.sample(partial, vae, cond=cond, amp=True)
-        ar.sample(partial, vae, cond=cond, amp=True)
-    assert sum('bf16' in str(x.message) for x in w) == 1
+
+
+# fp16 engine (amp=True): logits vs the reference's fp32 ones.  The reference's own fp16 autocast is 0.0015-0.0018 max / 0.00026 mean off its
+# fp32 logits (profiles/r05_amp_precision_costing.txt); measured here 0.0013-0.0020 max / 0.00022-0.00028 mean (bf16: 0.0107 / 0.0017)
+F16_MAX_ERR, F16_MEAN_ERR = 0.004, 0.0006
+
+
+def test_rqt_amp_fp16_engine(nat, golden):
+    """amp=True (transformers.py:21,206: the reference's fp16 autocast; main_sampling_fid.py:216 passes it) runs on the fp16 build of the
+    engine (librqamd_f16.so: weights, GEMM operands and KV cache IEEE fp16; fp32 accumulation / residual stream / LayerNorm / softmax /
+    logits): teacher-forced logits within 0.004 of the reference's fp32 ones on the tiny fixture (bf16: 0.011; the full 1.4B model:
+    test_gpu_parity_big.py),
+    cached_forward == forward bit for bit in that mode too, sample(amp=True) reproducible, graph == eager == uncached, and the bf16
+    engine's results are untouched by the fp16 engine living next to it."""
+    g = golden('rqt_tiny.npz')
+    vae, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
+    codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    bf = ar(codes, vae, cond=cond)
+    hf = ar(codes, vae, cond=cond, amp=True)
+    assert ar._eng(True).half and not ar._eng(False).half and ar._eng(True) is not ar._eng(False)
+    e16, ebf = np.abs(N(hf) - g['logits']), np.abs(N(bf) - g['logits'])
+    print('rqt tiny logits, fp16 engine (amp=True): max err %.4f mean %.5f (bf16 engine: %.4f / %.5f)' % (e16.max(), e16.mean(), ebf.max(), ebf.mean()))
+    assert e16.max() < F16_MAX_ERR and e16.mean() < F16_MEAN_ERR
+    assert torch.equal(ar(codes, vae, cond=cond), bf)                       # the bf16 engine is unaffected
+    # the reference's own loop over cached_forward in fp16: == the teacher-forced logits of that mode
+    B, H, W, D = codes.shape
+    ar.init_cache()
+    for h in range(H):
+        for w in range(W):
+            for d in range(D):
+                lg = ar.cached_forward(codes[:, :h + 1], vae, cond=cond, amp=True, sample_loc=(h, w, d))
+                assert torch.equal(lg, hf[:, h, w, d]), (h, w, d)
+    partial = torch.zeros((2, 4, 4, 4), dtype=torch.long, device=DEV)
+    res = []
+    for graph, cached in ((True, True), (False, True), (True, False)):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(5)
+        res.append(ar.sample(partial, vae, cond=cond[:2].contiguous(), top_k=20, top_p=0.9, amp=True, cached=cached))
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert int(res[0].min()) >= 0 and int(res[0].max()) < 500
 
 
 def test_rqt_sample_torch_multinomial_mode(nat, golden):

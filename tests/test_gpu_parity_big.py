@@ -172,6 +172,58 @@ def test_rqt_in1400m_through_the_benchmarked_kernels(golden):
     torch.cuda.empty_cache()
 
 
+def test_rqt_in1400m_amp_fp16_engine(golden):
+    """amp=True on the full 1.4B model: the fp16 build of the engine against the REFERENCE's fp32 logits -- 2 rows (weight-streaming
+    kernels), 2050 rows through the kernels of the bench batch (256 x 256 eight-phase GEMMs) and exactly 500 rows (mid-batch tiles).
+    Bound 0.004 max / 0.0006 mean (the reference's own fp16 autocast is 0.0015-0.0018 / 0.00026 off its fp32 logits; this engine's
+    bf16 default 0.0154 / 0.0022).  Overflow: fp16 storage saturates to inf beyond 65504 exactly like torch.float16; the tensors stored
+    in 16 bits here (LayerNorm outputs, q / k / v, attention outputs, GELU outputs, weights) stay far inside it on these models."""
+    from rqvae import _native
+    g = golden('rqt_in1400m.npz')
+    cfg = C.RQT_IN_1400M
+    ar = _load(cfg, int(g['seed']))
+    V, D = cfg['vocab_size'], cfg['block_size'][2]
+    cb = np.random.default_rng(int(g['cb_seed'])).standard_normal((V, 256), dtype=np.float32)
+    aux = Aux(cb, D)
+    ref = g['logits'].astype(np.float32)
+    codes2, cond2 = G(g['codes'], torch.long), G(g['cond'], torch.long)
+    out = ar(codes2, aux, cond=cond2, amp=True)
+    got = torch.stack([out[:, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+    err = np.abs(got - ref)
+    print(f'rqt in1400m, fp16 engine (amp=True): logits max err {err.max():.4f} mean {err.mean():.5f}')
+    assert err.max() < 0.004 and err.mean() < 0.0006
+    reps = 1025
+    codes = G(np.tile(g['codes'], (reps, 1, 1, 1)), torch.long)
+    cond = G(np.tile(g['cond'], (reps, 1)), torch.long)
+    lib16 = _native.lib16()
+    _native.check(lib16.rqamd_dbg_set_row_scale(5), lib16)
+    try:
+        out = ar(codes, aux, cond=cond, amp=True)
+    finally:
+        _native.check(lib16.rqamd_dbg_set_row_scale(1), lib16)
+    worst = 0.0
+    for r0 in (0, 1024, 2048):
+        gb = torch.stack([out[r0:r0 + 2, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+        worst = max(worst, float(np.abs(gb - ref).max()))
+        assert np.abs(gb - ref).mean() < 0.0006
+    print(f'rqt in1400m, fp16 engine, through the large-batch kernels (2050 rows): logits max err {worst:.4f}')
+    assert worst < 0.004
+    out = ar(codes[:500].contiguous(), aux, cond=cond[:500].contiguous(), amp=True)
+    gb = torch.stack([out[498:500, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
+    print(f'rqt in1400m, fp16 engine, exactly 500 rows per step: logits max err {np.abs(gb - ref).max():.4f}')
+    assert np.abs(gb - ref).max() < 0.004
+    # sampling in that mode: graph == eager, codes in range
+    part = torch.zeros_like(codes2)
+    res = []
+    for graph in (True, False):
+        ar.use_graph = graph
+        torch.cuda.manual_seed_all(77)
+        res.append(ar.sample(part, aux, cond=cond2, top_k=1024, top_p=0.95, amp=True))
+    assert torch.equal(res[0], res[1]) and int(res[0].min()) >= 0 and int(res[0].max()) < V
+    del out, ar
+    torch.cuda.empty_cache()
+
+
 def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch):
     """Opt-in 8-bit key cache (RQAMD_KV=int8k) on the full 1.4B model against the REFERENCE's logits with the bound of
     the bf16 cache: 2 rows (small-batch kernels, <= 8-key and register-block attention forms) and 2050 rows through the kernels of the

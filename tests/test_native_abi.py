@@ -34,6 +34,14 @@ def test_header_symbols_exported(lib_path):
     assert declared == set(_native.EXPORTS)
     lib.rqamd_abi_version.restype = ctypes.c_int
     assert lib.rqamd_abi_version() == _native.ABI_VERSION == 6
+    # the fp16 build of the RQ-Transformer engine (sample(amp=True)): the rqamd_rqt_* subset of the same ABI
+    assert os.path.exists(_native.LIB16_PATH)
+    lib16 = ctypes.CDLL(_native.LIB16_PATH)
+    for name in _native.EXPORTS_F16:
+        assert hasattr(lib16, name), f'{name} missing from librqamd_f16.so'
+    assert {n for n in declared if n.startswith('rqamd_rqt_')} <= set(_native.EXPORTS_F16)
+    lib16.rqamd_abi_version.restype = ctypes.c_int
+    assert lib16.rqamd_abi_version() == _native.ABI_VERSION
 
 
 def test_status_codes_without_gpu(lib_path):
