@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument('--top-k', type=int, default=1024)
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--sweep', type=str, default='64,100,200,500', help='extra per-GPU batches measured after the timed region ("" = none)')
+    ap.add_argument('--formats', type=int, default=1,
+                    help='1 (default): after everything else, time the 1.4B model at 2048 images with the default bf16 engine, the opt-in 8-bit key '
+                         'cache (RQAMD_KV=int8k) and the fp16 build of the engine (sample(amp=True)) -> "kv_cache_formats"; 0: skip (~25 s)')
     ap.add_argument('--also', type=str, default='xhuge:64,txt3900m:64',
                     help='model:batch points measured after everything else on rank 0 at N = 1 (default: the two models BASELINE.json quotes on '
                          '8 GPUs, at their per-GPU share of 64 images; "" = none).  Adds ~40 s to a default run: after the headline model is '
@@ -351,7 +354,14 @@ def decoder_flops_per_image(dd, embed_dim, executed=False):
                 fl += attn(block_in, res)
         if lvl != 0:
             res *= 2
-            sub = executed and res >= 64 and (res // 2) % 32 == 0 and not os.environ.get('RQAMD_NO_UPS_SUBPIXEL')
+            # the engine's own eligibility test for the sub-pixel form (VaeRun::conv + rq_conv_halo_subpixel_supported, engine_vae.hip /
+            # conv_halo.hip): halo kernel available at that layer (output side >= 64, or 32 with the low-resolution halo rule; whole
+            # 8 x 32 output tiles; Cin % 64 == 0, Cout % 128 == 0), source image in whole 8 x 32 tiles, no A/B switch set
+            src = res // 2
+            halo = (res >= 64 or os.environ.get('RQAMD_HALO_LOWRES', '1') != '0') and res % 32 == 0 and res % 8 == 0 \
+                and block_in % 128 == 0 and res * res <= 65536
+            off = any(os.environ.get(k) for k in ('RQAMD_NO_HALO', 'RQAMD_NO_HALO_UPS', 'RQAMD_NO_UPS_SUBPIXEL'))
+            sub = executed and halo and not off and src % 32 == 0 and src % 8 == 0
             fl += conv(block_in, block_in, 3, res) * (4.0 / 9.0 if sub else 1.0)
     return fl + conv(block_in, dd['out_ch'], 3, res)
 
@@ -895,25 +905,33 @@ def main(argv=None):
     # ---- the opt-in 8-bit key cache next to the default bf16 one ("report both ways"), same model, one moderate batch, measured live;
     # the headline batch both ways: profiles/r05_kv_int8k_ab.txt.  Engines read RQAMD_KV when they are created.
     kv_formats = None
-    if rank == 0 and world == 1 and args.also and args.model == 'huge' and not args.overlap and os.environ.get('RQAMD_KV', 'bf16') == 'bf16':
+    if rank == 0 and world == 1 and args.formats and args.model == 'huge' and not args.overlap and os.environ.get('RQAMD_KV', 'bf16') == 'bf16':
         kv_formats = []
+        kv_before = os.environ.get('RQAMD_KV')
         try:
-            for fmt in ('bf16', 'int8k'):
-                os.environ['RQAMD_KV'] = fmt
+            # ('fp16': the fp16 build of the engine, what sample(amp=True) runs on -- same MFMA rate, three more mantissa bits)
+            for fmt in ('bf16', 'int8k', 'fp16'):
+                os.environ['RQAMD_KV'] = 'bf16' if fmt == 'fp16' else fmt
                 _, ar3, cfg3 = presets.build('huge', device=device, seed=0)
+                if fmt == 'fp16':
+                    _s = ar3.sample
+                    ar3.sample = lambda *a, **k: _s(*a, **dict(k, amp=True))
                 ips, a_ms, d_ms, es, ec = timed_batch(vae, ar3, 2048, device, args.top_k, args.top_p, steps=2, warmup=1)
                 kv_formats.append({'kv_cache': fmt, 'batch_per_gpu': 2048, 'images_per_sec': ips, 'ar_ms_per_image': a_ms,
-                                   'kv_bytes_per_image_GB': kv_bytes_per_image(cfg3) / 1e9})
-                if getattr(ar3, '_engine', None) is not None:
-                    ar3._engine.close()
-                    ar3._engine = None
+                                   'kv_bytes_per_image_GB': kv_bytes_per_image(cfg3) / 1e9})      # (reads RQAMD_KV, set above)
+                for e3, _sig in list(ar3._engines.values()):
+                    e3.close()
+                ar3._engines.clear()
                 del ar3, es, ec
                 torch.cuda.empty_cache()
         except Exception as e:
-            print(f'bench.py: kv-cache format comparison failed: {e!r}', file=sys.stderr)
+            print(f'bench.py: storage-format comparison failed: {e!r}', file=sys.stderr)
             kv_formats.append({'error': repr(e)})
         finally:
-            os.environ.pop('RQAMD_KV', None)
+            if kv_before is None:
+                os.environ.pop('RQAMD_KV', None)
+            else:
+                os.environ['RQAMD_KV'] = kv_before
 
     if rank == 0:
         n_img = world * B * args.steps

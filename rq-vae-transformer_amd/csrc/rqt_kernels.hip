@@ -217,11 +217,20 @@ static __device__ __forceinline__ rq_u64w quant_key_chunk(rq_u128 kbf, float& sc
     am = fmaxf(am, rq_dpp_xor1(am));
     am = fmaxf(am, rq_dpp_xor2(am));
     am = fmaxf(am, rq_dpp_half_mirror(am));
-    scale = am > 0.f ? am * (1.0f / 127.0f) : 1.0f;
-    const float inv = am > 0.f ? 127.0f / am : 0.f;
+    // a key with a NaN / inf component cannot be represented: its scale becomes NaN (every score against it is NaN, as with the bf16
+    // cache) and its bytes the zero point -- never an int cast of a non-finite value
+    float amf = am;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amf = kf[e] == kf[e] ? amf : __int_as_float(0x7fc00000);      // (fmaxf drops NaNs)
+    amf = amf + rq_dpp_xor1(amf) * 0.f;
+    amf = amf + rq_dpp_xor2(amf) * 0.f;
+    amf = amf + rq_dpp_half_mirror(amf) * 0.f;
+    const bool fin = amf <= 3.0e38f;                                   // false for NaN and inf
+    scale = fin ? (am > 0.f ? am * (1.0f / 127.0f) : 1.0f) : __int_as_float(0x7fc00000);
+    const float inv = (fin && am > 0.f) ? 127.0f / am : 0.f;
     uint32_t u[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) u[e] = (uint32_t)((int)rintf(kf[e] * inv) + 128) & 0xffu;
+    for (int e = 0; e < 8; ++e) u[e] = (uint32_t)((int)rintf(fin ? kf[e] * inv : 0.f) + 128) & 0xffu;
     rq_u64w w;
     w.x = u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24);
     w.y = u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24);

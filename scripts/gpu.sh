@@ -44,7 +44,7 @@ bench)
   tail -1 gpurun_out/${TAG}_bench.log > gpurun_out/${TAG}_bench.json; cat gpurun_out/${TAG}_bench.json ;;
 trace)
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --sweep "" --also "" $RQ_TRACE_ARGS > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o trace -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --sweep "" --also "" --formats 0 $RQ_TRACE_ARGS > $R/gpurun_out/${TAG}_rocprof.log 2>&1
   cd $R; stats_md gpurun_out/prof gpurun_out/${TAG}_kernel_stats.md; rm -rf gpurun_out/prof ;;
 pmc)
   M=${RQ_M:-8192}

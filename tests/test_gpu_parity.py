@@ -741,6 +741,47 @@ def test_vae_full_size_batch_golden(nat, golden):
     if not same[clear].all():      # (say which margins failed)
         print(f'vae imagenet get_codes x8: {int((clear & ~same).sum())} clear-margin codes differ; their top-2 gaps: {np.sort(gaps[clear & ~same])[:8]}')
     assert clear.sum() > 0.5 * clear.size and same[clear].all()
+    # Round 6: tie the codes that DO differ to the encoder's error budget.  With the shallower depths equal, this
+    # engine's residual is the reference's plus dz = z_e - z_e(ref), so choosing c_b where the reference chose c_a needs
+    #   d(c_b) - d(c_a) <= 2 dz.(c_b - c_a) <= 2 |dz| |c_b - c_a|      (d = squared distance of the reference's residual)
+    # -- a flip the measured z_e error cannot explain would be a quantiser bug, not rounding.  Checked per flipped code; and the flip
+    # rate of first-depth codes by top-2 margin is printed and bounded (measured on MI355X: see the message).
+    dz = (z_e - g['z_e']).reshape(-1, 256).astype(np.float64)
+    zr = g['z_e'].reshape(-1, 256).astype(np.float64)
+    co, cr = codes.reshape(-1, 4), g['enc_codes'].reshape(-1, 4)
+    gp = gaps.reshape(-1, 4)
+    cb64 = cb.astype(np.float64)
+    n_flip = n_checked = 0
+    slack = []
+    for v in range(co.shape[0]):
+        res = zr[v].copy()
+        for k in range(4):
+            if co[v, k] != cr[v, k]:
+                n_flip += 1
+                ca, cbk = cb64[cr[v, k]], cb64[co[v, k]]
+                gap_ab = ((res - cbk) ** 2).sum() - ((res - ca) ** 2).sum()
+                room = 2.0 * np.linalg.norm(dz[v]) * np.linalg.norm(cbk - ca)
+                assert -1e-3 <= gap_ab <= room + 1e-3, (v, k, gap_ab, room)
+                assert gp[v, k] <= gap_ab + 1e-6
+                slack.append(gap_ab / room)
+                n_checked += 1
+                break                                   # deeper depths of this vector quantise another residual
+            res -= cb64[cr[v, k]]
+    g0, s0 = gp[:, 0], co[:, 0] == cr[:, 0]
+    bins = [(0.0, 0.02), (0.02, 0.05), (0.05, 0.1), (0.1, 0.2), (0.2, 0.5), (0.5, 1e9)]
+    rates = [(lo, hi, int(((g0 >= lo) & (g0 < hi)).sum()), float((~s0[(g0 >= lo) & (g0 < hi)]).mean()) if ((g0 >= lo) & (g0 < hi)).any() else 0.0)
+             for lo, hi in bins]
+    print('vae imagenet get_codes x8: %d first-differing codes, each inside 2 |dz| |c_b - c_a| (largest share of that room used: %.2f); '
+          'first-depth flip rate by top-2 margin: ' % (n_checked, max(slack) if slack else 0.0)
+          + ', '.join(f'[{lo:g}, {hi:g}): {r:.3f} of {n}' for lo, hi, n, r in rates))
+    # bounds ~2 x what was measured on MI355X (round 6, 512 vectors: 9 first-depth flips = 0.018; by margin 1 of 1, 1 of 4, 4 of 9, 2 of 16,
+    # 1 of 51, 0 of 431; the largest share of its Cauchy-Schwarz room a flip used: 0.22): none from 0.5 up, <= 8 % in [0.2, 0.5),
+    # <= 50 % in [0.05, 0.2), <= 4 % of all first-depth codes
+    in_bin = lambda lo, hi: (g0 >= lo) & (g0 < hi)
+    assert not (~s0[in_bin(0.5, 1e9)]).any()
+    assert (~s0[in_bin(0.2, 0.5)]).mean() <= 0.08
+    assert (~s0[in_bin(0.05, 0.2)]).mean() <= 0.5
+    assert (~s0).mean() <= 0.04
 
 
 def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
