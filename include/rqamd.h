@@ -154,7 +154,8 @@ typedef struct {
     int input_embed_dim;      /* codebook dim fed to input_mlp/head_mlp */
     int vocab_size_cond, block_size_cond;
     int H, W, D;              /* block_size */
-    int gelu_v2;              /* attentions.py:25-36: 0 = exact erf GELU ('v1'), 1 = x*sigmoid(1.702x) */
+    int gelu_v2;              /* attentions.py:25-36: 0 = exact erf GELU ('v1') in both stacks, 1 = x*sigmoid(1.702x) ('v2') in both;
+                                 2 = body 'v1' / head 'v2', 3 = body 'v2' / head 'v1' (the stacks have their own block configs) */
     /* stage-2 flags (transformers.py:60-99; every released config sets all five): 0 selects the primitives.py variants --
      * learned token embeddings (nn.Embedding / TupleEmbedding "tok_emb") instead of the RQ-VAE codebook through
      * input_mlp / head_mlp, no depth cumsum in the head context, one classifier matrix per depth (BatchLinear) */

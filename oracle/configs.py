@@ -84,6 +84,12 @@ RQT_TINY_NOBIAS = _variant(RQT_TINY)
 RQT_TINY_NOBIAS['body']['block']['attn_bias'] = False
 RQT_TINY_NOBIAS['head']['block']['mlp_bias'] = False
 
+# the two stacks with different GELU forms (AttentionBlockConfig.gelu per stack, configs.py:21-40, attentions.py:25-36,117-122): body 'v2'
+# (x * sigmoid(1.702 x)), head 'v1' (erf) -- round 6
+RQT_TINY_GELUMIX = _variant(RQT_TINY)
+RQT_TINY_GELUMIX['body']['block']['gelu'] = 'v2'
+RQT_TINY_GELUMIX['head']['block']['gelu'] = 'v1'
+
 PARAM_COUNTS_M = {  # BASELINE.md §2 / reference README.md:38-47
     'RQT_FFHQ_355M': 355.4, 'RQT_IN_480M': 480.9, 'RQT_IN_821M': 820.9,
     'RQT_IN_1400M': 1387.5, 'RQT_IN_3800M': 3822.5, 'RQT_CC3M_654M': 654.1,

@@ -67,7 +67,8 @@ class RQTransformerOracle:
         self.nh_layers = cfg['head']['n_layer']
         self.n_head_body = cfg['body']['block']['n_head']
         self.n_head_head = cfg['head']['block']['n_head']
-        self.gelu = cfg.get('gelu', 'v1')
+        # AttentionBlockConfig.gelu of each stack (configs.py:21-40, attentions.py:25-36,117-122); every released config: 'v1'
+        self.gelu = {'body_transformer': cfg['body']['block'].get('gelu', 'v1'), 'head_transformer': cfg['head']['block'].get('gelu', 'v1')}
         # variant flags (transformers.py:60-99): all True in every released config
         self.input_vq = cfg.get('input_emb_vqvae', True)
         self.head_vq = cfg.get('head_emb_vqvae', True)
@@ -113,7 +114,7 @@ class RQTransformerOracle:
             a, present = self._attn(pre, h, n_head), None
         x = x + a
         h = layer_norm(x, p[f'{pre}.ln2.weight'], p[f'{pre}.ln2.bias'])
-        h = gelu(linear(h, p[f'{pre}.mlp.0.weight'], p.get(f'{pre}.mlp.0.bias')), self.gelu)
+        h = gelu(linear(h, p[f'{pre}.mlp.0.weight'], p.get(f'{pre}.mlp.0.bias')), self.gelu[pre.split('.', 1)[0]])
         x = x + linear(h, p[f'{pre}.mlp.2.weight'], p.get(f'{pre}.mlp.2.bias'))
         return x, present
 

@@ -77,6 +77,7 @@ struct rqamd_rqt {
     uint64_t* rng;      // {seed, offset}
     int* smp_redo;      // [rows] sampler workspace (rows the top-k kernel hands back to the general kernel)
     int max_slabs = 8;
+    int cur_gelu_v2 = 0;   // GELU form of the stack being run (cfg.gelu_v2: 0 both erf, 1 both sigmoid, 2 body erf / head sigmoid, 3 body sigmoid / head erf)
     bool kv_int8k = false;   // RQAMD_KV=int8k when the handle was created: body-stack keys cached as 64 bytes + one fp32 scale (rqt_kernels.hip)
 
     // graph cache
@@ -119,6 +120,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     if (c->n_layer_body < 1 || c->n_layer_head < 0)      // head.n_layer = 0: the depth-1 "VQ-GAN" shapes (measure_throughput/__main__.py:166-210)
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: needs >= 1 body layer and >= 0 head layers");
     if (c->D < 1 || c->D > 8 || c->H < 1 || c->W < 1) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: bad block_size");
+    if (c->gelu_v2 < 0 || c->gelu_v2 > 3) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: gelu_v2 = %d (0 .. 3)", c->gelu_v2);
     rqamd_rqt* h = new rqamd_rqt();
     h->cfg = *c;
     {   // opt-in storage format of the body stack's key cache, fixed for the life of the handle (default: bf16, what BASELINE.json asks for)
@@ -390,7 +392,7 @@ static int step_gemm(rqamd_rqt* h, const bf16_t* A, int lda, const bf16_t* W, in
                      const float* bias, const int* bias_step, int bias_stride, void* out, int ldo, int* n_slabs, hipStream_t st,
                      float* resid = nullptr, const float* resid_bias = nullptr) {
     GemmArgs a{};
-    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cfg.gelu_v2;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.epi = epi; a.gelu_v2 = h->cur_gelu_v2;
     a.bias = bias; a.bias_step = bias_step; a.bias_stride = bias_stride; a.out = out; a.ldo = ldo;
     int bm, bn, sk, gl = 0;
     rq_gemm_pick_tile(M, N, K, epi == EPI_F32_PARTIAL, &bm, &bn, &sk, &gl);
@@ -486,6 +488,7 @@ struct StepCtx {
 // t_max: host-side bound on the number of cached keys (selects the attention kernel's register-block count)
 static int body_stack(rqamd_rqt* h, int rows, const int* step, int step_off, int t_max, Pending& pend, hipStream_t st) {
     pend = Pending{nullptr, 0, nullptr};
+    h->cur_gelu_v2 = h->cfg.gelu_v2 == 1 || h->cfg.gelu_v2 == 3;
     for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, step, step_off, t_max, h->Tbody, st));
     return RQAMD_OK;
 }
@@ -544,6 +547,7 @@ static int position_depth(rqamd_rqt* h, const StepCtx& c, int d, const Pending& 
         else RQ_TRY(tok_embed(h, c, 0, d - 1, d, h->pos_d, false, d, h->xh, st));
         hp = Pending{nullptr, 0, nullptr};
     }
+    h->cur_gelu_v2 = h->cfg.gelu_v2 == 1 || h->cfg.gelu_v2 == 2;
     for (size_t li = 0; li < h->head.size(); ++li) {
         RQ_TRY(run_block(h, h->head[li], li == 0 ? x_in : h->xh, h->xh, hp, li == 0 ? addvec : nullptr, B, nullptr, d, d, h->D, st));
     }
@@ -603,6 +607,7 @@ static int begin_batch(rqamd_rqt* h, const StepCtx& c, const int64_t* partial, c
             const int rows = pf.n_img * P;
             RQ_TRY(rq_launch_cond_embed_multi(h->cond + (long)b0 * h->cond_len, h->cond_len, P, h->cond_emb, vc, h->pos_cond, h->x, pf.n_img, h->E, st));
             Pending pend{nullptr, 0, nullptr};
+            h->cur_gelu_v2 = h->cfg.gelu_v2 == 1 || h->cfg.gelu_v2 == 3;
             for (auto& L : h->body) RQ_TRY(run_block(h, L, h->x, h->x, pend, nullptr, rows, nullptr, 0, 0, h->Tbody, st, &pf));
             if (c.cond_logits_out) {
                 if (!h->w_ccls || h->n_ccls_seen < 4) return rq_fail(RQAMD_ERR_STATE, "rqt: cond_classifier parameters not set");

@@ -336,7 +336,8 @@ def gen_rqt_variants():
     hps, dd = C.VAE_TINY
     vae, vparams = ref_rqvae(hps, dd, seed=31)
     cb = vparams['quantizer.codebooks.0.weight'][:-1]
-    for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED), ('nobias', C.RQT_TINY_NOBIAS)):
+    for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED), ('nobias', C.RQT_TINY_NOBIAS),
+                     ('gelumix', C.RQT_TINY_GELUMIX)):
         m, params = ref_rqt(cfg, seed=47)
         H, W, D = cfg['block_size']
         vs = cfg['vocab_size'] if isinstance(cfg['vocab_size'], list) else [cfg['vocab_size']] * D

@@ -402,14 +402,15 @@ def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
         _rqt_engine(nat, cfg, params)
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix'])
 def test_emu_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding + BatchLinear + per-depth vocabularies; cumsum_depth_ctx off; learned head
     embedding) through the mirror classes and the engine, against the reference's forward() logits."""
     from rqvae.models.rqtransformer import RQTransformer
     from rqvae.models.rqvae import RQVAE
     g = golden(f'rqt_var_{tag}.npz')
-    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS}[tag]
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS,
+           'gelumix': C.RQT_TINY_GELUMIX}[tag]
     hps, dd = C.VAE_TINY
     vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
     vae.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed'])).items()})
@@ -425,8 +426,14 @@ def test_emu_rqt_flag_variants(nat, golden, tag):
         emb = ar.tok_emb(codes)
         assert emb.shape == codes.shape + (ar.tok_emb.embedding_dim,)
         assert torch.equal(emb, ar.tok_emb.weight.detach()[codes + ar.tok_emb.offsets.view(1, 1, 1, -1)])
-        with pytest.raises(RuntimeError):
-            ar.classifier.linear(torch.zeros(1, 4, 128))
+        # BatchLinear / LogitMask on their own (round 6: plain torch forms for stand-alone use, any device, differentiable)
+        hvec = torch.randn(3, 4, 128)
+        lin = ar.classifier.linear
+        want = torch.einsum('bij,ijk->bik', hvec, lin.weight.detach()) + lin.bias.detach()
+        assert torch.allclose(lin(hvec), want, atol=1e-5)
+        assert torch.allclose(lin(hvec[:, :2], indices=[3, 1]), want[:, [3, 1]] - want[:, [3, 1]] + torch.einsum('bij,ijk->bik', hvec[:, :2], lin.weight.detach()[[3, 1]]) + lin.bias.detach()[[3, 1]], atol=1e-5)
+        masked = ar.classifier.logit_mask(torch.zeros(2, 4, max(ar.vocab_size)))
+        assert all(torch.isinf(masked[:, d, v:]).all() and not torch.isinf(masked[:, d, :v]).any() for d, v in enumerate(ar.vocab_size))
         ar.use_graph = False
         out = ar.sample(torch.zeros_like(codes), None, cond=cond, top_k=50, top_p=0.9)
         vs = ar.vocab_size

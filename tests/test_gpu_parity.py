@@ -605,12 +605,13 @@ def test_rqt_text_conditioned(nat, golden):
     assert torch.equal(a, b) and int(a.max()) < 500
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix'])
 def test_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding / BatchLinear / LogitMask, cumsum_depth_ctx off, learned head embedding):
     teacher-forced logits vs the reference's forward(), sampling inside each depth's vocabulary, graph == eager."""
     g = golden(f'rqt_var_{tag}.npz')
-    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS}[tag]
+    cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS,
+           'gelumix': C.RQT_TINY_GELUMIX}[tag]
     vae, _, _, _ = _models(C.VAE_TINY, None, int(g['vae_seed']), 0)
     from rqvae.models.rqtransformer import RQTransformer
     ar = RQTransformer(cfg)
