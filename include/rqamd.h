@@ -258,6 +258,11 @@ int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, in
 /* Kernel variants are selected by the number of rows (batch).  factor > 1 makes the selection logic see rows * factor, so
  * that the large-batch variants run on test-sized inputs (results must not change); 1 restores normal behaviour. */
 int rqamd_dbg_set_row_scale(int factor);
+/* Diagnostics (scripts/lanes_probe2.py, round 6): `dst` -- a handle of the same configuration that has not run yet -- drops its own
+ * parameter arena and runs on `src`'s (its own workspace, KV caches, graphs): two handles fed half a batch each on two streams are two
+ * independent decode chains over one copy of the weights.  Measured slower than one chain at every batch (profiles/r06_lanes_probe.txt);
+ * not used by the product path. */
+int rqamd_dbg_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src);
 
 /* The dense bf16 MFMA rate the board sustains, measured: `launches` launches of one 512-thread workgroup per CU, every wavefront issuing
  * n_per_wave v_mfma_f32_32x32x16_bf16 from registers alone.  mode 0: constant operands (the data-sheet instruction rate); mode 1: operands

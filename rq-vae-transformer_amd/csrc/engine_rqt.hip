@@ -736,7 +736,7 @@ extern "C" int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64
 // ---- lanes (round 6): a second handle that runs on the SAME parameter arena as `src` -- its own workspace, KV caches, graphs and
 // stepping state, no weights of its own.  Two handles fed half a batch each on two streams run two independent decode chains
 // over one copy of the weights (L2 / MALL hits for whichever chain reaches a layer second).
-extern "C" int rqamd_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src) {
+extern "C" int rqamd_dbg_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src) {
     if (!dst || !src) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: null argument");
     if (memcmp(&dst->cfg, &src->cfg, sizeof(dst->cfg)) != 0) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: configurations differ");
     if (src->seen.size() - src->n_ccls_seen < src->n_required || src->tables_dirty)

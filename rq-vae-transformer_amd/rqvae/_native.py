@@ -88,6 +88,7 @@ _SIGS = {
     'rqamd_dbg_conv_halo_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_set_row_scale': (C.c_int, [C.c_int]),
+    'rqamd_dbg_rqt_share_params': (C.c_int, [C.c_void_p, C.c_void_p]),
     'rqamd_dbg_mfma_rate': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     'rqamd_dbg_conv_in_bf16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_dbg_ups_subpixel_weights': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Probe (round 6): L independent decode chains ("lanes") of B/L rows each on L HIP streams, ALL ON ONE COPY OF THE WEIGHTS
-(rqamd_rqt_share_params), against one chain of B rows.  Round 2's lanes_probe.py ran separate engines with separate weight copies
+(rqamd_dbg_rqt_share_params), against one chain of B rows.  Round 2's lanes_probe.py ran separate engines with separate weight copies
 (2.8 GB each: no L2 / MALL sharing) on the round-2 kernels and was slower everywhere; the mid-batch tiles of round 5 leave 64-112
 of the 256 CUs idle per GEMM launch, which a second chain can use.  RQ_BS=64,100,200,500  RQ_LANES=1,2,3,4  RQ_MODEL=huge."""
 import ctypes as C
@@ -24,8 +24,6 @@ ar.sample(part, model_aux=vae, cond=torch.zeros((2, ar.block_size_cond), device=
 torch.cuda.synchronize()
 eng0 = ar._eng()
 lib = _native.lib()
-lib.rqamd_rqt_share_params.restype = C.c_int
-lib.rqamd_rqt_share_params.argtypes = [C.c_void_p, C.c_void_p]
 c = ar.config
 engs = [eng0]
 for i in range(1, LMAX):
@@ -33,7 +31,7 @@ for i in range(1, LMAX):
                           vocab_size=max(ar.vocab_size), input_embed_dim=c.input_embed_dim, vocab_size_cond=ar.vocab_size_cond,
                           block_size_cond=ar.block_size_cond, block_size=list(ar.block_size), gelu_v2=c.body.block.gelu == 'v2', device=dev,
                           vocab_sizes=ar.vocab_size)
-    _native.check(lib.rqamd_rqt_share_params(e._h, eng0._h))
+    _native.check(lib.rqamd_dbg_rqt_share_params(e._h, eng0._h))
     engs.append(e)
 streams = [torch.cuda.Stream(dev) for _ in range(LMAX)]
 cbs = ar._checked_codebooks(vae)

@@ -98,9 +98,12 @@ def test_sample_argument_normalisation(monkeypatch):
             @staticmethod
             def codebook_list():
                 return [torch.zeros((500, 64))] * 4
-    monkeypatch.setattr(ar, '_eng', lambda: FakeEngine())
+    picked = []
+    monkeypatch.setattr(ar, '_eng', lambda amp=False: (picked.append(bool(amp)), FakeEngine())[1])
     z = torch.zeros((2, 4, 4, 4), dtype=torch.long)
     ar.sample(z, Aux)
+    ar.sample(z, Aux, amp=True)
+    assert picked == [False, True]                   # amp=True selects the fp16 engine (round 6)
     assert seen['top_k'] == [500] * 4 and seen['top_p'] == [1.0] * 4 and seen['cond'] is None
     ar.sample(z, Aux, top_k=1000, top_p=0.95, temperature=0.7, start_loc=(1, 2))
     assert seen['top_k'] == [500] * 4 and seen['top_p'] == [0.95] * 4 and seen['t'] == 0.7 and seen['start'] == (1, 2)
