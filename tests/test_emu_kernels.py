@@ -103,7 +103,7 @@ def test_emu_rq_quantize_non_finite_rows(nat):
         assert np.array_equal(codes[keep], good.numpy()[keep])
 
 
-@pytest.mark.parametrize('which', ['golden', 'ragged', 'split'])
+@pytest.mark.parametrize('which', ['ragged', 'split'])
 def test_emu_rq_quantize_codebook_dma_lands_late(nat, golden, monkeypatch, which):
     """Round 6: the quantiser's codebook ring (four 32-KB stages + the tile's norms, filled by LDS-DMA) with RQ_EMU_DMA=late -- every
     DMA lands only when the issuing lane's counted `s_waitcnt vmcnt(N)` retires it, so a fragment (or norm) read that is not behind the
