@@ -23,6 +23,18 @@ def _newer(a, b):
 
 
 def build(force=False, verbose=True):
+    """(serialised by a file lock: several test workers / processes may ask for the library at once)"""
+    import fcntl
+    os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
+    with open(os.path.join(HERE, 'build', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)

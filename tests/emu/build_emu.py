@@ -13,6 +13,17 @@ CXX = os.environ.get('RQ_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')
 
 
 def build(force=False):
+    """(serialised by a file lock: the CPU suite may run its tests in several pytest-xdist workers, each of which comes here)"""
+    import fcntl
+    with open(os.path.join(HERE, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force=False):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip')) + [os.path.join(HERE, 'rq_emu.cpp')]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(HERE, 'rq_emu.h')]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
