@@ -1385,6 +1385,7 @@ struct ConvInArgs {
     const float* w;         // [ky][kx][ci][Cout] fp32 (repacked conv_in weight)
     const float* bias;      // [Cout]
     bf16_t* y;              // NHWC [B][H][W][Cout]
+    float* stats;           // GroupNorm partials of y, [B][tiles][32][2] (sum, sumsq) as the halo convs' epilogues write them, or null
     int B, H, W;
 };
 constexpr int CI_COUT = 128, CI_PATCH = 3 * (HT_H + 2) * HP_W;        // 1020 floats (+ zero slot)
@@ -1436,6 +1437,10 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[ks][j] = as_bf16x8(ld128(sWt + (j * 32 + px) * CI_WROW + (ks * 16 + g * 8) * 2));
     char* stg = sO + wave * CI_STG;
+    // GroupNorm partials of the tile (round 6: the encoder's first ResnetBlock reads them instead of a 0.41-ms statistics pass over the
+    // 2.1-GB output): this lane stores 16-byte chunk (lane & 15) of 32 pixels per row -- channels 8 (lane & 15) .. + 7 = groups
+    // 2 (lane & 15), 2 (lane & 15) + 1 of the 32 four-channel groups -- and sums what it stores (the bf16-rounded values)
+    float gs_[4] = {0.f, 0.f, 0.f, 0.f}, gq_[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int i = 0; i < 2; ++i) {
         const int row = wave * 2 + i;                                  // output row of the tile
@@ -1473,9 +1478,32 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInArgs p) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int c = lane + 64 * k, opx = c >> 4, part = c & 15;
-            st128(p.y + (pix0 + opx) * CI_COUT + part * 8, ld128(stg + opx * (CI_COUT * 2 + 16) + part * 16));
+            const rq_u128 u = ld128(stg + opx * (CI_COUT * 2 + 16) + part * 16);
+            st128(p.y + (pix0 + opx) * CI_COUT + part * 8, u);
+            if (p.stats) rq_stats_piece(u, gs_, gq_);
         }
         rq_syncthreads();
+    }
+    if (p.stats) {                                                      // uniform
+        // channel pairs -> groups of four channels, the 4 lanes that share a chunk, then the 4 wavefronts through LDS (fixed order)
+        float a0 = gs_[0] + gs_[1], q0 = gq_[0] + gq_[1], a1 = gs_[2] + gs_[3], q1 = gq_[2] + gq_[3];
+        a0 += rq_shfl_xor(a0, 16); q0 += rq_shfl_xor(q0, 16); a1 += rq_shfl_xor(a1, 16); q1 += rq_shfl_xor(q1, 16);
+        a0 += rq_shfl_xor(a0, 32); q0 += rq_shfl_xor(q0, 32); a1 += rq_shfl_xor(a1, 32); q1 += rq_shfl_xor(q1, 32);
+        float* sred = (float*)sO;                                      // [4 waves][16 chunks][4] (the staging tiles are free now)
+        if (lane < 16) {
+            float* o = sred + (wave * 16 + lane) * 4;
+            o[0] = a0; o[1] = q0; o[2] = a1; o[3] = q1;
+        }
+        rq_syncthreads();
+        if (tid < 32) {
+            const int chunk = tid >> 1, pair = tid & 1;                // group 2 chunk + pair
+            float a = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += sred[(w * 16 + chunk) * 4 + pair * 2]; q += sred[(w * 16 + chunk) * 4 + pair * 2 + 1]; }
+            float* o = p.stats + (((long)img * (tiles_y * tiles_x) + trem) * 32 + tid) * 2;
+            o[0] = a;
+            o[1] = q;
+        }
     }
 }
 
@@ -1483,9 +1511,9 @@ bool rq_conv_in_mfma_supported(int H, int W, int Cin, int Cout) {
     return Cin == 3 && Cout == CI_COUT && H % HT_H == 0 && W % HT_W == 0;
 }
 
-int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, hipStream_t s) {
+int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, float* stats, int B, int H, int W, hipStream_t s) {
     ConvInArgs a{};
-    a.x = x; a.w = w; a.bias = bias; a.y = y; a.B = B; a.H = H; a.W = W;
+    a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats; a.B = B; a.H = H; a.W = W;
     const size_t smem = 4096 + 128 + (size_t)CI_COUT * CI_WROW + 4 * (size_t)CI_STG;
     static RqDeviceOnce attr_once;      // kernel attributes are per device
     if (attr_once.first()) {
@@ -1691,7 +1719,7 @@ extern "C" int rqamd_dbg_conv_out_bf16(const void* x, const float* w, const floa
 extern "C" int rqamd_dbg_conv_in_bf16(const float* x, const float* w, const float* bias, int B, int H, int W, void* y, void* stream) {
     if (!x || !w || !bias || !y) return rq_fail(RQAMD_ERR_INVALID, "dbg_conv_in: null argument");
     if (!rq_conv_in_mfma_supported(H, W, 3, CI_COUT)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "dbg_conv_in: shape %dx%d", H, W);
-    return rq_launch_conv_in_mfma(x, w, bias, (bf16_t*)y, B, H, W, (hipStream_t)stream);
+    return rq_launch_conv_in_mfma(x, w, bias, (bf16_t*)y, nullptr, B, H, W, (hipStream_t)stream);
 }
 
 #ifdef RQ_CONV_TRACE

@@ -450,7 +450,13 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
         const float* w = (const float*)r.P("encoder.conv_in.weight");
         const float* b = (const float*)r.P("encoder.conv_in.bias");
         if (r.err) return r.err;
-        if (!h->no_halo && rq_conv_in_mfma_supported(res, res, c.in_channels, c.ch)) RQ_TRY(rq_launch_conv_in_mfma(x, w, b, r.X, B, res, res, st));
+        if (!h->no_halo && rq_conv_in_mfma_supported(res, res, c.in_channels, c.ch)) {
+            // (round 6) its epilogue leaves the GroupNorm partials of the first ResnetBlock's input, like the halo convs do
+            const bool st_ok = !h->no_fuse_stats && r.stat_fits(res, res);
+            RQ_TRY(rq_launch_conv_in_mfma(x, w, b, r.X, st_ok ? h->part.as<float>() : nullptr, B, res, res, st));
+            r.stats_of = st_ok ? r.X : nullptr;
+            r.stats_n = st_ok ? rq_conv_halo_stat_tiles(res, res) : 0;
+        }
         else RQ_TRY(rq_launch_conv_in3(x, w, b, r.X, B, res, res, c.in_channels, c.ch, st));
     }
     int block_in = c.ch;

@@ -29,6 +29,7 @@ int rq_launch_conv_out_halo(const bf16_t* x, const float* w, const float* bias, 
                             int Cin, int Cout, hipStream_t s);
 // MFMA Encoder.conv_in (3 -> 128 channels, NCHW fp32 image in, NHWC bf16 out)
 bool rq_conv_in_mfma_supported(int H, int W, int Cin, int Cout);
-int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, hipStream_t s);
+// stats != null: also the GroupNorm partials of y ([B][rq_conv_halo_stat_tiles(H, W)][32][2])
+int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, float* stats, int B, int H, int W, hipStream_t s);
 int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
                         int nchunk_have, hipStream_t s);
