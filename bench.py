@@ -75,8 +75,8 @@ def parse_args(argv=None):
     ap.add_argument('--top-p', type=float, default=0.95)
     ap.add_argument('--sweep', type=str, default='64,100,200,500', help='extra per-GPU batches measured after the timed region ("" = none)')
     ap.add_argument('--formats', type=int, default=1,
-                    help='1 (default): after everything else, time the 1.4B model at 2048 images with the default bf16 engine, the opt-in 8-bit key '
-                         'cache (RQAMD_KV=int8k) and the fp16 build of the engine (sample(amp=True)) -> "kv_cache_formats"; 0: skip (~25 s)')
+                    help='1 (default): after everything else, time the 1.4B model at 2048 images with the default bf16 engine, the opt-in 8-bit key / '
+                         'key + value caches (RQAMD_KV=int8k / int8kv) and the fp16 build of the engine (sample(amp=True)) -> "kv_cache_formats"; 0: skip (~25 s)')
     ap.add_argument('--also', type=str, default='xhuge:64,txt3900m:64',
                     help='model:batch points measured after everything else on rank 0 at N = 1 (default: the two models BASELINE.json quotes on '
                          '8 GPUs, at their per-GPU share of 64 images; "" = none).  Adds ~40 s to a default run: after the headline model is '
@@ -314,6 +314,8 @@ def kv_bytes_per_image(cfg):
     head = H * W * sum(d + 1 for d in range(D)) * cfg['head']['n_layer']
     if os.environ.get('RQAMD_KV', 'bf16') == 'int8k':      # opt-in: body keys as 64 bytes + an fp32 scale per head (68 B per 64 components), values bf16
         return body * (E * 2 + E + (E // 64) * 4) + head * E * 2 * 2
+    if os.environ.get('RQAMD_KV', 'bf16') == 'int8kv':     # opt-in: body keys AND values as bytes + scales
+        return body * 2 * (E + (E // 64) * 4) + head * E * 2 * 2
     return (body + head) * E * 2 * 2
 
 
@@ -910,7 +912,7 @@ def main(argv=None):
         kv_before = os.environ.get('RQAMD_KV')
         try:
             # ('fp16': the fp16 build of the engine, what sample(amp=True) runs on -- same MFMA rate, three more mantissa bits)
-            for fmt in ('bf16', 'int8k', 'fp16'):
+            for fmt in ('bf16', 'int8k', 'int8kv', 'fp16'):
                 os.environ['RQAMD_KV'] = 'bf16' if fmt == 'fp16' else fmt
                 _, ar3, cfg3 = presets.build('huge', device=device, seed=0)
                 if fmt == 'fp16':

@@ -26,7 +26,8 @@ struct RqtLayer {
     bf16_t *wqkv, *wproj, *wfc1, *wfc2;
     float *bqkv, *bproj, *bfc1, *bfc2, *ln1w, *ln1b, *ln2w, *ln2b;
     bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
-    float* ksc;        // body layers with the opt-in 8-bit key cache (RQAMD_KV=int8k): per-key scales, `kc` then holds bytes; else null
+    float* ksc;        // body layers with the opt-in 8-bit key cache (RQAMD_KV=int8k / int8kv): per-key scales, `kc` then holds bytes; else null
+    float* vsc;        // body layers with RQAMD_KV=int8kv: per-value-row scales, `vc` then holds bytes; else null
 };
 
 struct GemmProfile {
@@ -78,7 +79,8 @@ struct rqamd_rqt {
     int* smp_redo;      // [rows] sampler workspace (rows the top-k kernel hands back to the general kernel)
     int max_slabs = 8;
     int cur_gelu_v2 = 0;   // GELU form of the stack being run (cfg.gelu_v2: 0 both erf, 1 both sigmoid, 2 body erf / head sigmoid, 3 body sigmoid / head erf)
-    bool kv_int8k = false;   // RQAMD_KV=int8k when the handle was created: body-stack keys cached as 64 bytes + one fp32 scale (rqt_kernels.hip)
+    bool kv_int8k = false;   // RQAMD_KV=int8k / int8kv when the handle was created: body-stack keys cached as 64 bytes + one fp32 scale (rqt_kernels.hip)
+    bool kv_int8v = false;   // RQAMD_KV=int8kv: the body-stack values likewise (round 6)
 
     // graph cache
     // one captured position per 8-key bucket of the body context (the attention kernel variant is baked in)
@@ -126,8 +128,9 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     {   // opt-in storage format of the body stack's key cache, fixed for the life of the handle (default: bf16, what BASELINE.json asks for)
         const char* kvf = getenv("RQAMD_KV");
         if (kvf && *kvf && strcmp(kvf, "bf16") != 0) {
-            if (strcmp(kvf, "int8k") != 0) { delete h; return rq_fail(RQAMD_ERR_INVALID, "rqt_create: RQAMD_KV=%s (bf16 or int8k)", kvf); }
+            if (strcmp(kvf, "int8k") != 0 && strcmp(kvf, "int8kv") != 0) { delete h; return rq_fail(RQAMD_ERR_INVALID, "rqt_create: RQAMD_KV=%s (bf16, int8k or int8kv)", kvf); }
             h->kv_int8k = true;
+            h->kv_int8v = strcmp(kvf, "int8kv") == 0;
         }
     }
     h->E = c->embed_dim; h->HW = c->H * c->W; h->D = c->D; h->V = c->vocab_size; h->Din = c->input_embed_dim;
@@ -176,6 +179,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
             L.bproj = (float*)take(E * 4); L.bfc2 = (float*)take(E * 4);
             L.ln1w = (float*)take(E * 4); L.ln1b = (float*)take(E * 4); L.ln2w = (float*)take(E * 4); L.ln2b = (float*)take(E * 4);
             L.kc = L.vc = nullptr;
+            L.ksc = L.vsc = nullptr;
         }
     };
     mk(h->body, c->n_layer_body);
@@ -334,8 +338,8 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     // (cap 0, no graphs), never pointing at freed memory; the caller may retry with a smaller batch.
     h->cap = 0;
     h->gvalid = false;
-    for (auto& L : h->body) { L.kc = L.vc = nullptr; L.ksc = nullptr; }
-    for (auto& L : h->head) { L.kc = L.vc = nullptr; L.ksc = nullptr; }
+    for (auto& L : h->body) { L.kc = L.vc = nullptr; L.ksc = L.vsc = nullptr; }
+    for (auto& L : h->head) { L.kc = L.vc = nullptr; L.ksc = L.vsc = nullptr; }
     const size_t E = h->E, V = h->V;
     const size_t brows = (size_t)B;
     const size_t prow = (size_t)prefill_chunk(h, B) * (h->cond_len - 1);
@@ -357,13 +361,15 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     const size_t kvb = al(brows * E * h->Tbody * 2), kvh = al(brows * E * h->D * 2);
     // (8-bit keys: half the bytes for K plus one fp32 scale per (row, head, position))
     const size_t kkb = h->kv_int8k ? al(brows * E * h->Tbody) : kvb, ksb = h->kv_int8k ? al(brows * (E / 64) * h->Tbody * 4) : 0;
-    RQ_TRY(h->kv.reserve((kkb + ksb + kvb) * h->body.size() + 2 * kvh * h->head.size()));
+    const size_t vvb = h->kv_int8v ? kkb : kvb, vsb = h->kv_int8v ? ksb : 0;
+    RQ_TRY(h->kv.reserve((kkb + ksb + vvb + vsb) * h->body.size() + 2 * kvh * h->head.size()));
     char* q = (char*)h->kv.p;
     for (auto& L : h->body) {
-        L.kc = (bf16_t*)q; q += kkb; L.vc = (bf16_t*)q; q += kvb;
+        L.kc = (bf16_t*)q; q += kkb; L.vc = (bf16_t*)q; q += vvb;
         L.ksc = h->kv_int8k ? (float*)q : nullptr; q += ksb;
+        L.vsc = h->kv_int8v ? (float*)q : nullptr; q += vsb;
     }
-    for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; L.ksc = nullptr; }
+    for (auto& L : h->head) { L.kc = (bf16_t*)q; q += kvh; L.vc = (bf16_t*)q; q += kvh; L.ksc = L.vsc = nullptr; }
     h->cap = B;
     return RQAMD_OK;
 }
@@ -441,7 +447,9 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     if (pf) {
         AttnPrefillArgs ap{};
         const long img_stride = (long)h->cfg.n_head * Tcap * 64;
-        ap.qkv = h->qkv; ap.vc = L.vc + pf->img0 * img_stride; ap.y = h->ya;
+        ap.qkv = h->qkv; ap.y = h->ya;
+        ap.vc = L.vsc ? (bf16_t*)((unsigned char*)L.vc + pf->img0 * img_stride) : L.vc + pf->img0 * img_stride;
+        ap.vsc = L.vsc ? L.vsc + (long)pf->img0 * h->cfg.n_head * Tcap : nullptr;
         // (8-bit keys: a key is 64 bytes, i.e. half the bf16 stride, and has one scale)
         ap.kc = L.ksc ? (bf16_t*)((unsigned char*)L.kc + pf->img0 * img_stride) : L.kc + pf->img0 * img_stride;
         ap.ksc = L.ksc ? L.ksc + (long)pf->img0 * h->cfg.n_head * Tcap : nullptr;
@@ -449,7 +457,7 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
         RQ_TRY(rq_launch_attn_prefill(ap, st));
     } else {
         AttnDecodeArgs at{};
-        at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.ksc = L.ksc; at.y = h->ya; at.step = step; at.step_off = step_off;
+        at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.ksc = L.ksc; at.vsc = L.vsc; at.y = h->ya; at.step = step; at.step_off = step_off;
         at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
         GemmProfile& pfl = h->prof;
         if (pfl.on) {
@@ -745,7 +753,7 @@ extern "C" int rqamd_dbg_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src) 
         for (size_t i = 0; i < d.size(); ++i) {
             RqtLayer keep = d[i];
             d[i] = s[i];
-            d[i].kc = keep.kc; d[i].vc = keep.vc; d[i].ksc = keep.ksc;
+            d[i].kc = keep.kc; d[i].vc = keep.vc; d[i].ksc = keep.ksc; d[i].vsc = keep.vsc;
         }
     };
     cp(dst->body, src->body); cp(dst->head, src->head);

@@ -34,6 +34,7 @@ struct AttnDecodeArgs {
     bf16_t* vc;             // V cache [rows][nh][Tcap][64]
     float* ksc;             // null: bf16 keys.  Non-null (opt-in RQAMD_KV=int8k, body stack): `kc` holds [rows][nh][Tcap][64] BYTES,
                             // key component = (byte - 128) * ksc[row][head][position], one absmax / 127 scale per cached key
+    float* vsc;             // null: bf16 values.  Non-null (opt-in RQAMD_KV=int8kv; needs ksc): `vc` holds bytes + these scales, like the keys
     bf16_t* y;              // [rows][E]
     const int* step;        // device-side step counter (or null)
     int step_off;           // t = *step + step_off = number of cached keys before this token
@@ -48,6 +49,7 @@ struct AttnPrefillArgs {
     bf16_t* kc;             // K cache of the FIRST image of this chunk: [n_img][nh][Tcap][64]; positions 0..P-1 are written
     bf16_t* vc;
     float* ksc;             // as AttnDecodeArgs::ksc (of the first image of the chunk), or null
+    float* vsc;             // as AttnDecodeArgs::vsc, or null
     bf16_t* y;              // [n_img * P][E]
     int n_img, P, nh, E, Tcap;
 };

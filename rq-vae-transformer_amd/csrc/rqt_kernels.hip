@@ -262,8 +262,12 @@ static __device__ __forceinline__ float group8_sum(float v) {
 // P = (row, head) pairs per wavefront (heads h0 .. h0+P-1 of one row), processed stage by stage so that the loads of
 // all P pairs are in flight together: at short contexts a wavefront's lifetime is one memory round trip, and with
 // 98 304 pairs per launch the launch time was 12 rounds of 8192 resident wavefronts x that latency (45 us at t = 0).
-template <int NJ, bool DYN, int P, bool KQ = false>
+// VQ (round 6, opt-in RQAMD_KV=int8kv; implies KQ): the cached VALUES are bytes + one scale per (token, head) as well -- out = sum_j p_j
+// scale_j (byte_j - 128) is accumulated as sum_j w_j byte_j - 128 sum_j w_j with w_j = p_j scale_j; this token's own value is used as
+// it comes out of the qkv GEMM (bf16) and quantised only on its way into the cache.
+template <int NJ, bool DYN, int P, bool KQ = false, bool VQ = false>
 static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lane, int b, int h0, int t) {
+    static_assert(!VQ || KQ, "8-bit values come with 8-bit keys");
     const int E = p.E, Tcap = p.Tcap;
     const int cc = lane & 7, g = lane >> 3;
     const int nblk = (t >> 3) + 1;
@@ -275,6 +279,8 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
     bf16_t* vc[P];
     unsigned char* kc8[P];                              // KQ: the same cache as bytes, and its scales
     float* ksc[P];
+    unsigned char* vc8[P];                              // VQ: likewise for the values
+    float* vsc[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const long pair = (long)b * p.nh + h0 + i;
@@ -283,19 +289,23 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
         vc[i] = p.vc + pair * Tcap * 64;                // measured +10 % at long contexts and no gain at short ones
         kc8[i] = (unsigned char*)p.kc + pair * Tcap * 64;
         ksc[i] = KQ ? p.ksc + pair * Tcap : nullptr;
+        vc8[i] = (unsigned char*)p.vc + pair * Tcap * 64;
+        vsc[i] = VQ ? p.vsc + pair * Tcap : nullptr;
     }
 
     // every global load is issued before the first use (q, this token's k|v, all K and V blocks); rows j >= t
     // read this token's k / v straight from qkv (the cache row is written by this launch), clamped, unmasked
-    rq_u128 qv[P], kv_new[P], kr[P][KQ ? 1 : NJ], vr[P][NJ];
+    rq_u128 qv[P], kv_new[P], kr[P][KQ ? 1 : NJ], vr[P][VQ ? 1 : NJ];
     rq_u128 kn_all[P];                                  // KQ: this token's key chunk in EVERY group (the self score)
-    rq_u64w kr8[P][KQ ? NJ : 1];
-    float ksv[P][KQ ? NJ : 1];
+    rq_u128 vn_all[P];                                  // VQ: this token's value chunk in every group (its own row of the weighted sum)
+    rq_u64w kr8[P][KQ ? NJ : 1], vr8[P][VQ ? NJ : 1];
+    float ksv[P][KQ ? NJ : 1], vsv[P][VQ ? NJ : 1];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         qv[i] = ld128(qrow[i] + cc * 8);
         kv_new[i] = ld128(qrow[i] + (lane < 8 ? E : 2 * E) + cc * 8);
         if (KQ) kn_all[i] = ld128(qrow[i] + E + cc * 8);
+        if (VQ) vn_all[i] = ld128(qrow[i] + 2 * E + cc * 8);
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) {
@@ -320,7 +330,12 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             if (DYN && jj >= nblk) continue;
             const int j = jj * 8 + g;
             const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
-            vr[i][jj] = ld128((j >= t) ? (qrow[i] + 2 * E + cc * 8) : (vc[i] + off));
+            if constexpr (VQ) {
+                vr8[i][jj] = ld64(vc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
+                vsv[i][jj] = vsc[i][j < t ? j : tprev];
+            } else {
+                vr[i][jj] = ld128((j >= t) ? (qrow[i] + 2 * E + cc * 8) : (vc[i] + off));
+            }
         }
     }
 #pragma unroll
@@ -331,7 +346,10 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             const rq_u64w kb = quant_key_chunk(kv_new[i], s_app);              // (lanes >= 8 quantise their value chunk: unused)
             if (lane < 8) st64(kc8[i] + (long)t * 64 + cc * 8, kb);
             if (lane == 0) ksc[i][t] = s_app;
-            if (lane >= 8 && lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+            if constexpr (VQ) {                                                  // (lanes 8 .. 15 just quantised the value chunk they hold)
+                if (lane >= 8 && lane < 16) st64(vc8[i] + (long)t * 64 + cc * 8, kb);
+                if (lane == 8) vsc[i][t] = s_app;
+            } else if (lane >= 8 && lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
         } else {
             if (lane < 8) st128(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
             else if (lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
@@ -403,14 +421,35 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        float wsum = 0.f;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
             if (DYN && jj >= nblk) continue;
             const float pj = sc[i][jj] * inv[i];                    // 0 for j > t
-            float vf[8];
-            unpack8(vr[i][jj], vf);
+            if constexpr (VQ) {
+                const int j = jj * 8 + g;
+                const float w = j < t ? pj * vsv[i][jj] : 0.f;      // cached rows: weight x scale on the bytes
+                const rq_u64w vb = vr8[i][jj];
+                acc[0] = fmaf(w, rq_ubyte_f32<0>(vb.x), acc[0]); acc[1] = fmaf(w, rq_ubyte_f32<1>(vb.x), acc[1]);
+                acc[2] = fmaf(w, rq_ubyte_f32<2>(vb.x), acc[2]); acc[3] = fmaf(w, rq_ubyte_f32<3>(vb.x), acc[3]);
+                acc[4] = fmaf(w, rq_ubyte_f32<0>(vb.y), acc[4]); acc[5] = fmaf(w, rq_ubyte_f32<1>(vb.y), acc[5]);
+                acc[6] = fmaf(w, rq_ubyte_f32<2>(vb.y), acc[6]); acc[7] = fmaf(w, rq_ubyte_f32<3>(vb.y), acc[7]);
+                wsum += w;
+                const float ps = j < t ? 0.f : pj;                  // this token's own row (j == t; 0 beyond it), bf16
+                float vf[8];
+                unpack8(vn_all[i], vf);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(ps, vf[e], acc[e]);
+            } else {
+                float vf[8];
+                unpack8(vr[i][jj], vf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+            }
+        }
+        if constexpr (VQ) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(-128.0f, wsum, acc[e]);      // the bytes' zero point
         }
         // Reduce-scatter over the 8 key groups so that every lane ends with ONE of the 64 outputs (6 cross-row
         // shuffles instead of 24: the ds_bpermute count, 2.4 M per launch, was the LDS pipe's whole budget):
@@ -437,7 +476,7 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
 // One kernel per register-block count: the launch picks the smallest NJ that covers the host-known bound on t
 // (engine_rqt.hip keeps one captured graph per NJ), so short contexts and the depth transformer (t < 8) run
 // with few VGPRs and 8 wavefronts per SIMD instead of inheriting the 64-key variant's register budget.
-template <int NJ, bool DYN, int P, bool KQ = false>
+template <int NJ, bool DYN, int P, bool KQ = false, bool VQ = false>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = rq_uniform((int)(threadIdx.x >> 6));
@@ -445,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
     if (h0 >= p.nh) return;                                        // whole wave exits together (nh % P == 0)
     const int t = (p.step ? *p.step : 0) + p.step_off;
     if ((t >> 3) >= NJ) rq_trap();                                 // host bound violated: never drop keys silently
-    attn_run<NJ, DYN, P, KQ>(p, lane, (int)blockIdx.y, h0, t);
+    attn_run<NJ, DYN, P, KQ, VQ>(p, lane, (int)blockIdx.y, h0, t);
 }
 
 // Contexts of at most 8 keys (t <= 7: every step of the depth transformer and the first 8 spatial positions -- 44 % of all
@@ -454,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnDecodeArgs p) {
 // its launch time at t = 0 was the texture-address path's instruction rate (7+ wavefront loads / stores per pair), not
 // bytes.  Here a wavefront instruction moves 1 KB of useful data for 8 pairs, the softmax over <= 8 keys stays inside
 // the lanes of a group (three DPP steps per dot product), and nothing crosses groups.
-template <int T, bool KQ = false>      // number of cached keys (t), 0..7; KQ: 8-bit key cache (see quant_key_chunk)
+template <int T, bool KQ = false, bool VQ = false>      // number of cached keys (t), 0..7; KQ / VQ: 8-bit key / value cache (see quant_key_chunk)
 static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, long pair, bool valid, int cc) {
     const int E = p.E, Tcap = p.Tcap;
     const int b = (int)(pair / p.nh), h = (int)(pair - (long)b * p.nh);
@@ -463,24 +502,35 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
     bf16_t* vc = p.vc + pair * Tcap * 64 + cc * 8;
     unsigned char* kc8 = (unsigned char*)p.kc + pair * Tcap * 64 + cc * 8;
     float* ksc = KQ ? p.ksc + pair * Tcap : nullptr;
+    unsigned char* vc8 = (unsigned char*)p.vc + pair * Tcap * 64 + cc * 8;
+    float* vsc = VQ ? p.vsc + pair * Tcap : nullptr;
     const rq_u128 qv = ld128(qrow), kn = ld128(qrow + E), vn = ld128(qrow + 2 * E);
-    rq_u128 kr[(!KQ && T > 0) ? T : 1], vr[T > 0 ? T : 1];
-    rq_u64w kr8[(KQ && T > 0) ? T : 1];
-    float ksv[(KQ && T > 0) ? T : 1];
+    rq_u128 kr[(!KQ && T > 0) ? T : 1], vr[(!VQ && T > 0) ? T : 1];
+    rq_u64w kr8[(KQ && T > 0) ? T : 1], vr8[(VQ && T > 0) ? T : 1];
+    float ksv[(KQ && T > 0) ? T : 1], vsv[(VQ && T > 0) ? T : 1];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         if constexpr (KQ) { kr8[j] = ld64(kc8 + j * 64); ksv[j] = ksc[j]; }
         else kr[j] = ld128(kc + j * 64);
     }
 #pragma unroll
-    for (int j = 0; j < T; ++j) vr[j] = ld128(vc + j * 64);
+    for (int j = 0; j < T; ++j) {
+        if constexpr (VQ) { vr8[j] = ld64(vc8 + j * 64); vsv[j] = vsc[j]; }
+        else vr[j] = ld128(vc + j * 64);
+    }
     if constexpr (KQ) {                            // append: key as bytes + scale (every lane takes part in the group reduction)
         float s_app;
         const rq_u64w kb = quant_key_chunk(kn, s_app);
+        float s_appv = 0.f;
+        rq_u64w vb = kb;
+        if constexpr (VQ) vb = quant_key_chunk(vn, s_appv);
         if (valid) {
             st64(kc8 + T * 64, kb);
             if (cc == 0) ksc[T] = s_app;
-            st128(vc + T * 64, vn);
+            if constexpr (VQ) {
+                st64(vc8 + T * 64, vb);
+                if (cc == 0) vsc[T] = s_appv;
+            } else st128(vc + T * 64, vn);
         }
     } else if (valid) {                            // append this token's k / v
         st128(kc + T * 64, kn);
@@ -523,13 +573,28 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    float wsum = 0.f;
 #pragma unroll
     for (int j = 0; j <= T; ++j) {
-        float vf[8];
-        unpack8(j < T ? vr[j < T ? j : 0] : vn, vf);
         const float pj = sc[j] * inv;
+        if (VQ && j < T) {
+            const float w = pj * vsv[j < T ? j : 0];
+            const rq_u64w vb = vr8[j < T ? j : 0];
+            acc[0] = fmaf(w, rq_ubyte_f32<0>(vb.x), acc[0]); acc[1] = fmaf(w, rq_ubyte_f32<1>(vb.x), acc[1]);
+            acc[2] = fmaf(w, rq_ubyte_f32<2>(vb.x), acc[2]); acc[3] = fmaf(w, rq_ubyte_f32<3>(vb.x), acc[3]);
+            acc[4] = fmaf(w, rq_ubyte_f32<0>(vb.y), acc[4]); acc[5] = fmaf(w, rq_ubyte_f32<1>(vb.y), acc[5]);
+            acc[6] = fmaf(w, rq_ubyte_f32<2>(vb.y), acc[6]); acc[7] = fmaf(w, rq_ubyte_f32<3>(vb.y), acc[7]);
+            wsum += w;
+        } else {
+            float vf[8];
+            unpack8((!VQ && j < T) ? vr[(!VQ && j < T) ? j : 0] : vn, vf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vf[e], acc[e]);
+        }
+    }
+    if constexpr (VQ) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(-128.0f, wsum, acc[e]);
     }
     if (valid) {
         rq_u128 o;
@@ -539,7 +604,7 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
     }
 }
 
-template <bool KQ>
+template <bool KQ, bool VQ = false>
 __global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long total = (long)p.rows * p.nh;
@@ -548,14 +613,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(AttnDecodeArgs p) {
     if (!valid) pair = total - 1;                  // clamped loads, masked stores
     const int t = (p.step ? *p.step : 0) + p.step_off;
     switch (t) {
-        case 0: attn_small_run<0, KQ>(p, pair, valid, lane & 7); break;
-        case 1: attn_small_run<1, KQ>(p, pair, valid, lane & 7); break;
-        case 2: attn_small_run<2, KQ>(p, pair, valid, lane & 7); break;
-        case 3: attn_small_run<3, KQ>(p, pair, valid, lane & 7); break;
-        case 4: attn_small_run<4, KQ>(p, pair, valid, lane & 7); break;
-        case 5: attn_small_run<5, KQ>(p, pair, valid, lane & 7); break;
-        case 6: attn_small_run<6, KQ>(p, pair, valid, lane & 7); break;
-        case 7: attn_small_run<7, KQ>(p, pair, valid, lane & 7); break;
+        case 0: attn_small_run<0, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 1: attn_small_run<1, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 2: attn_small_run<2, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 3: attn_small_run<3, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 4: attn_small_run<4, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 5: attn_small_run<5, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 6: attn_small_run<6, KQ, VQ>(p, pair, valid, lane & 7); break;
+        case 7: attn_small_run<7, KQ, VQ>(p, pair, valid, lane & 7); break;
         default: rq_trap();                        // host bound violated
     }
 }
@@ -567,18 +632,21 @@ static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t
     // the long-context forms with two pairs were never launched but were compiled, with 104 spilled registers at 32 blocks
     if constexpr (!DYN && NJ <= 4) {
         if (pairs_per_wave == 2) {
-            if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2, true>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+            if (a.vsc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2, true, true>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+            else if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2, true>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
             else RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 2>), dim3((unsigned)((a.nh / 2 + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
             return;
         }
     }
-    if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1, true>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    if (a.vsc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1, true, true>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
+    else if (a.ksc) RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1, true>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
     else RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
 }
 
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
     if (a.rows > 65535) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: %d rows > 65535", a.rows);
+    if (a.vsc && !a.ksc) return rq_fail(RQAMD_ERR_INVALID, "attention: 8-bit values come with 8-bit keys");
     const int nj_cap = (a.Tcap + 7) / 8;
     int nj = a.t_max >= 0 ? (a.t_max >> 3) + 1 : nj_cap;
     if (nj > nj_cap) nj = nj_cap;
@@ -587,7 +655,8 @@ int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
     static const bool no_small = getenv("RQAMD_NO_ATTN_SMALL") != nullptr;      // A/B switch
     if (nj == 1 && !no_small) {                   // at most 8 keys: eight pairs per wavefront
         const long pairs = (long)a.rows * a.nh;
-        if (a.ksc) RQ_LAUNCH(attn_small_kernel<true>, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
+        if (a.vsc) RQ_LAUNCH((attn_small_kernel<true, true>), dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
+        else if (a.ksc) RQ_LAUNCH(attn_small_kernel<true>, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
         else RQ_LAUNCH(attn_small_kernel<false>, dim3((unsigned)((pairs + 31) / 32)), dim3(256), 0, s, a);
         return rq_check_launch("attn_small_kernel");
     }
@@ -629,6 +698,8 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(AttnPrefillArgs p) {
     bf16_t* vc = p.vc + (long)pair * p.Tcap * 64;
     unsigned char* kc8 = (unsigned char*)p.kc + (long)pair * p.Tcap * 64;
     float* ksc = p.ksc ? p.ksc + (long)pair * p.Tcap : nullptr;
+    unsigned char* vc8 = (unsigned char*)p.vc + (long)pair * p.Tcap * 64;
+    float* vsc = p.vsc ? p.vsc + (long)pair * p.Tcap : nullptr;
     for (int i0 = 0; i0 < P * 8; i0 += 64) {          // (whole wavefront per pass: the 8-bit append reduces over the 8 lanes of a key)
         const int idx = i0 + lane;
         const bool in = idx < P * 8;                  // whole 8-lane groups: P * 8 is a multiple of 8
@@ -644,10 +715,19 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(AttnPrefillArgs p) {
         } else if (in) {
             st128(kc + j * 64 + c * 8, kv);
         }
+        if (vsc) {                                    // uniform: opt-in 8-bit value cache (likewise: the prefix attention runs on the bf16 values)
+            float s_app;
+            const rq_u64w vb = quant_key_chunk(vv, s_app);
+            if (in) {
+                st64(vc8 + j * 64 + c * 8, vb);
+                if (c == 0) vsc[j] = s_app;
+            }
+        } else if (in) {
+            st128(vc + j * 64 + c * 8, vv);
+        }
         if (in) {
             st128(sK + j * 64 + c * 8, kv);
             st128(sV + j * 64 + c * 8, vv);
-            st128(vc + j * 64 + c * 8, vv);
         }
     }
     rq_syncthreads();

@@ -351,8 +351,10 @@ def test_emu_rqt_long_prefix(nat):
     assert e1 < 0.06 and e2 < 0.06
 
 
-def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
-    """Opt-in 8-bit key cache of the body stack (RQAMD_KV=int8k, read when an engine is created): cached keys as
+@pytest.mark.parametrize('fmt', ['int8k', 'int8kv'])
+def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch, fmt):
+    """(fmt = int8kv, round 6: the VALUES of the body stack cached the same way as well -- bytes + a scale per (token, head), this token's own
+    value bf16.)  Opt-in 8-bit key cache of the body stack (RQAMD_KV=int8k, read when an engine is created): cached keys as
     64 bytes + one fp32 absmax / 127 scale per (token, head), this token's own key and all values bf16 as before.  Through every
     attention kernel that has the variant -- <= 8 keys (attn_small), register blocks, the DYN long-context form behind a 69-token
     prefix, the quantising prefill -- against the
@@ -365,11 +367,12 @@ def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch):
     params = oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']))
     codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
     base = _rqt_engine(nat, cfg, params).logits(codes, cond, [T(cb)] * 4).numpy()
-    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    monkeypatch.setenv('RQAMD_KV', fmt)
     eng = _rqt_engine(nat, cfg, params)
     logits = eng.logits(codes, cond, [T(cb)] * 4).numpy()
     err = np.abs(logits - g['logits'])
-    print('emu rqt tiny logits, 8-bit key cache: max err %.4f mean %.5f vs the reference; max %.4f mean %.5f vs the bf16 cache'
+    print(f'emu rqt tiny logits, {fmt} cache:'
+          ' max err %.4f mean %.5f vs the reference; max %.4f mean %.5f vs the bf16 cache'
           % (err.max(), err.mean(), np.abs(logits - base).max(), np.abs(logits - base).mean()))
     assert err.max() < 0.06 and err.mean() < 0.01
     assert 0 < np.abs(logits - base).max() < 0.02            # the cache format is really in use, and costs little

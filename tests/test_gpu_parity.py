@@ -360,18 +360,21 @@ def test_rqt_cached_forward_steps(nat, golden):
         ar.cached_forward(codes[:, :1], vae, cond=cond, sample_loc=(0, 0, 2))
 
 
-def test_rqt_int8k_key_cache_tiny(nat, golden, monkeypatch):
-    """Opt-in 8-bit key cache (RQAMD_KV=int8k) on the tiny fixtures: logits vs the reference with the bf16 bound and close to the
+@pytest.mark.parametrize('fmt', ['int8k', 'int8kv'])
+def test_rqt_int8k_key_cache_tiny(nat, golden, monkeypatch, fmt):
+    """(fmt = int8kv, round 6: the body stack's values cached as bytes + a scale per (token, head) as well.)
+    Opt-in 8-bit key cache (RQAMD_KV=int8k) on the tiny fixtures: logits vs the reference with the bf16 bound and close to the
     bf16-cache engine, the text-conditioned shape (quantising prefill), sample(): hipGraph == eager, cached == uncached."""
     g = golden('rqt_tiny.npz')
     vae, _, ar0, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
     codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
     base = N(ar0(codes, vae, cond=cond))
-    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    monkeypatch.setenv('RQAMD_KV', fmt)
     _, _, ar, _ = _models(C.VAE_TINY, C.RQT_TINY, int(g['vae_seed']), int(g['seed']))
     logits = N(ar(codes, vae, cond=cond))
     err = np.abs(logits - g['logits'])
-    print('rqt tiny logits, 8-bit key cache: max err %.4f mean %.5f vs the reference; max %.4f vs the bf16 cache'
+    print(f'rqt tiny logits, {fmt} cache:'
+          ' max err %.4f mean %.5f vs the reference; max %.4f vs the bf16 cache'
           % (err.max(), err.mean(), np.abs(logits - base).max()))
     assert err.max() < 0.03 and err.mean() < 0.005
     assert 0 < np.abs(logits - base).max() < 0.02

@@ -224,13 +224,16 @@ def test_rqt_in1400m_amp_fp16_engine(golden):
     torch.cuda.empty_cache()
 
 
-def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch):
-    """Opt-in 8-bit key cache (RQAMD_KV=int8k) on the full 1.4B model against the REFERENCE's logits with the bound of
+@pytest.mark.parametrize('fmt', ['int8k', 'int8kv'])
+def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch, fmt):
+    """(fmt = int8kv, round 6: keys AND values of the body stack in 8 bits + scales -- costed in round 4 at 1.4 x the bf16 engine's total
+    error, profiles/r04_kv_cache_precision_costing.txt; same bound.)
+    Opt-in 8-bit key cache (RQAMD_KV=int8k) on the full 1.4B model against the REFERENCE's logits with the bound of
     the bf16 cache: 2 rows (small-batch kernels, <= 8-key and register-block attention forms) and 2050 rows through the kernels of the
     bench batch (two heads per wavefront at short contexts).  Costed in round 4 on the reference model itself: 0.0053 max / 0.00063 mean
     added by 8-bit keys alone, what bf16 storage adds (profiles/r04_kv_cache_precision_costing.txt)."""
     from rqvae import _native
-    monkeypatch.setenv('RQAMD_KV', 'int8k')
+    monkeypatch.setenv('RQAMD_KV', fmt)
     g = golden('rqt_in1400m.npz')
     cfg = C.RQT_IN_1400M
     ar = _load(cfg, int(g['seed']))
@@ -242,7 +245,7 @@ def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch):
     out = ar(codes2, aux, cond=cond2)
     got = torch.stack([out[:, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
     err = np.abs(got - ref)
-    print(f'rqt in1400m, 8-bit key cache: logits max err {err.max():.4f} mean {err.mean():.5f}')
+    print(f'rqt in1400m, {fmt} cache: logits max err {err.max():.4f} mean {err.mean():.5f}')
     assert err.max() < MAX_ERR and err.mean() < MEAN_ERR
     reps = 1025
     codes = G(np.tile(g['codes'], (reps, 1, 1, 1)), torch.long)
@@ -257,7 +260,7 @@ def test_rqt_in1400m_int8k_key_cache(golden, monkeypatch):
         gb = torch.stack([out[r0:r0 + 2, int(h), int(w)] for h, w in g['pos']], 1).cpu().numpy()
         worst = max(worst, float(np.abs(gb - ref).max()))
         assert np.abs(gb - ref).mean() < MEAN_ERR
-    print(f'rqt in1400m, 8-bit key cache, through the large-batch kernels (2050 rows): logits max err {worst:.4f}')
+    print(f'rqt in1400m, {fmt} cache, through the large-batch kernels (2050 rows): logits max err {worst:.4f}')
     assert worst < MAX_ERR
     # sampling on it: graph == eager, codes in range
     part = torch.zeros_like(codes2)
