@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RQAMD_ABI_VERSION 6
+#define RQAMD_ABI_VERSION 7
 
 typedef enum {
     RQAMD_OK = 0,
@@ -131,6 +131,10 @@ typedef struct {
 
 int rqamd_vae_create(const rqamd_vae_config* cfg, rqamd_vae** out);
 int rqamd_vae_destroy(rqamd_vae* h);
+/* options of a handle that the config struct does not carry (ABI v7).  "resamp_with_conv" = 0 | 1 <- ddconfig.resamp_with_conv (modules.py:12,103;
+ * layers.py:20-57): 1 (default, every released config) = Upsample / Downsample carry their 3 x 3 conv; 0 = bare nearest-2x
+ * upsample / 2 x 2 average pool, no `*.upsample.conv.*` / `*.downsample.conv.*` parameters. */
+int rqamd_vae_set_option(rqamd_vae* h, const char* name, int value);
 /* copies + repacks (fp32 -> bf16, OIHW -> O,kh,kw,I) on `stream`; the source may be freed after
  * the stream reaches this point. */
 int rqamd_vae_set_param(rqamd_vae* h, const char* name, const float* dev_ptr, const int64_t* shape,

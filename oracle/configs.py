@@ -25,6 +25,8 @@ VAE_FFHQ = vae(2048, (16,))
 # 16x16 image -> 8x8x4 codes; exercises conv s1/s2, upsample, nin_shortcut, attention, GN
 VAE_TINY = vae(n_embed=500, attn_res=(8,), ch=64, ch_mult=(1, 2), resolution=16, z_channels=64,
                embed_dim=64, num_res_blocks=1)
+# the same with ddconfig.resamp_with_conv = False (layers.py:20-57: bare nearest upsample / 2 x 2 average pool; no released config) -- round 6
+VAE_TINY_NORESAMP = (copy.deepcopy(VAE_TINY[0]), dict(copy.deepcopy(VAE_TINY[1]), resamp_with_conv=False))
 
 
 def rqt(embed_dim, n_head, n_body, n_headl, vocab, vocab_cond=1000, block_cond=1,

@@ -117,7 +117,11 @@ class RQVAEOracle:
                 if f'encoder.down.{i_level}.attn.{i_block}.norm.weight' in self.p:
                     h = self._attn(f'encoder.down.{i_level}.attn.{i_block}', h)
             if i_level != nres - 1:
-                h = self._conv(f'encoder.down.{i_level}.downsample.conv', h, stride=2, pad=(0, 1, 0, 1))
+                if dd.get('resamp_with_conv', True):
+                    h = self._conv(f'encoder.down.{i_level}.downsample.conv', h, stride=2, pad=(0, 1, 0, 1))
+                else:                                                # layers.py:55-56: avg_pool2d(kernel_size=2, stride=2)
+                    B, H, W, C_ = h.shape
+                    h = h.reshape(B, H // 2, 2, W // 2, 2, C_).mean(axis=(2, 4), dtype=np.float32)
         h = self._res('encoder.mid.block_1', h)
         h = self._attn('encoder.mid.attn_1', h)
         h = self._res('encoder.mid.block_2', h)
@@ -139,7 +143,8 @@ class RQVAEOracle:
                     h = self._attn(f'decoder.up.{i_level}.attn.{i_block}', h)
             if i_level != 0:
                 h = h.repeat(2, axis=1).repeat(2, axis=2)            # nearest x2 (layers.py:32)
-                h = self._conv(f'decoder.up.{i_level}.upsample.conv', h)
+                if dd.get('resamp_with_conv', True):
+                    h = self._conv(f'decoder.up.{i_level}.upsample.conv', h)
         h = silu(self._norm('decoder.norm_out', h))
         return np.transpose(self._conv('decoder.conv_out', h), (0, 3, 1, 2))
 

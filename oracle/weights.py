@@ -63,7 +63,8 @@ def encoder_param_shapes(dd, prefix='encoder'):
             if curr_res in dd['attn_resolutions']:
                 _attnblock(d, f'{prefix}.down.{i_level}.attn.{i_block}', block_in)
         if i_level != len(ch_mult) - 1:
-            _conv(d, f'{prefix}.down.{i_level}.downsample.conv', block_in, block_in, 3)
+            if dd.get('resamp_with_conv', True):                    # (layers.py:38-48: the conv exists only then)
+                _conv(d, f'{prefix}.down.{i_level}.downsample.conv', block_in, block_in, 3)
             curr_res //= 2
     _resblock(d, prefix + '.mid.block_1', block_in, block_in)
     _attnblock(d, prefix + '.mid.attn_1', block_in)
@@ -93,7 +94,8 @@ def decoder_param_shapes(dd, prefix='decoder'):
             if curr_res in dd['attn_resolutions']:
                 _attnblock(d, f'{prefix}.up.{i_level}.attn.{i_block}', block_in)
         if i_level != 0:
-            _conv(d, f'{prefix}.up.{i_level}.upsample.conv', block_in, block_in, 3)
+            if dd.get('resamp_with_conv', True):
+                _conv(d, f'{prefix}.up.{i_level}.upsample.conv', block_in, block_in, 3)
             curr_res *= 2
     _norm(d, prefix + '.norm_out', block_in)
     _conv(d, prefix + '.conv_out', block_in, dd['out_ch'], 3)

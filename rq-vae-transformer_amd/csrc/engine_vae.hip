@@ -27,6 +27,7 @@ struct rqamd_vae {
     DevBuf ws, part, gnp;      // gnp: [chunk][C][2] GroupNorm (scale, shift) for the fused norm->swish->conv
     DevBuf stage;              // two-phase calls: the <= 16^2 activation of a super-chunk of images between the two phases
     bool no_two_phase = false; // RQAMD_VAE_TWO_PHASE=0 (A/B switch)
+    bool resamp_with_conv = true;      // ddconfig.resamp_with_conv (rqamd_vae_set_option): false = bare nearest upsample / average pool (layers.py:20-57)
     bf16_t* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap_elems = 0;
     int chunk = 0;
@@ -75,6 +76,19 @@ extern "C" int rqamd_vae_create(const rqamd_vae_config* c, rqamd_vae** out) {
     if (const char* e = getenv("RQAMD_VAE_TWO_PHASE")) h->no_two_phase = atoi(e) == 0;
     *out = h;
     return RQAMD_OK;
+}
+
+// options of a handle that are not part of rqamd_vae_config (ABI v7): "resamp_with_conv" = 0 | 1 (ddconfig.resamp_with_conv, modules.py:12,103;
+// default 1, what every released config uses)
+extern "C" int rqamd_vae_set_option(rqamd_vae* h, const char* name, int value) {
+    if (!h || !name) return rq_fail(RQAMD_ERR_INVALID, "vae_set_option: null argument");
+    if (strcmp(name, "resamp_with_conv") == 0) {
+        if (value != 0 && value != 1) return rq_fail(RQAMD_ERR_INVALID, "vae_set_option(resamp_with_conv): %d", value);
+        if (h->resamp_with_conv != (value != 0)) h->gen++;      // captured graphs hold the other layer sequence
+        h->resamp_with_conv = value != 0;
+        return RQAMD_OK;
+    }
+    return rq_fail(RQAMD_ERR_INVALID, "vae_set_option: unknown option %s", name);
 }
 
 extern "C" int rqamd_vae_destroy(rqamd_vae* h) {
@@ -245,6 +259,13 @@ struct VaeRun {
         }
         a.vsplit = sk;
         err = rq_gemm_launch(a, bm, bn, st);
+    }
+    // Upsample / Downsample without their conv (resamp_with_conv = False): X -> Y, then swap
+    void resample(bool up, int Hout, int Wout, int C) {
+        if (err) return;
+        err = up ? rq_launch_upsample2(X, Y, B, Hout, Wout, C, st) : rq_launch_avgpool2(X, Y, B, Hout, Wout, C, st);
+        if ((const void*)stats_of == (const void*)Y) stats_of = nullptr;
+        swap();
     }
     bool stat_fits(int H, int W) const { return (size_t)B * rq_conv_halo_stat_tiles(H, W) * 32 * 2 * 4 <= h->part.bytes; }
     void norm(const std::string& name, const bf16_t* src, bf16_t* dst, int HW, int C, int silu) {
@@ -418,8 +439,10 @@ static int decode_chunk(rqamd_vae* h, const float* z_q, int B, float* out, hipSt
         }
         if (l != 0) {
             res *= 2;   // nearest x2 folded into the conv gather (layers.py:31-35)
-            r.conv(up + ".upsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 1, 1, EPI_BF16, nullptr);
-            r.swap();
+            if (h->resamp_with_conv) {
+                r.conv(up + ".upsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 1, 1, EPI_BF16, nullptr);
+                r.swap();
+            } else r.resample(true, res, res, block_in);
         }
     }
     const float* w = (const float*)r.P("decoder.conv_out.weight");
@@ -475,8 +498,10 @@ static int encode_chunk(rqamd_vae* h, const float* x, int B, float* z_e, hipStre
             if (vae_has_attn(c, res)) r.attn(dn + ".attn." + std::to_string(ib), res, res, block_in);
         }
         if (l != nl - 1) {
-            r.conv(dn + ".downsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 2, 0, EPI_BF16, nullptr);
-            r.swap();
+            if (h->resamp_with_conv) {
+                r.conv(dn + ".downsample.conv", r.X, r.Y, res, res, block_in, block_in, 3, 2, 0, EPI_BF16, nullptr);
+                r.swap();
+            } else r.resample(false, res / 2, res / 2, block_in);
             res /= 2;
         }
         if (phase == 1 && l == l_lo - 1) {

@@ -33,3 +33,7 @@ bool rq_conv_in_mfma_supported(int H, int W, int Cin, int Cout);
 int rq_launch_conv_in_mfma(const float* x, const float* w, const float* bias, bf16_t* y, float* stats, int B, int H, int W, hipStream_t s);
 int rq_launch_gn_params(const bf16_t* x, float* part, const float* gamma, const float* beta, float* gn, int B, int HW, int C,
                         int nchunk_have, hipStream_t s);
+
+// resamp_with_conv = False (layers.py:20-57): bare nearest-2x upsample / 2 x 2 average pool, NHWC bf16; Ho, Wo = OUTPUT size
+int rq_launch_upsample2(const bf16_t* x, bf16_t* y, int B, int Ho, int Wo, int C, hipStream_t s);
+int rq_launch_avgpool2(const bf16_t* x, bf16_t* y, int B, int Ho, int Wo, int C, hipStream_t s);

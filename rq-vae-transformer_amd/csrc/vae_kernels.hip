@@ -486,3 +486,57 @@ int rq_launch_splitk_reduce(const float* slabs, int n_slabs, int M, int N, const
     RQ_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((MN / 4 + 255) / 256)), dim3(256), 0, s, slabs, n_slabs, MN, N, bias, resid, out, out_f32);
     return rq_check_launch("splitk_reduce_kernel");
 }
+
+
+// -------------------------------------------------------------------------------------------------
+// resamp_with_conv = False (rqvae/models/rqvae/layers.py:20-57 of the reference; no released config): Upsample is the bare
+// F.interpolate(scale_factor=2, mode='nearest'), Downsample is F.avg_pool2d(kernel_size=2, stride=2).  NHWC bf16, 16-byte pieces.
+__global__ void upsample2_nearest_kernel(const rq_u128* x, rq_u128* y, long n_out, int Ho, int Wo, int C8) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_out) return;
+    const int c = (int)(gid % C8);
+    long pix = gid / C8;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const long b = pix / Ho;
+    y[gid] = x[((b * (Ho >> 1) + (oy >> 1)) * (Wo >> 1) + (ox >> 1)) * C8 + c];
+}
+__global__ void avgpool2_kernel(const rq_u128* x, rq_u128* y, long n_out, int Ho, int Wo, int C8) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_out) return;
+    const int c = (int)(gid % C8);
+    long pix = gid / C8;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const long b = pix / Ho;
+    const int Wi = Wo * 2;
+    const rq_u128* s0 = x + ((b * (Ho * 2) + 2 * oy) * Wi + 2 * ox) * C8 + c;
+    const rq_u128 p00 = s0[0], p01 = s0[C8], p10 = s0[(long)Wi * C8], p11 = s0[(long)Wi * C8 + C8];
+    const uint32_t a[4] = {p00.x, p00.y, p00.z, p00.w}, bq[4] = {p01.x, p01.y, p01.z, p01.w};
+    const uint32_t cq[4] = {p10.x, p10.y, p10.z, p10.w}, d[4] = {p11.x, p11.y, p11.z, p11.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a0, a1, b0, b1, c0, c1, d0, d1;
+        rq_unpack2(a[e], a0, a1); rq_unpack2(bq[e], b0, b1); rq_unpack2(cq[e], c0, c1); rq_unpack2(d[e], d0, d1);
+        // window order of avg_pool2d: row 0 (left, right), then row 1; fp32 sum, one rounding
+        o[e] = pack_bf16x2((((a0 + b0) + c0) + d0) * 0.25f, (((a1 + b1) + c1) + d1) * 0.25f);
+    }
+    rq_u128 r;
+    r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    y[gid] = r;
+}
+int rq_launch_upsample2(const bf16_t* x, bf16_t* y, int B, int Ho, int Wo, int C, hipStream_t s) {
+    if (C % 8 || (Ho & 1) || (Wo & 1)) return rq_fail(RQAMD_ERR_UNSUPPORTED, "upsample2: C %% 8 and even output sizes needed");
+    const long n = (long)B * Ho * Wo * (C / 8);
+    RQ_LAUNCH(upsample2_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const rq_u128*)x, (rq_u128*)y, n, Ho, Wo, C / 8);
+    return rq_check_launch("upsample2_nearest_kernel");
+}
+int rq_launch_avgpool2(const bf16_t* x, bf16_t* y, int B, int Ho, int Wo, int C, hipStream_t s) {
+    if (C % 8) return rq_fail(RQAMD_ERR_UNSUPPORTED, "avgpool2: C %% 8 needed");
+    const long n = (long)B * Ho * Wo * (C / 8);
+    RQ_LAUNCH(avgpool2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const rq_u128*)x, (rq_u128*)y, n, Ho, Wo, C / 8);
+    return rq_check_launch("avgpool2_kernel");
+}

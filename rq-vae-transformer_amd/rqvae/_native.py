@@ -17,7 +17,7 @@ LIB16_PATH = os.path.join(_PKG, 'librqamd_f16.so')
 
 _lib = None
 _lib16 = None
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class RqamdError(RuntimeError):
@@ -62,6 +62,7 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rqamd_vae_create': (C.c_int, [C.POINTER(VaeConfig), C.POINTER(C.c_void_p)]),
     'rqamd_vae_destroy': (C.c_int, [C.c_void_p]),
+    'rqamd_vae_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'rqamd_vae_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     'rqamd_vae_decode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_vae_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -508,6 +509,8 @@ class VaeEngine(_Engine):
         c.embed_dim, c.double_z = int(embed_dim), int(bool(ddconfig.get('double_z', True)))
         self.cfg = c
         super().__init__(c, device)
+        if not ddconfig.get('resamp_with_conv', True):      # bare nearest upsample / average pool (layers.py:20-57; no released config)
+            check(self._L.rqamd_vae_set_option(self._h, b'resamp_with_conv', 0), self._L)
 
     def decode(self, z_q):
         """z_q (B,h,w,embed_dim) fp32 NHWC -> (B,out_ch,H,W) fp32"""

@@ -17,21 +17,23 @@ class _Holder(nn.Module):
 
 
 class Upsample(_Holder):
+    """nearest x2 (+ a 3 x 3 conv when with_conv; without it the engine runs the bare upsample: rqamd_vae_set_option)"""
+
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError('resamp_with_conv=False')
         self.with_conv = with_conv
-        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        if with_conv:
+            self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
 
 
 class Downsample(_Holder):
+    """3 x 3 / stride-2 conv behind a (0, 1, 0, 1) zero pad when with_conv, else a 2 x 2 average pool"""
+
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError('resamp_with_conv=False')
         self.with_conv = with_conv
-        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        if with_conv:
+            self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
 
 
 class ResnetBlock(_Holder):

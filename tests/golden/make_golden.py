@@ -165,6 +165,19 @@ def gen_vae():
     save('vae_tiny.npz', seed=31, x=x, z_e=z_e.numpy(), codes=codes.numpy().astype(np.int32), decode_code=dec.numpy(),
          forward_out=out.numpy(), loss=np.float32(loss.item()))
 
+    # ddconfig.resamp_with_conv = False (round 6): bare nearest upsample / average pool
+    hps, dd = C.VAE_TINY_NORESAMP
+    m, params = ref_rqvae(hps, dd, seed=36)
+    assert not any('sample.conv' in k for k in params)
+    x = np.clip(np.random.default_rng(37).standard_normal((2, 3, 16, 16), dtype=np.float32), -1, 1)
+    z_e = m.encode(torch.from_numpy(x))
+    out, loss, codes = m(torch.from_numpy(x))
+    dec = m.decode_code(codes)
+    ov = oracle.RQVAEOracle(hps, dd, params)
+    print(f'  vae[tiny, resamp_with_conv=False] oracle vs ref: encode {rel(ov.encode(x), z_e.numpy()):.2e}, '
+          f'decode_code {rel(ov.decode_code(codes.numpy()), dec.numpy()):.2e}')
+    save('vae_tiny_noresamp.npz', seed=36, x=x, z_e=z_e.numpy(), codes=codes.numpy().astype(np.int32), decode_code=dec.numpy())
+
     for tag, (hps, dd) in (('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)):
         m, params = ref_rqvae(hps, dd, seed=33)
         rng = np.random.default_rng(34)

@@ -553,6 +553,25 @@ def test_emu_vae_tiny(nat, golden):
     assert err.max() < 0.05 and err.mean() < 0.008
 
 
+def test_emu_vae_tiny_without_resample_convs(nat, golden):
+    """ddconfig.resamp_with_conv = False (layers.py:20-57 of the reference; round 6): Upsample is the bare nearest x2, Downsample a 2 x 2
+    average pool -- rqamd_vae_set_option(h, "resamp_with_conv", 0), no *.upsample.conv / *.downsample.conv parameters -- against the
+    reference's own outputs for that config."""
+    g = golden('vae_tiny_noresamp.npz')
+    hps, dd = C.VAE_TINY_NORESAMP
+    params = oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['seed']))
+    assert not any('sample.conv' in k for k in params)
+    eng = _vae_engine(nat, hps, dd, params)
+    cb = params['quantizer.codebooks.0.weight'][:-1]
+    dec = eng.decode(T(oracle.rq_embed_code(g['codes'], [cb] * 4))).numpy()
+    err = np.abs(dec - g['decode_code'])
+    print('emu vae tiny (no resample convs) decode: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.05 and err.mean() < 0.008
+    err = np.abs(eng.encode(T(g['x'])).numpy() - g['z_e'])
+    print('emu vae tiny (no resample convs) encode: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.05 and err.mean() < 0.008
+
+
 def test_emu_vae_batch_invariance_across_split_k_forms(nat, golden):
     """An image's pixels / latents do not depend on how many images shared its call: calls of <= 8 images divide the K loop of
     the low-resolution convs over workgroups (fp32 slabs + splitk_reduce), larger calls fold the same chunks inside one

@@ -668,6 +668,21 @@ def test_vae_tiny_golden(nat, golden):
         vae.decode_code(torch.zeros((1, 4, 4, 4), dtype=torch.long, device=DEV))
 
 
+def test_vae_tiny_without_resample_convs(nat, golden):
+    """ddconfig.resamp_with_conv = False (layers.py:20-57; round 6): bare nearest upsample / 2 x 2 average pool instead of the resample
+    convs, through the mirror classes (no *.upsample.conv / *.downsample.conv in the state_dict, strict load) against the reference's
+    outputs for that config."""
+    g = golden('vae_tiny_noresamp.npz')
+    vae, vparams, _, _ = _models(C.VAE_TINY_NORESAMP, None, int(g['seed']), 0)
+    assert not any('sample.conv' in k for k in vae.state_dict())
+    err = np.abs(N(vae.decode_code(G(g['codes'], torch.long))) - g['decode_code'])
+    print('vae tiny (no resample convs) decode_code: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.06 and err.mean() < 0.01
+    err = np.abs(N(vae.encode(G(g['x']))) - g['z_e'])
+    print('vae tiny (no resample convs) encode: max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.05 and err.mean() < 0.008
+
+
 @pytest.mark.parametrize('tag,cfg', [('imagenet', C.VAE_IMAGENET), ('ffhq', C.VAE_FFHQ)])
 def test_vae_full_size_golden(nat, golden, tag, cfg):
     """Released RQ-VAE shapes (104.4 M params, 256x256): decode_code and encode vs the reference fp32

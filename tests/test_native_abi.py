@@ -33,7 +33,7 @@ def test_header_symbols_exported(lib_path):
     from rqvae import _native
     assert declared == set(_native.EXPORTS)
     lib.rqamd_abi_version.restype = ctypes.c_int
-    assert lib.rqamd_abi_version() == _native.ABI_VERSION == 6
+    assert lib.rqamd_abi_version() == _native.ABI_VERSION == 7
     # the fp16 build of the RQ-Transformer engine (sample(amp=True)): the rqamd_rqt_* subset of the same ABI
     assert os.path.exists(_native.LIB16_PATH)
     lib16 = ctypes.CDLL(_native.LIB16_PATH)
