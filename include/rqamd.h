@@ -169,6 +169,11 @@ typedef struct {
 
 int rqamd_rqt_create(const rqamd_rqt_config* cfg, rqamd_rqt** out);
 int rqamd_rqt_destroy(rqamd_rqt* h);
+/* options of a handle that the config struct does not carry (ABI v7).  "head.n_head" <- head.block.n_head where it differs from
+ * body.block.n_head = cfg.n_head (transformers.py:86-87: each AttentionStack has its own block config; attentions.py:44-57: any
+ * embed_dim / n_head).  Head size 64 -- every released config -- takes the tuned attention kernels; any other size <= 256 a plain
+ * wavefront-per-(row, head) kernel (bf16 / fp16 cache only: the RQAMD_KV 8-bit formats need 64). */
+int rqamd_rqt_set_option(rqamd_rqt* h, const char* name, int value);
 int rqamd_rqt_set_param(rqamd_rqt* h, const char* name, const float* dev_ptr, const int64_t* shape,
                         int ndim, void* stream);
 /* rqamd_rqt_sample <- RQTransformer.sample (transformers.py:294-369) with cached=True:

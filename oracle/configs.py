@@ -92,6 +92,15 @@ RQT_TINY_GELUMIX = _variant(RQT_TINY)
 RQT_TINY_GELUMIX['body']['block']['gelu'] = 'v2'
 RQT_TINY_GELUMIX['head']['block']['gelu'] = 'v1'
 
+# head sizes other than 64 and different head counts in the two stacks (attentions.py:44-57: any embed_dim / n_head; transformers.py:86-87:
+# each stack has its own block config): body 4 heads of 32, head stack 1 head of 128 -- round 6
+RQT_TINY_HEADS = _variant(RQT_TINY)
+RQT_TINY_HEADS['body']['block']['n_head'] = 4
+RQT_TINY_HEADS['head']['block']['n_head'] = 1
+# the text-conditioned form of the same (prefix prefill through the plain attention kernel): 8 heads of 16 / 2 heads of 64
+RQT_TINY_TXT_HEADS = _variant(RQT_TINY_TXT)
+RQT_TINY_TXT_HEADS['body']['block']['n_head'] = 8
+
 PARAM_COUNTS_M = {  # BASELINE.md §2 / reference README.md:38-47
     'RQT_FFHQ_355M': 355.4, 'RQT_IN_480M': 480.9, 'RQT_IN_821M': 820.9,
     'RQT_IN_1400M': 1387.5, 'RQT_IN_3800M': 3822.5, 'RQT_CC3M_654M': 654.1,

@@ -28,6 +28,7 @@ struct RqtLayer {
     bf16_t *kc, *vc;   // KV cache (workspace, per batch capacity)
     float* ksc;        // body layers with the opt-in 8-bit key cache (RQAMD_KV=int8k / int8kv): per-key scales, `kc` then holds bytes; else null
     float* vsc;        // body layers with RQAMD_KV=int8kv: per-value-row scales, `vc` then holds bytes; else null
+    int nh;            // attention heads of the layer's stack (body: cfg.n_head; head: the same unless the "head.n_head" option says otherwise)
 };
 
 struct GemmProfile {
@@ -115,8 +116,8 @@ static size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
 
 extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
     if (!c || !out) return rq_fail(RQAMD_ERR_INVALID, "rqt_create: null argument");
-    if (c->embed_dim != c->n_head * 64)
-        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: head_dim must be 64 (embed_dim=%d n_head=%d)", c->embed_dim, c->n_head);
+    if (c->n_head < 1 || c->embed_dim % c->n_head || c->embed_dim / c->n_head > 256)      // 64 is what the tuned kernels take; any other size <= 256: the plain attention kernel
+        return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: embed_dim=%d must be a multiple of n_head=%d with head_dim <= 256", c->embed_dim, c->n_head);
     if (c->embed_dim % 64 || c->input_embed_dim % 64 || c->embed_dim > 4096)
         return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: embed_dim / input_embed_dim must be multiples of 64, embed_dim <= 4096");
     if (c->n_layer_body < 1 || c->n_layer_head < 0)      // head.n_layer = 0: the depth-1 "VQ-GAN" shapes (measure_throughput/__main__.py:166-210)
@@ -129,6 +130,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
         const char* kvf = getenv("RQAMD_KV");
         if (kvf && *kvf && strcmp(kvf, "bf16") != 0) {
             if (strcmp(kvf, "int8k") != 0 && strcmp(kvf, "int8kv") != 0) { delete h; return rq_fail(RQAMD_ERR_INVALID, "rqt_create: RQAMD_KV=%s (bf16, int8k or int8kv)", kvf); }
+            if (c->embed_dim != c->n_head * 64) { delete h; return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_create: RQAMD_KV=%s is written for head_dim 64 (embed_dim=%d n_head=%d)", kvf, c->embed_dim, c->n_head); }
             h->kv_int8k = true;
             h->kv_int8v = strcmp(kvf, "int8kv") == 0;
         }
@@ -180,6 +182,7 @@ extern "C" int rqamd_rqt_create(const rqamd_rqt_config* c, rqamd_rqt** out) {
             L.ln1w = (float*)take(E * 4); L.ln1b = (float*)take(E * 4); L.ln2w = (float*)take(E * 4); L.ln2b = (float*)take(E * 4);
             L.kc = L.vc = nullptr;
             L.ksc = L.vsc = nullptr;
+            L.nh = c->n_head;
         }
     };
     mk(h->body, c->n_layer_body);
@@ -210,6 +213,19 @@ extern "C" int rqamd_rqt_destroy(rqamd_rqt* h) {
     for (auto e : h->prof.ev_attn) (void)hipEventDestroy(e);
     delete h;
     return RQAMD_OK;
+}
+
+// options of a handle that the config struct does not carry (include/rqamd.h)
+extern "C" int rqamd_rqt_set_option(rqamd_rqt* h, const char* name, int value) {
+    if (!h || !name) return rq_fail(RQAMD_ERR_INVALID, "rqt_set_option: null argument");
+    if (strcmp(name, "head.n_head") == 0) {      // head.block.n_head where it differs from body.block.n_head (transformers.py:86-87: the stacks have their own block configs)
+        if (value < 1 || h->E % value || h->E / value > 256)
+            return rq_fail(RQAMD_ERR_UNSUPPORTED, "rqt_set_option: embed_dim=%d must be a multiple of head.n_head=%d with head_dim <= 256", h->E, value);
+        for (auto& L : h->head) L.nh = value;
+        h->gvalid = false;                       // captured graphs hold the old launches
+        return RQAMD_OK;
+    }
+    return rq_fail(RQAMD_ERR_INVALID, "rqt_set_option: unknown option '%s'", name);
 }
 
 static long numel(const int64_t* shape, int ndim) {
@@ -446,19 +462,19 @@ static int run_block(rqamd_rqt* h, RqtLayer& L, float* x_in, float* x, Pending& 
     RQ_TRY(step_gemm(h, h->y, E, L.wqkv, rows, 3 * E, E, EPI_BF16, L.bqkv, nullptr, 0, h->qkv, 3 * E, nullptr, st));
     if (pf) {
         AttnPrefillArgs ap{};
-        const long img_stride = (long)h->cfg.n_head * Tcap * 64;
+        const long img_stride = (long)E * Tcap;
         ap.qkv = h->qkv; ap.y = h->ya;
         ap.vc = L.vsc ? (bf16_t*)((unsigned char*)L.vc + pf->img0 * img_stride) : L.vc + pf->img0 * img_stride;
-        ap.vsc = L.vsc ? L.vsc + (long)pf->img0 * h->cfg.n_head * Tcap : nullptr;
+        ap.vsc = L.vsc ? L.vsc + (long)pf->img0 * L.nh * Tcap : nullptr;
         // (8-bit keys: a key is 64 bytes, i.e. half the bf16 stride, and has one scale)
         ap.kc = L.ksc ? (bf16_t*)((unsigned char*)L.kc + pf->img0 * img_stride) : L.kc + pf->img0 * img_stride;
-        ap.ksc = L.ksc ? L.ksc + (long)pf->img0 * h->cfg.n_head * Tcap : nullptr;
-        ap.n_img = pf->n_img; ap.P = pf->P; ap.nh = h->cfg.n_head; ap.E = E; ap.Tcap = Tcap;
+        ap.ksc = L.ksc ? L.ksc + (long)pf->img0 * L.nh * Tcap : nullptr;
+        ap.n_img = pf->n_img; ap.P = pf->P; ap.nh = L.nh; ap.E = E; ap.Tcap = Tcap;
         RQ_TRY(rq_launch_attn_prefill(ap, st));
     } else {
         AttnDecodeArgs at{};
         at.qkv = h->qkv; at.kc = L.kc; at.vc = L.vc; at.ksc = L.ksc; at.vsc = L.vsc; at.y = h->ya; at.step = step; at.step_off = step_off;
-        at.t_max = t_max; at.rows = rows; at.nh = h->cfg.n_head; at.E = E; at.Tcap = Tcap;
+        at.t_max = t_max; at.rows = rows; at.nh = L.nh; at.E = E; at.Tcap = Tcap;
         GemmProfile& pfl = h->prof;
         if (pfl.on) {
             if (pfl.used_attn + 2 > pfl.ev_attn.size())
@@ -746,7 +762,8 @@ extern "C" int rqamd_rqt_forward(rqamd_rqt* h, const int64_t* codes, const int64
 // over one copy of the weights (L2 / MALL hits for whichever chain reaches a layer second).
 extern "C" int rqamd_dbg_rqt_share_params(rqamd_rqt* dst, const rqamd_rqt* src) {
     if (!dst || !src) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: null argument");
-    if (memcmp(&dst->cfg, &src->cfg, sizeof(dst->cfg)) != 0) return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: configurations differ");
+    if (memcmp(&dst->cfg, &src->cfg, sizeof(dst->cfg)) != 0 || (!dst->head.empty() && dst->head[0].nh != src->head[0].nh))
+        return rq_fail(RQAMD_ERR_INVALID, "rqt_share_params: configurations differ");
     if (src->seen.size() - src->n_ccls_seen < src->n_required || src->tables_dirty)
         return rq_fail(RQAMD_ERR_STATE, "rqt_share_params: the source handle has not run yet (parameters incomplete or tables not derived)");
     auto cp = [](std::vector<RqtLayer>& d, const std::vector<RqtLayer>& s) {

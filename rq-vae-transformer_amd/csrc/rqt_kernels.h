@@ -29,9 +29,9 @@ struct ResidLnArgs {
 };
 
 struct AttnDecodeArgs {
-    const bf16_t* qkv;      // [rows][3E]: q | k | v, head h at columns h*64..h*64+63 of each third
-    bf16_t* kc;             // K cache [rows][nh][Tcap][64]
-    bf16_t* vc;             // V cache [rows][nh][Tcap][64]
+    const bf16_t* qkv;      // [rows][3E]: q | k | v, head h at columns h*hd..h*hd+hd-1 of each third (hd = E / nh; 64 in every released config)
+    bf16_t* kc;             // K cache [rows][nh][Tcap][hd]
+    bf16_t* vc;             // V cache [rows][nh][Tcap][hd]
     float* ksc;             // null: bf16 keys.  Non-null (opt-in RQAMD_KV=int8k, body stack): `kc` holds [rows][nh][Tcap][64] BYTES,
                             // key component = (byte - 128) * ksc[row][head][position], one absmax / 127 scale per cached key
     float* vsc;             // null: bf16 values.  Non-null (opt-in RQAMD_KV=int8kv; needs ksc): `vc` holds bytes + these scales, like the keys

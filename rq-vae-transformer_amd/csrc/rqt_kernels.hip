@@ -643,8 +643,96 @@ static void launch_attn(const AttnDecodeArgs& a, int pairs_per_wave, hipStream_t
     else RQ_LAUNCH((attn_decode_kernel<NJ, DYN, 1>), dim3((unsigned)((a.nh + 3) / 4), (unsigned)a.rows), blk, 0, s, a);
 }
 
+// =================================================================================================
+// Head sizes other than 64 (attentions.py:44-57 takes any embed_dim / n_head, and the two stacks carry their own n_head; every released
+// config has 64, which the kernels above are written for).  One wavefront per (row, head): q in LDS as fp32, lane = key for the scores
+// (fp32 dot products of bf16 operands, scale 1/sqrt(head_dim), attentions.py:87), a wavefront-wide softmax, then lane = output component
+// for the weighted sum of the value rows (coalesced).  The same arithmetic as the 64-wide kernels in a plain form -- an HBM-bound pass
+// over the pair's cached keys and values; no released model takes it.
+static __device__ __forceinline__ void attn_generic_core(const bf16_t* q, const bf16_t* kpast, long kstride, const bf16_t* vpast, long vstride,
+                                                         int n_past, const bf16_t* kself, const bf16_t* vself, bf16_t* y, int hd, int lane,
+                                                         float* sQ, float* sP) {
+    for (int d = lane; d < hd; d += 64) sQ[d] = bf16_to_f32(q[d]);
+    rq_syncthreads();
+    const float NEG_INF = -__int_as_float(0x7f800000);
+    const float scale = 1.0f / sqrtf((float)hd);
+    float mx = NEG_INF;
+    for (int j = lane; j <= n_past; j += 64) {
+        const bf16_t* kr = j < n_past ? kpast + (long)j * kstride : kself;
+        float dot = 0.f;
+        for (int d = 0; d < hd; ++d) dot = fmaf(sQ[d], bf16_to_f32(kr[d]), dot);
+        dot *= scale;
+        sP[j] = dot;
+        mx = fmaxf(mx, dot);
+    }
+    mx = wave_max(mx);
+    float l = 0.f;
+    for (int j = lane; j <= n_past; j += 64) {
+        const float w = rq_fast_exp2((sP[j] - mx) * 1.4426950408889634f);
+        sP[j] = w;
+        l += w;
+    }
+    l = wave_sum(l);
+    rq_syncthreads();
+    const float inv = 1.0f / l;
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < n_past; ++j) acc = fmaf(sP[j], bf16_to_f32(vpast[(long)j * vstride + d]), acc);
+        acc = fmaf(sP[n_past], bf16_to_f32(vself[d]), acc);
+        y[d] = f32_to_bf16(acc * inv);
+    }
+}
+
+// decode step: append this token's key / value at position t, attend over positions 0..t (AttnDecodeArgs as the kernels above; bf16 cache only)
+__global__ __launch_bounds__(64) void attn_generic_decode_kernel(AttnDecodeArgs p) {
+    __shared__ float sQ[256], sP[264];
+    const int lane = threadIdx.x;
+    const long pair = blockIdx.x;
+    const int b = (int)(pair / p.nh), hh = (int)(pair - (long)b * p.nh), hd = p.E / p.nh;
+    const int t = (p.step ? *p.step : 0) + p.step_off;
+    if (t >= p.Tcap) rq_trap();                                    // host bound violated: never write past the cache
+    const bf16_t* q = p.qkv + (long)b * 3 * p.E + hh * hd;
+    const bf16_t *k = q + p.E, *v = q + 2 * p.E;
+    bf16_t* kc = p.kc + pair * p.Tcap * hd;
+    bf16_t* vc = p.vc + pair * p.Tcap * hd;
+    for (int d = lane; d < hd; d += 64) { kc[(long)t * hd + d] = k[d]; vc[(long)t * hd + d] = v[d]; }
+    attn_generic_core(q, kc, hd, vc, hd, t, k, v, p.y + (long)b * p.E + hh * hd, hd, lane, sQ, sP);
+}
+
+// conditioning prefix (AttnPrefillArgs as attn_prefill_kernel): one wavefront per (image, head, token i); keys / values 0..i straight from
+// the qkv rows of the image, token i's own pair appended to the cache at position i
+__global__ __launch_bounds__(64) void attn_generic_prefill_kernel(AttnPrefillArgs p) {
+    __shared__ float sQ[256], sP[264];
+    const int lane = threadIdx.x;
+    const long blk = blockIdx.x;
+    const int i = (int)(blk % p.P);
+    const long pair = blk / p.P;
+    const int img = (int)(pair / p.nh), hh = (int)(pair - (long)img * p.nh), hd = p.E / p.nh;
+    const bf16_t* q0 = p.qkv + (long)img * p.P * 3 * p.E + hh * hd;       // token 0 of the image, this head
+    const bf16_t* q = q0 + (long)i * 3 * p.E;
+    const bf16_t *k = q + p.E, *v = q + 2 * p.E;
+    bf16_t* kc = p.kc + (pair * p.Tcap + i) * hd;
+    bf16_t* vc = p.vc + (pair * p.Tcap + i) * hd;
+    for (int d = lane; d < hd; d += 64) { kc[d] = k[d]; vc[d] = v[d]; }
+    attn_generic_core(q, q0 + p.E, 3L * p.E, q0 + 2 * p.E, 3L * p.E, i, k, v, p.y + ((long)img * p.P + i) * p.E + hh * hd, hd, lane, sQ, sP);
+}
+
+static int attn_generic_check(int E, int nh, int Tcap, const void* ksc) {
+    if (nh < 1 || E % nh) return rq_fail(RQAMD_ERR_INVALID, "attention: embed_dim %d is not a multiple of n_head %d", E, nh);
+    if (E / nh > 256) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim %d > 256", E / nh);
+    if (Tcap > 256) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: context %d > 256", Tcap);
+    if (ksc) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: the 8-bit cache formats (RQAMD_KV) are written for head_dim 64 (E=%d, n_head=%d)", E, nh);
+    return RQAMD_OK;
+}
+
 int rq_launch_attn_decode(const AttnDecodeArgs& a, hipStream_t s) {
-    if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
+    if (a.nh < 1 || a.E != a.nh * 64) {             // any other head size: the plain kernel
+        RQ_TRY(attn_generic_check(a.E, a.nh, a.Tcap, a.ksc));
+        const long pairs = (long)a.rows * a.nh;
+        if (pairs > 0x7fffffffL) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: %ld (row, head) pairs", pairs);
+        RQ_LAUNCH(attn_generic_decode_kernel, dim3((unsigned)pairs), dim3(64), 0, s, a);
+        return rq_check_launch("attn_generic_decode_kernel");
+    }
     if (a.rows > 65535) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: %d rows > 65535", a.rows);
     if (a.vsc && !a.ksc) return rq_fail(RQAMD_ERR_INVALID, "attention: 8-bit values come with 8-bit keys");
     const int nj_cap = (a.Tcap + 7) / 8;
@@ -781,8 +869,15 @@ __global__ __launch_bounds__(64) void attn_prefill_kernel(AttnPrefillArgs p) {
 }
 
 int rq_launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t s) {
-    if (a.E != a.nh * 64) return rq_fail(RQAMD_ERR_UNSUPPORTED, "attention: head_dim must be 64 (E=%d, n_head=%d)", a.E, a.nh);
-    if (a.P < 1 || a.P > a.Tcap || a.P > 255) return rq_fail(RQAMD_ERR_UNSUPPORTED, "prefill attention: %d tokens (cache %d, max 255)", a.P, a.Tcap);
+    if (a.nh >= 1 && a.E != a.nh * 64) {            // any other head size: the plain kernel
+        RQ_TRY(attn_generic_check(a.E, a.nh, a.Tcap, a.ksc));
+        if (a.P < 1 || a.P > a.Tcap) return rq_fail(RQAMD_ERR_UNSUPPORTED, "prefill attention: %d tokens (cache %d)", a.P, a.Tcap);
+        const long blocks = (long)a.n_img * a.nh * a.P;
+        if (blocks > 0x7fffffffL) return rq_fail(RQAMD_ERR_UNSUPPORTED, "prefill attention: %ld (image, head, token) triples", blocks);
+        RQ_LAUNCH(attn_generic_prefill_kernel, dim3((unsigned)blocks), dim3(64), 0, s, a);
+        return rq_check_launch("attn_generic_prefill_kernel");
+    }
+    if (a.nh < 1 || a.P < 1 || a.P > a.Tcap || a.P > 255) return rq_fail(RQAMD_ERR_UNSUPPORTED, "prefill attention: %d tokens (cache %d, max 255)", a.P, a.Tcap);
     const size_t smem = (size_t)a.P * 64 * 2 * 2;
     RQ_LAUNCH(attn_prefill_kernel, dim3((unsigned)(a.n_img * a.nh)), dim3(64), smem, s, a);
     return rq_check_launch("attn_prefill_kernel");

@@ -68,6 +68,7 @@ _SIGS = {
     'rqamd_vae_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'rqamd_rqt_create': (C.c_int, [C.POINTER(RqtConfig), C.POINTER(C.c_void_p)]),
     'rqamd_rqt_destroy': (C.c_int, [C.c_void_p]),
+    'rqamd_rqt_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     'rqamd_rqt_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     'rqamd_rqt_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                    C.c_float, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_int,
@@ -543,7 +544,7 @@ class RqtEngine(_Engine):
 
     def __init__(self, *, embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
                  block_size_cond, block_size, gelu_v2=False, device='cuda', input_emb_vqvae=True, head_emb_vqvae=True,
-                 shared_tok_emb=True, shared_cls_emb=True, cumsum_depth_ctx=True, vocab_sizes=None, half=False):
+                 shared_tok_emb=True, shared_cls_emb=True, cumsum_depth_ctx=True, vocab_sizes=None, half=False, n_head_head=None):
         c = RqtConfig(embed_dim, n_head, n_layer_body, n_layer_head, vocab_size, input_embed_dim, vocab_size_cond,
                       block_size_cond, block_size[0], block_size[1], block_size[2], int(gelu_v2), int(bool(input_emb_vqvae)),
                       int(bool(head_emb_vqvae)), int(bool(shared_tok_emb)), int(bool(shared_cls_emb)), int(bool(cumsum_depth_ctx)))
@@ -552,6 +553,8 @@ class RqtEngine(_Engine):
             c.vocab_sizes[i] = int(v)
         self.cfg = c
         super().__init__(c, device, half=half)
+        if n_head_head is not None and int(n_head_head) != int(n_head):       # head.block.n_head != body.block.n_head (no released config)
+            check(self._L.rqamd_rqt_set_option(self._h, b'head.n_head', int(n_head_head)), self._L)
 
     def _check(self, codes, cond, codebooks):
         c = self.cfg

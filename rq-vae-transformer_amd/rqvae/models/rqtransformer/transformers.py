@@ -125,15 +125,13 @@ class RQTransformer(Stage2Model):
                 c = self.config
                 gb, gh = c.body.block.gelu == 'v2', c.head.block.gelu == 'v2'
                 gelu_code = 1 if (gb and gh) else 3 if gb else 2 if gh else 0      # (the stacks may differ: include/rqamd.h)
-                if c.body.block.n_head != c.head.block.n_head:
-                    raise NotImplementedError('different head counts in body and head')
                 eng = _native.RqtEngine(
                     embed_dim=c.embed_dim, n_head=c.body.block.n_head, n_layer_body=c.body.n_layer, n_layer_head=c.head.n_layer,
                     vocab_size=max(self.vocab_size), input_embed_dim=c.input_embed_dim, vocab_size_cond=self.vocab_size_cond,
                     block_size_cond=self.block_size_cond, block_size=list(self.block_size), gelu_v2=gelu_code,
                     device=self.pos_emb_hw.device, input_emb_vqvae=c.input_emb_vqvae, head_emb_vqvae=c.head_emb_vqvae,
                     shared_tok_emb=c.shared_tok_emb, shared_cls_emb=c.shared_cls_emb, cumsum_depth_ctx=c.cumsum_depth_ctx,
-                    vocab_sizes=self.vocab_size, half=amp)
+                    vocab_sizes=self.vocab_size, half=amp, n_head_head=c.head.block.n_head)
             push_all(self, eng)
             # bias-free layers (attn_bias / mlp_bias = False): the engine's epilogues always add a bias vector -- zeros here
             dev = self.pos_emb_hw.device

@@ -350,15 +350,18 @@ def gen_rqt_variants():
     vae, vparams = ref_rqvae(hps, dd, seed=31)
     cb = vparams['quantizer.codebooks.0.weight'][:-1]
     for tag, cfg in (('tuple', C.RQT_TINY_TUPLE), ('nocumsum', C.RQT_TINY_NOCUMSUM), ('mixed', C.RQT_TINY_MIXED), ('nobias', C.RQT_TINY_NOBIAS),
-                     ('gelumix', C.RQT_TINY_GELUMIX)):
+                     ('gelumix', C.RQT_TINY_GELUMIX), ('heads', C.RQT_TINY_HEADS), ('txtheads', C.RQT_TINY_TXT_HEADS)):
         m, params = ref_rqt(cfg, seed=47)
         H, W, D = cfg['block_size']
         vs = cfg['vocab_size'] if isinstance(cfg['vocab_size'], list) else [cfg['vocab_size']] * D
         rng = np.random.default_rng(48)
         codes = np.stack([rng.integers(0, v, (2, H, W)) for v in vs], -1)
-        cond = rng.integers(0, cfg['vocab_size_cond'], (2, 1))
-        logits = m(torch.from_numpy(codes), vae, cond=torch.from_numpy(cond)).numpy()
+        cond = rng.integers(0, cfg['vocab_size_cond'], (2, max(cfg['block_size_cond'], 1)))
+        logits = m(torch.from_numpy(codes), vae, cond=torch.from_numpy(cond))
         ol = oracle.RQTransformerOracle(cfg, params).forward(codes, [cb] * D, cond)
+        if isinstance(logits, tuple):         # text-conditioned: (seq_logits, cond_logits), transformers.py:185-186
+            logits, ol = logits[0], (ol[0] if isinstance(ol, tuple) else ol)
+        logits = logits.numpy()
         fin = np.isfinite(logits)
         assert np.array_equal(fin, np.isfinite(ol))
         print(f'  rqt[{tag}] oracle forward vs ref: {np.abs(ol[fin] - logits[fin]).max():.2e}; -inf entries {int((~fin).sum())}')

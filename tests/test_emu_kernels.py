@@ -405,22 +405,24 @@ def test_emu_rqt_int8k_key_cache(nat, golden, monkeypatch, fmt):
         _rqt_engine(nat, cfg, params)
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix', 'heads', 'txtheads'])
 def test_emu_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding + BatchLinear + per-depth vocabularies; cumsum_depth_ctx off; learned head
-    embedding) through the mirror classes and the engine, against the reference's forward() logits."""
+    embedding) through the mirror classes and the engine, against the reference's forward() logits.  'heads' / 'txtheads' (round 6):
+    head sizes 32 / 128 / 16 and different head counts in the two stacks -- the plain attention kernels (decode step and prefix)."""
     from rqvae.models.rqtransformer import RQTransformer
     from rqvae.models.rqvae import RQVAE
     g = golden(f'rqt_var_{tag}.npz')
     cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS,
-           'gelumix': C.RQT_TINY_GELUMIX}[tag]
+           'gelumix': C.RQT_TINY_GELUMIX, 'heads': C.RQT_TINY_HEADS, 'txtheads': C.RQT_TINY_TXT_HEADS}[tag]
     hps, dd = C.VAE_TINY
     vae = RQVAE(**hps, ddconfig=dd, checkpointing=False)
     vae.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqvae_param_shapes(hps, dd), int(g['vae_seed'])).items()})
     ar = RQTransformer(cfg).eval()
     ar.load_state_dict({k: T(v) for k, v in oracle.make_params(oracle.rqt_param_shapes(cfg), int(g['seed']), cfg).items()}, strict=True)
     codes, cond = T(g['codes'].astype(np.int64)), T(g['cond'].astype(np.int64))
-    logits = ar(codes, vae if tag != 'tuple' else None, cond=cond).numpy()
+    logits = ar(codes, vae if tag != 'tuple' else None, cond=cond)
+    logits = (logits[0] if isinstance(logits, tuple) else logits).numpy()      # ('txtheads': (seq_logits, cond_logits))
     err = np.abs(logits - g['logits'])
     print(f'emu rqt variant {tag}: max err {err.max():.4f} mean {err.mean():.5f}')
     assert err.max() < 0.06 and err.mean() < 0.01

@@ -608,13 +608,14 @@ def test_rqt_text_conditioned(nat, golden):
     assert torch.equal(a, b) and int(a.max()) < 500
 
 
-@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix'])
+@pytest.mark.parametrize('tag', ['tuple', 'nocumsum', 'mixed', 'nobias', 'gelumix', 'heads', 'txtheads'])
 def test_rqt_flag_variants(nat, golden, tag):
     """primitives.py variants (TupleEmbedding / BatchLinear / LogitMask, cumsum_depth_ctx off, learned head embedding):
-    teacher-forced logits vs the reference's forward(), sampling inside each depth's vocabulary, graph == eager."""
+    teacher-forced logits vs the reference's forward(), sampling inside each depth's vocabulary, graph == eager.  'heads' / 'txtheads'
+    (round 6): head sizes 32 / 128 / 16 and different head counts in the two stacks -- the plain attention kernels."""
     g = golden(f'rqt_var_{tag}.npz')
     cfg = {'tuple': C.RQT_TINY_TUPLE, 'nocumsum': C.RQT_TINY_NOCUMSUM, 'mixed': C.RQT_TINY_MIXED, 'nobias': C.RQT_TINY_NOBIAS,
-           'gelumix': C.RQT_TINY_GELUMIX}[tag]
+           'gelumix': C.RQT_TINY_GELUMIX, 'heads': C.RQT_TINY_HEADS, 'txtheads': C.RQT_TINY_TXT_HEADS}[tag]
     vae, _, _, _ = _models(C.VAE_TINY, None, int(g['vae_seed']), 0)
     from rqvae.models.rqtransformer import RQTransformer
     ar = RQTransformer(cfg)
@@ -622,9 +623,14 @@ def test_rqt_flag_variants(nat, golden, tag):
     ar = ar.to(DEV).eval()
     aux = vae if tag != 'tuple' else None
     codes, cond = G(g['codes'], torch.long), G(g['cond'], torch.long)
-    err = np.abs(N(ar(codes, aux, cond=cond)) - g['logits'])
+    out = ar(codes, aux, cond=cond)
+    err = np.abs(N(out[0] if isinstance(out, tuple) else out) - g['logits'])      # ('txtheads': (seq_logits, cond_logits))
     print(f'rqt variant {tag}: logits max err {err.max():.4f} mean {err.mean():.5f}')
     assert err.max() < 0.06 and err.mean() < 0.01
+    if tag == 'heads':          # the plain attention kernels in the fp16 build of the engine (amp=True)
+        err16 = np.abs(N(ar(codes, aux, cond=cond, amp=True)) - g['logits'])
+        print(f'rqt variant {tag}, fp16 engine: logits max err {err16.max():.4f} mean {err16.mean():.5f}')
+        assert err16.max() < 0.01 and err16.mean() < 0.002
     res = []
     for graph in (True, False):
         ar.use_graph = graph

@@ -51,10 +51,14 @@ def test_status_codes_without_gpu(lib_path):
     assert lib.rqamd_rqt_create(None, None) == -1
     assert b'null' in lib.rqamd_last_error()
     from rqvae._native import RqtConfig
-    cfg = RqtConfig(100, 3, 1, 1, 10, 64, 1, 1, 8, 8, 4, 0)          # head_dim != 64
+    cfg = RqtConfig(100, 3, 1, 1, 10, 64, 1, 1, 8, 8, 4, 0)          # embed_dim not a multiple of n_head (attentions.py:46 asserts)
     h = ctypes.c_void_p()
     assert lib.rqamd_rqt_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
     assert b'head_dim' in lib.rqamd_last_error()
+    cfg = RqtConfig(1024, 2, 1, 1, 10, 64, 1, 1, 8, 8, 4, 0)         # head_dim 512 > 256
+    assert lib.rqamd_rqt_create(ctypes.byref(cfg), ctypes.byref(h)) == -2
+    assert b'head_dim' in lib.rqamd_last_error()
+    assert lib.rqamd_rqt_set_option(None, b'head.n_head', 2) == -1
     assert lib.rqamd_vae_decode(None, None, 1, None, None) == -1
     lib.rqamd_rq_quantize.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
     assert lib.rqamd_rq_quantize(None, None, None, None, 4, 0, 256, None, None, None, 0, None) == 0     # empty input is a no-op
