@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     //    3x3 halo rows), n fastest so an A tile is reused by all its n-tiles at once.
     // The grid is padded to 8 x (largest slice); surplus workgroups exit here, before any barrier.
     const int MT = (p.M + BM - 1) / BM, NT = (p.N + BN - 1) / BN;
-    int mt, nt;
+    int mt, nt, zs = blockIdx.z;
     {
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         if (p.sched == 1) {
@@ -541,6 +541,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
             mt = xcd * mm + slot / NT;
             nt = slot - (slot / NT) * NT;
             if (slot >= mm * NT || mt >= MT) return;
+        } else if (p.sched == 4) {
+            // split-K slab GEMMs with 2, 4 or 8 K slices (round 6): a K SLICE per group of 8 / splitk XCDs, the n-tiles of the slice divided
+            // over the XCDs of the group, m fastest.  With n-ranges per XCD (sched 1) every XCD walks all K slices and pulls ALL of A through
+            // its L2 (fc2 at 500 rows: 8 x 6.1 MB on the fabric for 25 MB of operands); here an XCD reads its slice of A and of W once.
+            // The grid is one-dimensional: the slab index comes from the XCD, not from blockIdx.z.
+            const int xper = 8 / p.splitk;
+            zs = xcd / xper;
+            const int sub = xcd - zs * xper;
+            const int nb = NT / xper, rem = NT - nb * xper;
+            const int nn = nb + (sub < rem ? 1 : 0);
+            const int n_lo = sub * nb + (sub < rem ? sub : rem);
+            if (slot >= nn * MT) return;
+            nt = n_lo + slot / MT;
+            mt = slot - (slot / MT) * MT;
+            p.out = (float*)p.out + (long)zs * p.M * p.ldo;      // (blockIdx.z is 0 in the epilogue's slab offset)
         } else {
             mt = id / NT;
             nt = id - mt * NT;
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(GemmArgs p) {
     const int m0 = mt * BM, n0 = nt * BN;
     const int kt_total = p.K / BK;
     const int per = (kt_total + p.splitk - 1) / p.splitk;
-    const int kt0 = blockIdx.z * per;
+    const int kt0 = zs * per;
     const int kt1 = (kt0 + per < kt_total) ? kt0 + per : kt_total;
 
     const int chunk = tid & 7, lrow = tid >> 3;

@@ -14,8 +14,9 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
     // XCD-aware schedule (see the kernel): pad the grid to 8 x the largest per-XCD slice
     GemmArgs g = a;
     const int MT = (a.M + BM - 1) / BM, NT = (a.N + BN - 1) / BN;
-    int nblocks;
+    int nblocks, zdim = a.splitk;
     static const bool env_sched0 = getenv("RQAMD_GEMM_SCHED0") != nullptr, env_sched1 = getenv("RQAMD_GEMM_SCHED1") != nullptr;   // A/B switches
+    static const bool env_nosched4 = getenv("RQAMD_GEMM_NO_SCHED4") != nullptr;
     if (env_sched0) {
         g.sched = 0; g.sched_gm = 1; nblocks = MT * NT;
     } else if (NT >= 8 && !a.conv && MT >= 8 && 7.0 * ((double)a.M - a.N) * a.K * 2.0 > 100e6 && !env_sched1) {
@@ -25,6 +26,15 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         // and 99 -> 90 us with m-bands (proj, where the saving is 55 MB, measured 5 % slower: threshold 100 MB).
         g.sched = 2; g.sched_gm = 1;
         nblocks = 8 * ((MT + 7) / 8) * NT;
+    } else if (GL && !a.conv && a.epi == EPI_F32_PARTIAL && !a.accum && (a.splitk == 2 || a.splitk == 4 || a.splitk == 8) && MT >= 4 && MT <= 16 &&
+               (a.K / 64) % a.splitk == 0 && !env_sched1 && !env_nosched4) {
+        // split-K slab GEMMs at mid batch: K slices to XCD groups (see the kernel); one-dimensional grid.  Measured (profiles/r06_sched4_ab.txt,
+        // whole step): +0.7 % at 500 images, -0.5 % at 200 (two m-tiles), level at 100 -- taken from four m-tiles; the fabric traffic of fc2 falls
+        // from 3.0 x to the algorithmic bytes either way, which is not what bounds these launches.
+        const int xper = 8 / a.splitk;
+        g.sched = 4; g.sched_gm = 1;
+        nblocks = 8 * ((NT + xper - 1) / xper) * MT;
+        zdim = 1;
     } else if (NT >= 8) {
         const int ktiles = (a.K / 64 + a.splitk - 1) / a.splitk;
         long panel = (long)BM * ktiles * 64 * 2;                   // bytes of one m-tile's A panel for this K split
@@ -37,7 +47,7 @@ static int launch_c(const GemmArgs& a, hipStream_t stream) {
         g.sched = 2; g.sched_gm = 1;
         nblocks = 8 * ((MT + 7) / 8) * NT;
     }
-    dim3 grid(nblocks, 1, a.splitk);
+    dim3 grid(nblocks, 1, zdim);
     RQ_LAUNCH((gemm_bf16_kernel<BM, BN, MODE, TR, WGM, WGN, GL, VS>), grid, dim3(64 * WGM * WGN), smem, stream, g);
     return rq_check_launch("gemm_bf16_kernel");
 }
