@@ -784,6 +784,18 @@ def test_emu_gemm_mid_batch_tiles(nat):
             nat.dbg_gemm(a, w, bias, epi=4 + 96 + 2048, bm=bm, bn=bn, splitk=1, out=xs)
             slab = nat.dbg_gemm(a, w, None, epi=4 + 96, bm=bm, bn=bn, splitk=1)[0]
             assert torch.equal(xs, (x0 + slab) + bias), (M, N, K, bm, bn)
+    # round 6: from four m-tiles up the slab GEMMs deal K SLICES to groups of XCDs (schedule 4 in gemm.h: one-dimensional grid, the slab index
+    # comes from the workgroup id) -- every slab holds exactly its K range, for 2 / 4 / 8 slices, ragged M and N, more n-tiles than XCDs in a group
+    M, N, K = 520, 328, 1024
+    a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
+    w = torch.from_numpy((0.1 * rng.standard_normal((N, K))).astype(np.float32)).to(torch.bfloat16)
+    for (bm, bn) in ((132, 64), (136, 128)):
+        for sk in (2, 4, 8):
+            slabs = nat.dbg_gemm(a, w, None, epi=4 + 96, bm=bm, bn=bn, splitk=sk).numpy()
+            kk = K // sk
+            for z in range(sk):
+                ref = a[:, z * kk:(z + 1) * kk].float().numpy() @ w[:, z * kk:(z + 1) * kk].float().numpy().T
+                assert np.abs(slabs[z] - ref).max() < 2e-3 * np.abs(ref).max(), (bm, bn, sk, z)
     # the engine's own tile choice in the mid range: a slab GEMM (K split allowed), a bf16 GEMM and wide fp32 rows
     for (M, N, K, epi) in ((200, 256, 1024, 4), (500, 384, 256, 0), (300, 8192, 128, 3)):
         a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(torch.bfloat16)
