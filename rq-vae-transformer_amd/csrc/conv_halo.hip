@@ -20,6 +20,23 @@
 #include "gemm.h"
 #include "rq_common.h"
 #include "vae_kernels.h"
+#ifndef RQ_CONV_NT            // A/B switch, cache policy of the activations (each layer's output is GBs per chunk, read once by the next layer):
+#define RQ_CONV_NT 0          // 1 = output stores non-temporal, 2 = + the halo-piece and residual loads
+#endif
+static __device__ __forceinline__ rq_u128 ld128_act(const void* p) {
+#if RQ_CONV_NT >= 2
+    return ld128_nt(p);
+#else
+    return ld128(p);
+#endif
+}
+static __device__ __forceinline__ void st128_act(void* p, rq_u128 v) {
+#if RQ_CONV_NT >= 1
+    st128_nt(p, v);
+#else
+    st128(p, v);
+#endif
+}
 
 struct ConvHaloArgs {
     const bf16_t* x;        // NHWC [B][H][W][Cin] raw (pre-norm) activation, or already-activated when gn == null
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
             const int gy = (UPS ? ty0 >> 1 : ty0) + hy - 1, gx = (UPS ? tx0 >> 1 : tx0) + hx - 1;
             const int cy = gy < 0 ? 0 : (gy >= Hs ? Hs - 1 : gy), cx = gx < 0 ? 0 : (gx >= Ws ? Ws - 1 : gx);
             hd[it] = (unsigned)(cy * Ws + cx);
-            rh[it] = ld128(gX + (x_img + hd[it] * cin2));
+            rh[it] = ld128_act(gX + (x_img + hd[it] * cin2));
             hy += (NTH / 8) / PW; hx += (NTH / 8) % PW;
             if (hx >= PW) { hx -= PW; ++hy; }
         }
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
     auto h_ok = [&](int it) { return (hd[it] >> 29) & 1u; };
     auto h_loff = [&](int it) { return ((hd[it] >> 16) & 0x1fffu) << 4; };
     auto h_goff = [&](int it) { return x_img + (hd[it] & 0xffffu) * cin2; };
-    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
+    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128_act(gX + (h_goff(it) + (unsigned)c * 128u)); };
 
     unsigned w_loff[W_IT];
 #pragma unroll
@@ -450,8 +467,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                     // two pieces per tap in the FIRST four taps: the tile is an old activation (HBM, not the L2), and a piece fetched
                     // in tap 8 was still on its way when the epilogue wanted it (~1200 cycles of the epilogue, barrier timeline in
                     // profiles/r03_conv_halo_barrier_timeline.txt)
-                    rr[2 * tap] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap) * io_step));
-                    rr[2 * tap + 1] = ld128((const char*)rsrc + (io_off0 + (unsigned)(2 * tap + 1) * io_step));
+                    rr[2 * tap] = ld128_act((const char*)rsrc + (io_off0 + (unsigned)(2 * tap) * io_step));
+                    rr[2 * tap + 1] = ld128_act((const char*)rsrc + (io_off0 + (unsigned)(2 * tap + 1) * io_step));
                 }
             };
             // DMA form: where the tap's ordinary loads stand relative to its weight request (which follows the first k-step).  The
@@ -637,7 +654,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         } else {
             u = ld128(sT + ((tid >> 4) + HT_W * k) * LDR + (tid & 15) * 16);
         }
-        st128((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
+        st128_act((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
         if (p.stats) rq_stats_piece(u, gs_, gq_);
     }
     if (p.stats) {                                  // uniform
@@ -814,7 +831,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
     const char* gWt = (const char*)p.w;
 
     f32x4 gs[4];
-    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128(gX + (h_goff(it) + (unsigned)c * 128u)); };
+    auto load_halo_piece = [&](int c, rq_u128* rh, int it) { rh[it] = ld128_act(gX + (h_goff(it) + (unsigned)c * 128u)); };
     auto load_gs = [&](int c) {
         if (FUSE_GN) {
 #pragma unroll
@@ -1002,7 +1019,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 const int t_use = FIRST + it / PPT, t_load = t_use >= AHEAD ? t_use - AHEAD : 0;
                 if (t_load == tap) load_halo_piece(LAST ? 0 : c + 1, rh, it);
             }
-            if (LAST && RES && tap >= 1) rr[tap - 1] = ld128((const char*)p.resid + (io_off0 + (unsigned)(tap - 1) * io_step));
+            if (LAST && RES && tap >= 1) rr[tap - 1] = ld128_act((const char*)p.resid + (io_off0 + (unsigned)(tap - 1) * io_step));
             rq_sched_barrier();
             const bool ptap = tap >= FIRST;
             static_assert(PPT == 1 || !FUSE_GN, "the fused form normalises one patch piece per tap");
@@ -1089,7 +1106,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
 #pragma unroll
         for (int k = 0; k < R_IT; ++k) {
             const rq_u128 u = ld128(sT + ((tid_o >> 4) + HT_W * k) * PK_LDR + (tid_o & 15) * 16);
-            st128((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
+            st128_act((char*)p.out + (io_off0 + (unsigned)k * io_step), u);
             if (p.stats) rq_stats_piece(u, gs_, gq_);
         }
         if (p.stats) {                              // uniform; same reduction as conv3x3_halo_kernel

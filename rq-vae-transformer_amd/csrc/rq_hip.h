@@ -253,6 +253,18 @@ static __device__ __forceinline__ int wave_sum_i(int v) {
 struct __attribute__((aligned(16))) rq_u128 { uint32_t x, y, z, w; };
 static __device__ __forceinline__ rq_u128 ld128(const void* p) { return *(const rq_u128*)p; }
 static __device__ __forceinline__ void st128(void* p, rq_u128 v) { *(rq_u128*)p = v; }
+// non-temporal forms for data that streams through once per launch (KV cache, activations beyond any cache): same values, another cache policy
+static __device__ __forceinline__ rq_u128 ld128_nt(const void* p) {
+    typedef unsigned rq_v4u_t __attribute__((ext_vector_type(4)));
+    const rq_v4u_t v = __builtin_nontemporal_load((const rq_v4u_t*)p);
+    rq_u128 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+}
+static __device__ __forceinline__ void st128_nt(void* p, rq_u128 v) {
+    typedef unsigned rq_v4u_t __attribute__((ext_vector_type(4)));
+    rq_v4u_t u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    __builtin_nontemporal_store(u, (rq_v4u_t*)p);
+}
 static __device__ __forceinline__ rq_u128 zero128() { rq_u128 z; z.x = z.y = z.z = z.w = 0; return z; }
 static __device__ __forceinline__ bf16x8 as_bf16x8(rq_u128 v) {
     union { rq_u128 u; bf16x8 b; } c; c.u = v; return c.b;

@@ -205,8 +205,42 @@ static __device__ __forceinline__ void unpack8(rq_u128 u, float* f) {
 // adds 0.0053 max / 0.00063 mean to the logits, what bf16 storage itself adds); V stays bf16.  This token's own key is used as it
 // comes out of the qkv GEMM (bf16), like the bf16 path; it is quantised only on its way into the cache.
 struct __attribute__((aligned(8))) rq_u64w { uint32_t x, y; };
+// Cache policy of the KV cache traffic.  A decode-step launch reads every cached key / value of a layer exactly once (4 GB at 10752 images) and
+// nothing reads them again before the next position: with the default policy these lines displace the operands that ARE re-read (weights, the
+// residual stream).  RQ_ATTN_NT=1 (default): non-temporal loads -- measured 4.9 -> 5.5 TB/s on the decode attention and +2.2 % on the whole step at
+// 10752 images (profiles/r06_attn_nt_ab.txt).  RQ_ATTN_NT_ST: the appends likewise (A/B switch).
+#ifndef RQ_ATTN_NT
+#define RQ_ATTN_NT 1
+#endif
+#ifndef RQ_ATTN_NT_ST
+#define RQ_ATTN_NT_ST 0
+#endif
+static __device__ __forceinline__ rq_u128 ld128_kv(const void* p) {
+#if RQ_ATTN_NT
+    return ld128_nt(p);
+#else
+    return ld128(p);
+#endif
+}
+static __device__ __forceinline__ void st128_kv(void* p, rq_u128 v) {
+#if RQ_ATTN_NT_ST
+    st128_nt(p, v);
+#else
+    st128(p, v);
+#endif
+}
 static __device__ __forceinline__ rq_u64w ld64(const void* p) { return *(const rq_u64w*)p; }
 static __device__ __forceinline__ void st64(void* p, rq_u64w v) { *(rq_u64w*)p = v; }
+static __device__ __forceinline__ rq_u64w ld64_kv(const void* p) {        // 8-bit cache rows (RQAMD_KV=int8k / int8kv): the same policy
+#if RQ_ATTN_NT
+    typedef unsigned rq_v2u_t __attribute__((ext_vector_type(2)));
+    const rq_v2u_t v = __builtin_nontemporal_load((const rq_v2u_t*)p);
+    rq_u64w r; r.x = v.x; r.y = v.y;
+    return r;
+#else
+    return ld64(p);
+#endif
+}
 // the 8 lanes of a key group hold its 64 components, 8 bf16 each: bytes of this lane's chunk + the key's scale (uniform in the group)
 static __device__ __forceinline__ rq_u64w quant_key_chunk(rq_u128 kbf, float& scale) {
     float kf[8];
@@ -316,10 +350,10 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
             if constexpr (KQ) {
                 // cached keys only (rows j >= t are masked or served by the self score): 8 bytes per lane + the key's scale
-                kr8[i][jj] = ld64(kc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
+                kr8[i][jj] = ld64_kv(kc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
                 ksv[i][jj] = ksc[i][j < t ? j : tprev];
             } else {
-                kr[i][jj] = ld128((j >= t) ? (qrow[i] + E + cc * 8) : (kc[i] + off));
+                kr[i][jj] = ld128_kv((j >= t) ? (qrow[i] + E + cc * 8) : (kc[i] + off));
             }
         }
     }
@@ -331,10 +365,10 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             const int j = jj * 8 + g;
             const long off = (long)(j < t ? j : tprev) * kvs + cc * 8;
             if constexpr (VQ) {
-                vr8[i][jj] = ld64(vc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
+                vr8[i][jj] = ld64_kv(vc8[i] + (long)(j < t ? j : tprev) * 64 + cc * 8);
                 vsv[i][jj] = vsc[i][j < t ? j : tprev];
             } else {
-                vr[i][jj] = ld128((j >= t) ? (qrow[i] + 2 * E + cc * 8) : (vc[i] + off));
+                vr[i][jj] = ld128_kv((j >= t) ? (qrow[i] + 2 * E + cc * 8) : (vc[i] + off));
             }
         }
     }
@@ -349,10 +383,10 @@ static __device__ __forceinline__ void attn_run(const AttnDecodeArgs& p, int lan
             if constexpr (VQ) {                                                  // (lanes 8 .. 15 just quantised the value chunk they hold)
                 if (lane >= 8 && lane < 16) st64(vc8[i] + (long)t * 64 + cc * 8, kb);
                 if (lane == 8) vsc[i][t] = s_app;
-            } else if (lane >= 8 && lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+            } else if (lane >= 8 && lane < 16) st128_kv(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
         } else {
-            if (lane < 8) st128(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
-            else if (lane < 16) st128(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+            if (lane < 8) st128_kv(kc[i] + (long)t * kvs + cc * 8, kv_new[i]);
+            else if (lane < 16) st128_kv(vc[i] + (long)t * kvs + cc * 8, kv_new[i]);
         }
     }
 
@@ -510,13 +544,13 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
     float ksv[(KQ && T > 0) ? T : 1], vsv[(VQ && T > 0) ? T : 1];
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        if constexpr (KQ) { kr8[j] = ld64(kc8 + j * 64); ksv[j] = ksc[j]; }
-        else kr[j] = ld128(kc + j * 64);
+        if constexpr (KQ) { kr8[j] = ld64_kv(kc8 + j * 64); ksv[j] = ksc[j]; }
+        else kr[j] = ld128_kv(kc + j * 64);
     }
 #pragma unroll
     for (int j = 0; j < T; ++j) {
-        if constexpr (VQ) { vr8[j] = ld64(vc8 + j * 64); vsv[j] = vsc[j]; }
-        else vr[j] = ld128(vc + j * 64);
+        if constexpr (VQ) { vr8[j] = ld64_kv(vc8 + j * 64); vsv[j] = vsc[j]; }
+        else vr[j] = ld128_kv(vc + j * 64);
     }
     if constexpr (KQ) {                            // append: key as bytes + scale (every lane takes part in the group reduction)
         float s_app;
@@ -530,11 +564,11 @@ static __device__ __forceinline__ void attn_small_run(const AttnDecodeArgs& p, l
             if constexpr (VQ) {
                 st64(vc8 + T * 64, vb);
                 if (cc == 0) vsc[T] = s_appv;
-            } else st128(vc + T * 64, vn);
+            } else st128_kv(vc + T * 64, vn);
         }
     } else if (valid) {                            // append this token's k / v
-        st128(kc + T * 64, kn);
-        st128(vc + T * 64, vn);
+        st128_kv(kc + T * 64, kn);
+        st128_kv(vc + T * 64, vn);
     }
     float qf[8], sc[T + 1];
     unpack8(qv, qf);
@@ -1035,6 +1069,9 @@ int rq_launch_add_int(int* p, int v, hipStream_t s) {
 
 // =================================================================================================
 // on-device sampler: temperature, top-k, NaN scrub, softmax, top-p, renormalise, one draw per row
+#ifndef RQ_SMP_NT             // A/B switch: the logits rows of sample_topk_kernel (read once) with the non-temporal policy
+#define RQ_SMP_NT 0
+#endif
 constexpr int SMP_T = 256;    // threads per row: 4 wavefronts keep block barriers cheap (the first version used 1024
                               // threads and spent ~5 us per search iteration in 16-wave barriers)
 constexpr int SMP_VPT = 64;   // probabilities per thread held in registers during the top-p search (V <= 16384)
@@ -1471,7 +1508,11 @@ __global__ __launch_bounds__(SMP_T) void sample_topk_kernel(SampleArgs p) {
 #pragma unroll
     for (int j = 0; j < SMP_VPT / 4; ++j) {
         const int i4 = tid + SMP_T * j;
+#if RQ_SMP_NT
+        const f32x4 v = __builtin_nontemporal_load((const f32x4*)(lg + (long)(i4 < V4 ? i4 : V4 - 1) * 4));
+#else
         const f32x4 v = *(const f32x4*)(lg + (long)(i4 < V4 ? i4 : V4 - 1) * 4);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float x = scale ? v[e] / p.temperature : v[e];            // utils.py:96-97
