@@ -856,7 +856,7 @@ def main(argv=None):
                                   'algorithmic_GFLOP_per_image': efl / 1e9,
                                   'what': 'RQVAE.get_codes over 256 images: conv / attention-GEMM FLOPs of Encoder.forward (modules.py:73-98) over the '
                                           'device time of the whole call (the fp32 residual quantiser, ~11 % of it, included in the time, not in the '
-                                          'FLOPs); kernel shares: profiles/r05_encode_kernel_stats.md'}
+                                          'FLOPs); kernel shares: profiles/r06_encode_kernel_stats.md'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
