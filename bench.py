@@ -935,6 +935,42 @@ def main(argv=None):
             else:
                 os.environ['RQAMD_KV'] = kv_before
 
+    # ---- the opt-in fp16 RQ-VAE engine (RQAMD_VAE=fp16: same kernels, IEEE fp16 storage; tests/test_gpu_parity.py::test_vae_fp16_engine has its
+    # parity) next to the bf16 default: decode_code of 1024 code maps, measured live
+    vae_formats = None
+    if rank == 0 and world == 1 and args.formats and not args.overlap and os.environ.get('RQAMD_VAE', 'bf16') == 'bf16':
+        vae_formats = []
+        vae_before = os.environ.get('RQAMD_VAE')
+        try:
+            g = torch.Generator(device='cpu').manual_seed(5)
+            codes_f = torch.randint(0, vcfg['hparams']['n_embed'], (1024, 8, 8, 4), generator=g).to(device)
+            for fmt in ('bf16', 'fp16'):
+                os.environ['RQAMD_VAE'] = fmt
+                vae3, ar_tmp, _ = presets.build(args.model, device=device, seed=0)
+                del ar_tmp
+                vae3.decode_code(codes_f)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(2):
+                    vae3.decode_code(codes_f)
+                e1.record()
+                torch.cuda.synchronize()
+                vae_formats.append({'vae': fmt, 'batch': 1024, 'decode_ms_per_image': e0.elapsed_time(e1) / (2 * 1024)})
+                if vae3._engine is not None:
+                    vae3._engine.close()
+                    vae3._engine = None
+                del vae3
+                torch.cuda.empty_cache()
+        except Exception as e:
+            print(f'bench.py: RQ-VAE storage-format comparison failed: {e!r}', file=sys.stderr)
+            vae_formats.append({'error': repr(e)})
+        finally:
+            if vae_before is None:
+                os.environ.pop('RQAMD_VAE', None)
+            else:
+                os.environ['RQAMD_VAE'] = vae_before
+
     if rank == 0:
         n_img = world * B * args.steps
         value = n_img / elapsed
@@ -977,7 +1013,7 @@ def main(argv=None):
             'decode_ms_per_image': t_dec / (args.steps * B) if not args.overlap else None,
             'verified': None if verify is None else verify['verified'], 'verify': verify,
             'roofline': roofline, 'roofline_attn': roofline_attn, 'roofline_decode': roofline_decode,
-            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'kv_cache_formats': kv_formats, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
+            'step_frac_of_mfma_peak': step_frac, 'batch_sweep': sweep, 'baseline_8gpu_models_per_gpu_point': also, 'kv_cache_formats': kv_formats, 'vae_formats': vae_formats, 'per_image_decode': pid, 'per_image_recon': pir, 'roofline_rq': rqr, 'cpu_baseline': cpu, 'rqvae_encode': enc,
         }
         # ---- flat scalars: the driver's record keeps the scalar members of `roofline` / `cpu_baseline` / `config` and only the
         # NAMES of other top-level keys, so everything this repo claims from the line is repeated as plain numbers -- at the top level and inside `roofline`

@@ -18,9 +18,11 @@
  * (BASELINE.json's compute dtype; the default everywhere).  librqamd_f16.so is the SAME source compiled with -DRQ_F16=1
  * (csrc/rq_hip.h): IEEE fp16 storage instead, fp32 accumulation / residual stream / LayerNorm / softmax / logits as before --
  * what the reference's `amp=True` (fp16 autocast, rqvae/models/rqtransformer/transformers.py:21,206; main_sampling_fid.py:216)
- * computes in.  It exports the rqamd_rqt_* entry points below with identical signatures and meaning, plus rqamd_abi_version /
- * rqamd_last_error / rqamd_dbg_set_row_scale; the RQ-VAE engine and the quantiser exist in librqamd.so only.  Values beyond
- * 65504 become inf in fp16 storage, as in torch.float16.
+ * computes in.  It exports the rqamd_rqt_* and (since the end of round 6) the rqamd_vae_* entry points below with identical signatures
+ * and meaning, plus rqamd_abi_version / rqamd_last_error / rqamd_dbg_set_row_scale; the quantiser (fp32 arithmetic) exists in
+ * librqamd.so only.  The fp16 RQ-VAE engine is opt-in on the Python side (RQAMD_VAE=fp16): three more mantissa bits in every stored
+ * activation and weight -- z_e and pixels ~8 x closer to the fp32 reference -- for ~5 % more decode time.  Values beyond 65504 become
+ * inf in fp16 storage, as in torch.float16.
  */
 #ifndef RQAMD_H
 #define RQAMD_H

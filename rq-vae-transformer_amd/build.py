@@ -11,11 +11,12 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'librqamd.so')
 SOURCES = ['api.hip', 'gemm.hip', 'quantize.hip', 'rqt_kernels.hip', 'engine_rqt.hip', 'vae_kernels.hip', 'conv_halo.hip', 'engine_vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-I', CSRC]
-# librqamd_f16.so: the RQ-Transformer engine once more with IEEE fp16 as the 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1) -- what
-# RQTransformer.sample(amp=True) / forward(amp=True) run on, as the reference's fp16 autocast does (transformers.py:21,206).  Same C ABI
-# (the rqamd_rqt_* entry points, rqamd_abi_version, rqamd_last_error); the RQ-VAE engine and the quantiser are not in it.
+# librqamd_f16.so: the two engines once more with IEEE fp16 as the 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1) -- what
+# RQTransformer.sample(amp=True) / forward(amp=True) run on, as the reference's fp16 autocast does (transformers.py:21,206), and what the
+# opt-in RQAMD_VAE=fp16 RQ-VAE engine runs on.  Same C ABI (the rqamd_rqt_* / rqamd_vae_* entry points, rqamd_abi_version,
+# rqamd_last_error); the quantiser (fp32 arithmetic) is not in it.
 OUT_F16 = os.path.join(HERE, 'librqamd_f16.so')
-SOURCES_F16 = ['api.hip', 'gemm.hip', 'rqt_kernels.hip', 'engine_rqt.hip']
+SOURCES_F16 = ['api.hip', 'gemm.hip', 'rqt_kernels.hip', 'engine_rqt.hip', 'vae_kernels.hip', 'conv_halo.hip', 'engine_vae.hip']
 
 
 def _newer(a, b):

@@ -63,7 +63,7 @@ static __device__ __forceinline__ void rq_stats_piece(const rq_u128& u, float (&
     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        sum[e] = rq_dot2_bf16(w[e], 0x3f803f80u, sum[e]);
+        sum[e] = rq_dot2_bf16(w[e], RQ_ONE_X2, sum[e]);
         sq[e] = rq_dot2_bf16(w[e], w[e], sq[e]);
     }
 }
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         if (FUSE_GN) {
             // 8 channels of this image: y = silu(x * scale + shift), (scale, shift) pre-multiplied by log2 e (rq_silu_l2)
             float f[8];
-            f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-            f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-            f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-            f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+            rq_unpack2(v.x, f[0], f[1]);
+            rq_unpack2(v.y, f[2], f[3]);
+            rq_unpack2(v.z, f[4], f[5]);
+            rq_unpack2(v.w, f[6], f[7]);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f32x4 ss = gs[e >> 1];                              // (scale, shift) x 2 channels
@@ -313,7 +313,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
         uint32_t& w = halo_word(rh, it, e);
         if (FUSE_GN) {
             const f32x4 ss = gs[e];                                       // (scale, shift) x 2 channels
-            const float a = fmaf(__uint_as_float(w << 16), ss[0], ss[1]), b = fmaf(__uint_as_float(w & 0xffff0000u), ss[2], ss[3]);
+            float wlo, whi;
+            rq_unpack2(w, wlo, whi);
+            const float a = fmaf(wlo, ss[0], ss[1]), b = fmaf(whi, ss[2], ss[3]);
             w = pack_bf16x2(rq_silu_l2(a), rq_silu_l2(b));
         }
         if (!h_ok(it)) w = 0u;                     // zero padding of the (normalised) input
@@ -619,8 +621,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (RES && !RF32) {
                     const uint32_t r0 = rres[i][j][q][0], r1 = rres[i][j][q][1];
-                    v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                    v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                    { float lo_, hi_; rq_unpack2(r0, lo_, hi_); v[0] += lo_; v[1] += hi_; }
+                    { float lo_, hi_; rq_unpack2(r1, lo_, hi_); v[2] += lo_; v[3] += hi_; }
                 }
                 struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
                 w2.a = pack_bf16x2(v[0], v[1]);
@@ -645,10 +647,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(ConvHaloArgs p) {
             const char* src = sT + ((tid >> 4) + HT_W * k) * LDF + (tid & 15) * 16;
             f32x4 a = *(const f32x4*)src, b = *(const f32x4*)(src + 256);
             const rq_u128 r = rr[k];
-            a[0] += __uint_as_float(r.x << 16); a[1] += __uint_as_float(r.x & 0xffff0000u);
-            a[2] += __uint_as_float(r.y << 16); a[3] += __uint_as_float(r.y & 0xffff0000u);
-            b[0] += __uint_as_float(r.z << 16); b[1] += __uint_as_float(r.z & 0xffff0000u);
-            b[2] += __uint_as_float(r.w << 16); b[3] += __uint_as_float(r.w & 0xffff0000u);
+            { float lo_, hi_; rq_unpack2(r.x, lo_, hi_); a[0] += lo_; a[1] += hi_; }
+            { float lo_, hi_; rq_unpack2(r.y, lo_, hi_); a[2] += lo_; a[3] += hi_; }
+            { float lo_, hi_; rq_unpack2(r.z, lo_, hi_); b[0] += lo_; b[1] += hi_; }
+            { float lo_, hi_; rq_unpack2(r.w, lo_, hi_); b[2] += lo_; b[3] += hi_; }
             u.x = pack_bf16x2(a[0], a[1]); u.y = pack_bf16x2(a[2], a[3]);
             u.z = pack_bf16x2(b[0], b[1]); u.w = pack_bf16x2(b[2], b[3]);
         } else {
@@ -847,10 +849,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
         rq_u128 v = rh[it];
         if (FUSE_GN) {
             float f[8];
-            f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-            f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-            f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-            f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+            rq_unpack2(v.x, f[0], f[1]);
+            rq_unpack2(v.y, f[2], f[3]);
+            rq_unpack2(v.z, f[4], f[5]);
+            rq_unpack2(v.w, f[6], f[7]);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f32x4 ss = gs[e >> 1];
@@ -933,7 +935,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                 uint32_t& w = ks == 0 ? rhp[pit].x : ks == 1 ? rhp[pit].y : ks == 2 ? rhp[pit].z : rhp[pit].w;
                 rq_opaque_u(w);
                 const f32x4 ss = gs[ks];
-                const float ga = fmaf(__uint_as_float(w << 16), ss[0], ss[1]), gb = fmaf(__uint_as_float(w & 0xffff0000u), ss[2], ss[3]);
+                float wlo, whi;
+                rq_unpack2(w, wlo, whi);
+                const float ga = fmaf(wlo, ss[0], ss[1]), gb = fmaf(whi, ss[2], ss[3]);
                 w = pack_bf16x2(rq_silu_l2(ga), rq_silu_l2(gb));
                 if (!h_ok(pit)) w = 0u;
                 rq_opaque_u(w);
@@ -1086,8 +1090,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_pk_kernel(ConvHaloArgs p,
                     if (RES) {
                         const uint32_t* rp = (const uint32_t*)(sT + ml * PK_LDR + nl * 2);
                         const uint32_t r0 = rp[0], r1 = rp[1];
-                        v[0] += __uint_as_float(r0 << 16); v[1] += __uint_as_float(r0 & 0xffff0000u);
-                        v[2] += __uint_as_float(r1 << 16); v[3] += __uint_as_float(r1 & 0xffff0000u);
+                        { float lo_, hi_; rq_unpack2(r0, lo_, hi_); v[0] += lo_; v[1] += hi_; }
+                        { float lo_, hi_; rq_unpack2(r1, lo_, hi_); v[2] += lo_; v[3] += hi_; }
                     }
                     struct __attribute__((aligned(8))) u64 { uint32_t a, b; } w2;
                     w2.a = pack_bf16x2(v[0], v[1]);
@@ -1263,10 +1267,10 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
             rq_u128 v = r[k];
             if (FUSE_GN) {
                 float f[8];
-                f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-                f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-                f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-                f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+                rq_unpack2(v.x, f[0], f[1]);
+                rq_unpack2(v.y, f[2], f[3]);
+                rq_unpack2(v.z, f[4], f[5]);
+                rq_unpack2(v.w, f[6], f[7]);
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     const f32x4 ss = gs[e >> 1];

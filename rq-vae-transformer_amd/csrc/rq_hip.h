@@ -77,6 +77,12 @@ static inline __host__ __device__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 #endif
 #endif
+// 1.0 in both halves of a packed word of the 16-bit storage type
+#if RQ_F16
+#define RQ_ONE_X2 0x3c003c00u
+#else
+#define RQ_ONE_X2 0x3f803f80u
+#endif
 // the two 16-bit values of a packed word as floats (bf16: a shift and a mask)
 static inline __host__ __device__ void rq_unpack2(uint32_t w, float& lo, float& hi) {
 #if RQ_F16

@@ -12,10 +12,10 @@
 #include "vae_kernels.h"
 
 static __device__ __forceinline__ void unpack8v(rq_u128 u, float* f) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    rq_unpack2(u.x, f[0], f[1]);
+    rq_unpack2(u.y, f[2], f[3]);
+    rq_unpack2(u.z, f[4], f[5]);
+    rq_unpack2(u.w, f[6], f[7]);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -466,8 +466,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     if (resid) {
         const uint32_t* rp = (const uint32_t*)(resid + i4);
         const uint32_t r0 = rp[0], r1 = rp[1];
-        acc[0] += __uint_as_float(r0 << 16); acc[1] += __uint_as_float(r0 & 0xffff0000u);
-        acc[2] += __uint_as_float(r1 << 16); acc[3] += __uint_as_float(r1 & 0xffff0000u);
+        { float lo_, hi_; rq_unpack2(r0, lo_, hi_); acc[0] += lo_; acc[1] += hi_; }
+        { float lo_, hi_; rq_unpack2(r1, lo_, hi_); acc[2] += lo_; acc[3] += hi_; }
     }
     if (out_f32) {
         *(f32x4*)((float*)out + i4) = acc;

@@ -11,8 +11,9 @@ import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, 'librqamd.so')
-# the RQ-Transformer engine compiled once more with IEEE fp16 as its 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1; build.py): what
-# RQTransformer.sample(amp=True) / forward(amp=True) run on.  Same entry points, same ABI version; RqtEngine(half=True) binds to it.
+# the two engines compiled once more with IEEE fp16 as their 16-bit storage type (csrc/rq_hip.h, -DRQ_F16=1; build.py): what
+# RQTransformer.sample(amp=True) / forward(amp=True) and the opt-in RQAMD_VAE=fp16 RQ-VAE run on.  Same entry points, same ABI version;
+# RqtEngine(half=True) / VaeEngine(half=True) bind to it.
 LIB16_PATH = os.path.join(_PKG, 'librqamd_f16.so')
 
 _lib = None
@@ -100,7 +101,7 @@ _SIGS = {
 EXPORTS = tuple(_SIGS)
 
 
-EXPORTS_F16 = tuple(n for n in _SIGS if n.startswith('rqamd_rqt_')) + ('rqamd_abi_version', 'rqamd_last_error', 'rqamd_dbg_set_row_scale')
+EXPORTS_F16 = tuple(n for n in _SIGS if n.startswith('rqamd_rqt_') or n.startswith('rqamd_vae_')) + ('rqamd_abi_version', 'rqamd_last_error', 'rqamd_dbg_set_row_scale')
 
 
 def _bind(path, names=None):
@@ -495,7 +496,7 @@ class _Engine:
 class VaeEngine(_Engine):
     _create, _destroy, _set = 'rqamd_vae_create', 'rqamd_vae_destroy', 'rqamd_vae_set_param'
 
-    def __init__(self, ddconfig, embed_dim, device='cuda'):
+    def __init__(self, ddconfig, embed_dim, device='cuda', half=False):
         c = VaeConfig()
         c.ch, c.out_ch, c.in_channels = ddconfig['ch'], ddconfig['out_ch'], ddconfig['in_channels']
         c.resolution, c.z_channels, c.num_res_blocks = ddconfig['resolution'], ddconfig['z_channels'], ddconfig['num_res_blocks']
@@ -509,7 +510,7 @@ class VaeEngine(_Engine):
             c.attn_resolutions[i] = int(a)
         c.embed_dim, c.double_z = int(embed_dim), int(bool(ddconfig.get('double_z', True)))
         self.cfg = c
-        super().__init__(c, device)
+        super().__init__(c, device, half=half)      # half: the fp16 build of the engine (opt-in RQAMD_VAE=fp16, see models/rqvae/rqvae.py)
         if not ddconfig.get('resamp_with_conv', True):      # bare nearest upsample / average pool (layers.py:20-57; no released config)
             check(self._L.rqamd_vae_set_option(self._h, b'resamp_with_conv', 0), self._L)
 
@@ -523,7 +524,7 @@ class VaeEngine(_Engine):
         self._on_my_device(z_q)
         B = z_q.shape[0]
         out = torch.empty((B, c.out_ch, c.resolution, c.resolution), dtype=torch.float32, device=z_q.device)
-        self._run(lambda: lib().rqamd_vae_decode(self._h, ptr(z_q, torch.float32), B, ptr(out), stream_of(z_q)))
+        self._run(lambda: self._L.rqamd_vae_decode(self._h, ptr(z_q, torch.float32), B, ptr(out), stream_of(z_q)))
         return out
 
     def encode(self, x):
@@ -535,7 +536,7 @@ class VaeEngine(_Engine):
         B = x.shape[0]
         lr = c.resolution >> (c.n_levels - 1)
         out = torch.empty((B, lr, lr, c.embed_dim), dtype=torch.float32, device=x.device)
-        self._run(lambda: lib().rqamd_vae_encode(self._h, ptr(x, torch.float32), B, ptr(out), stream_of(x)))
+        self._run(lambda: self._L.rqamd_vae_encode(self._h, ptr(x, torch.float32), B, ptr(out), stream_of(x)))
         return out
 
 

@@ -182,7 +182,13 @@ class RQVAE(Stage1Model):
             self._engine = None
         if self._engine is None or sig != self._engine_sig:
             if self._engine is None:
-                self._engine = _native.VaeEngine(self.ddconfig, self.embed_dim, device=dev)
+                # opt-in storage type of the engine's activations and weights, fixed when the engine is created (like RQAMD_KV): bf16
+                # (default, BASELINE.json's dtype) or IEEE fp16 -- three more mantissa bits at the same MFMA rate, for callers who
+                # want the encoder's z_e (and with it get_codes) closer to the fp32 reference; fp32 accumulation / GroupNorm either way
+                fmt = os.environ.get('RQAMD_VAE', 'bf16') or 'bf16'
+                if fmt not in ('bf16', 'fp16'):
+                    raise ValueError(f'RQAMD_VAE={fmt} (bf16 or fp16)')
+                self._engine = _native.VaeEngine(self.ddconfig, self.embed_dim, device=dev, half=(fmt == 'fp16'))
             push_all(self, self._engine, skip_prefixes=('quantizer.',))
             self._engine_sig = sig
         return self._engine

@@ -809,6 +809,43 @@ def test_vae_full_size_batch_golden(nat, golden):
     assert (~s0).mean() <= 0.04
 
 
+def test_vae_fp16_engine(nat, golden, monkeypatch):
+    """Opt-in RQAMD_VAE=fp16 (round 6): the RQ-VAE engine of librqamd_f16.so -- the same kernel sources with IEEE fp16 as the 16-bit storage
+    type (three more mantissa bits than bf16 at the same MFMA rate; fp32 accumulation / GroupNorm statistics as before).  Against the
+    reference's fp32 outputs on the released ImageNet shape: the encoder's z_e and the decoded pixels several times closer than the bf16
+    default, and with them the codes of get_codes (the bf16 encoder's error is what flips low-margin codes)."""
+    monkeypatch.setenv('RQAMD_VAE', 'fp16')
+    g = golden('vae_tiny.npz')
+    vae, _, _, _ = _models(C.VAE_TINY, None, int(g['seed']), 0)
+    assert vae._eng().half
+    err = np.abs(N(vae.decode_code(G(g['codes'], torch.long))) - g['decode_code'])
+    print('vae tiny, fp16 engine: decode_code max err %.4f mean %.5f' % (err.max(), err.mean()))
+    assert err.max() < 0.012 and err.mean() < 0.002
+    g = golden('vae_imagenet_batch.npz')
+    cfg = C.VAE_IMAGENET
+    vae, vparams, _, _ = _models(cfg, None, int(g['seed']), 0)
+    dec = N(vae.decode_code(G(g['codes'], torch.long)))
+    ref = g['decode_code'].astype(np.float32)
+    err = np.abs(dec - ref)
+    print(f'vae imagenet, fp16 engine: decode_code x4 max err {err.max():.4f} mean {err.mean():.5f} (bf16 default: 0.10-0.12 / 0.0069)')
+    assert err.max() < 0.04 and err.mean() < 0.002
+    rng = np.random.default_rng(int(g['data_seed']))
+    rng.integers(0, cfg[0]['n_embed'], (4, 8, 8, 4))
+    x = np.clip(rng.standard_normal((8, 3, 256, 256), dtype=np.float32), -1, 1)
+    z_e = N(vae.encode(G(x)))
+    ez = np.abs(z_e - g['z_e'])
+    print(f'vae imagenet, fp16 engine: encode x8 max err {ez.max():.4f} mean {ez.mean():.5f} (bf16 default: 0.0177 / 0.0025)')
+    assert ez.max() < 0.006 and ez.mean() < 0.0008
+    codes = N(vae.get_codes(G(x)))
+    same = codes == g['enc_codes']
+    print(f'vae imagenet, fp16 engine: get_codes x8 agreement over all codes {same.mean():.4f}, first depth {same[..., 0].mean():.4f} (bf16 default: 0.983 / 0.986)')
+    assert same.mean() > 0.99
+    monkeypatch.setenv('RQAMD_VAE', 'fp8')
+    from rqvae.models.rqvae import RQVAE
+    with pytest.raises(ValueError):
+        _models(C.VAE_TINY, None, 1, 0)[0].decode_code(G(golden('vae_tiny.npz')['codes'], torch.long))
+
+
 def test_vae_low_resolution_halo_rule(nat, golden, monkeypatch):
     """At 32 x 32 the 3x3 layers run through the halo kernel (fused GroupNorm, epilogue statistics) like the >= 64^2 ones, for
     every batch size (engine_vae.hip: halo_here -- the choice is a function of the layer only).  RQAMD_HALO_LOWRES=0 selects

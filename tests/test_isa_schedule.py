@@ -17,11 +17,11 @@ sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 import isa_summary  # noqa: E402
 
 
-def _asm(src, tmp_path_factory):
+def _asm(src, tmp_path_factory, extra=()):
     if not os.path.exists(HIPCC):
         pytest.skip('hipcc not available')
     out = str(tmp_path_factory.mktemp('isa') / (src + '.s'))
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, '-S', '--cuda-device-only',
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I', CSRC, *extra, '-S', '--cuda-device-only',
                            os.path.join(CSRC, src), '-o', out], stderr=subprocess.DEVNULL)
     return isa_summary.kernels(out)
 
@@ -29,6 +29,12 @@ def _asm(src, tmp_path_factory):
 @pytest.fixture(scope='module')
 def conv_kernels(tmp_path_factory):
     return _asm('conv_halo.hip', tmp_path_factory)
+
+
+@pytest.fixture(scope='module')
+def conv_kernels_f16(tmp_path_factory):
+    """the same source in the fp16 build of the library (-DRQ_F16=1: librqamd_f16.so, the opt-in fp16 RQ-VAE engine)"""
+    return _asm('conv_halo.hip', tmp_path_factory, ('-DRQ_F16=1',))
 
 
 @pytest.fixture(scope='module')
@@ -94,6 +100,18 @@ def test_halo_conv_weight_dma_waits_are_exact(conv_kernels, name):
     DMAs.  One too many and a wavefront passes the barrier with its part of the next unit still on the way (silent garbage on the GPU;
     the host emulator counts DMAs only); fewer and the wait also stands on loads that come from HBM.  Checked here on the instruction
     stream itself: a source edit that moves a load across a DMA, or a compiler that merges / splits / moves one, fails this."""
+    _check_weight_dma_waits(conv_kernels, name)
+
+
+@pytest.mark.parametrize('name', ['conv3x3_halo_kernel<1, 0, 0>', 'conv3x3_halo_kernel<1, 0, 1>', 'conv3x3_halo_kernel<0, 0, 0>',
+                                  'conv3x3_halo_kernel<0, 0, 1>', 'conv3x3_halo_kernel<0, 1, 0>'])
+def test_halo_conv_weight_dma_waits_are_exact_in_the_fp16_build(conv_kernels_f16, name):
+    """The same property of the instruction stream hipcc emits for the fp16 build (other conversion instructions around the same loads:
+    the hand-counted waits must fit that stream too)."""
+    _check_weight_dma_waits(conv_kernels_f16, name)
+
+
+def _check_weight_dma_waits(conv_kernels, name):
     taps = _tap_memory_ops(conv_kernels[name])
     checked = 0
     for i, ops in enumerate(taps):
