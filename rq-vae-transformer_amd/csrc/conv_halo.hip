@@ -23,6 +23,9 @@
 #ifndef RQ_CONV_NT            // A/B switch, cache policy of the activations (each layer's output is GBs per chunk, read once by the next layer):
 #define RQ_CONV_NT 0          // 1 = output stores non-temporal, 2 = + the halo-piece and residual loads
 #endif
+#ifndef RQ_CONVOUT_NT         // A/B switch: conv_out's input (4.3 GB per 255-image chunk, read once + halo) with the non-temporal policy
+#define RQ_CONVOUT_NT 0
+#endif
 static __device__ __forceinline__ rq_u128 ld128_act(const void* p) {
 #if RQ_CONV_NT >= 2
     return ld128_nt(p);
@@ -1255,7 +1258,11 @@ __global__ __launch_bounds__(O_NTH) void conv_out_halo_kernel(ConvOutArgs p) {
             if (hyx[k] == 0xffffu) continue;
             const int gy = d.ty0 + (int)(hyx[k] >> 8) - 1, gx = d.tx0 + (int)(hyx[k] & 255u) - 1;
             const int cy = gy < 0 ? 0 : (gy >= p.H ? p.H - 1 : gy), cx = gx < 0 ? 0 : (gx >= p.W ? p.W - 1 : gx);
+#if RQ_CONVOUT_NT
+            r[k] = ld128_nt(gX + ((((long)d.img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);
+#else
             r[k] = ld128(gX + ((((long)d.img * p.H + cy) * p.W + cx) * p.Cin + cq * 8) * 2);      // clamped: always readable
+#endif
         }
     };
     auto stage = [&](const Tile& d, const rq_u128* r, const f32x4* gs) {
