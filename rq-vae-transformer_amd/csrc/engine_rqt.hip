@@ -378,7 +378,11 @@ static int ensure_batch(rqamd_rqt* h, int B) {
     // (8-bit keys: half the bytes for K plus one fp32 scale per (row, head, position))
     const size_t kkb = h->kv_int8k ? al(brows * E * h->Tbody) : kvb, ksb = h->kv_int8k ? al(brows * (E / 64) * h->Tbody * 4) : 0;
     const size_t vvb = h->kv_int8v ? kkb : kvb, vsb = h->kv_int8v ? ksb : 0;
-    RQ_TRY(h->kv.reserve((kkb + ksb + vvb + vsb) * h->body.size() + 2 * kvh * h->head.size()));
+    // The KV workspace is uncached device memory (hipDeviceMallocUncached): every line of it is written once and read once per position, GBs
+    // apart -- nothing a cache could serve.  On top of the non-temporal loads of the attention kernels: 5.55 -> 5.67-5.76 TB/s on the decode
+    // attention, +0.45 % on the whole step at 10752 images, level at 64 / 500 (profiles/r06_kv_uncached_ab.txt).  RQAMD_KV_UNCACHED=0: plain hipMalloc.
+    static const bool kv_uncached = !(getenv("RQAMD_KV_UNCACHED") && atoi(getenv("RQAMD_KV_UNCACHED")) == 0);
+    RQ_TRY(h->kv.reserve((kkb + ksb + vvb + vsb) * h->body.size() + 2 * kvh * h->head.size(), kv_uncached ? hipDeviceMallocUncached : 0u));
     char* q = (char*)h->kv.p;
     for (auto& L : h->body) {
         L.kc = (bf16_t*)q; q += kkb; L.vc = (bf16_t*)q; q += vvb;

@@ -53,12 +53,17 @@ extern int g_rq_row_scale;     // diagnostics (api.hip): variant selection sees 
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
-    int reserve(size_t n) {
+    int reserve(size_t n, unsigned ext_flags = 0) {      // ext_flags != 0: hipExtMallocWithFlags (diagnostics: RQAMD_KV_UNCACHED)
         if (n <= bytes) return RQAMD_OK;
         if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
+        hipError_t e = ext_flags ? hipExtMallocWithFlags(&p, n, ext_flags) : hipMalloc(&p, n);
+        if (ext_flags && e != hipSuccess && e != hipErrorOutOfMemory) {      // a runtime without that memory type: the ordinary kind
+            (void)hipGetLastError();
+            p = nullptr;
+            e = hipMalloc(&p, n);
+        }
         if (e != hipSuccess) {
             // the runtime keeps a failed call as its "last error" until somebody reads it: clear it here, or the next
             // rq_check_launch (e.g. of the retried call, after the caller released cached memory) reports this stale failure

@@ -314,6 +314,8 @@ typedef void* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); memset(*p, 0xFF, n); return *p ? 0 : 2; }
+#define hipDeviceMallocUncached 0x3
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
