@@ -24,6 +24,9 @@
 #include <type_traits>
 #include "rq_hip.h"
 
+#ifndef RQ_EPI_ST_NT
+#define RQ_EPI_ST_NT 0
+#endif
 #ifndef RQ_TILED_W_NT        // weight DMAs of the LDS-DMA tiled kernels with the non-temporal policy (A/B switch)
 #define RQ_TILED_W_NT 0
 #endif
@@ -289,7 +292,11 @@ static __device__ __forceinline__ void rq_gemm_epilogue(const GemmArgs& p, f32x1
 #pragma unroll
             for (int k = 0; k < IT; ++k) u[k] = ld128(src + k * (RSTEP * LDR));
 #pragma unroll
+#if RQ_EPI_ST_NT            // A/B switch: whole-tile bf16 outputs (qkv, fc1 at large batch: read once by the next kernel) stored with the non-temporal policy
+            for (int k = 0; k < IT; ++k) st128_nt(o + (long)k * RSTEP * p.ldo, u[k]);
+#else
             for (int k = 0; k < IT; ++k) st128(o + (long)k * RSTEP * p.ldo, u[k]);
+#endif
             RQ_GT(5);
             return;
         }
